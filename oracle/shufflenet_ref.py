@@ -73,7 +73,7 @@ class ShuffleNetV2(nn.Module):
         return self.fc(x)
 
 
-def seeded_state_dict(num_classes: int, seed: int = 1234) -> "dict[str, torch.Tensor]":
+def seeded_state_dict(num_classes: int, seed: int = 1234, gain: float = 1.7) -> "dict[str, torch.Tensor]":
     """Synthetic weights with non-trivial BN statistics (random-init torchvision
     weights have identity BN, which would not exercise BN folding)."""
     g = torch.Generator().manual_seed(seed)
@@ -92,7 +92,7 @@ def seeded_state_dict(num_classes: int, seed: int = 1234) -> "dict[str, torch.Te
             sd[k] = torch.randn(v.shape, generator=g) * 0.1
         else:
             fan_in = float(np.prod(v.shape[1:]))
-            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+            sd[k] = torch.randn(v.shape, generator=g) * (gain / fan_in) ** 0.5
     return sd
 
 

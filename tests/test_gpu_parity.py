@@ -1,0 +1,436 @@
+"""GPU parity tests (``-m gpu``): every stage of the HIP path against the CPU oracle on the same
+seeded inputs, through the C-ABI.  Tolerances: bit-exact for the integer / decision work
+(NMS kept sets, ROI rectangles, PIL resize bytes); fp32 conv path <= 1e-3 (north_star);
+fp16 storage path compared with a documented looser bound.
+
+Nothing here reads /root/reference: models are seeded synthetic files of the reference's
+architecture written by litepi.ncnn_export.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng32():
+    from litepi import Engine
+    e = Engine(precision="fp32", max_batch=2, max_det=8400, num_classes=91)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng16():
+    from litepi import Engine
+    e = Engine(precision="fp16", max_batch=4, max_det=300, num_classes=91)
+    yield e
+    e.close()
+
+
+def _act(y, act):
+    if act == 1:
+        return y * torch.sigmoid(y)
+    if act == 2:
+        return torch.relu(y)
+    return y
+
+
+CONV_CASES = [
+    # k, stride, Cin, Cout, H, W, act, residual
+    (1, 1, 16, 16, 40, 40, 1, False),
+    (1, 1, 24, 16, 20, 24, 1, False),
+    (1, 1, 192, 64, 20, 20, 1, False),
+    (1, 1, 256, 128, 20, 20, 1, False),
+    (1, 1, 32, 8, 37, 19, 0, False),
+    (1, 1, 64, 96, 16, 16, 2, False),
+    (3, 1, 8, 8, 40, 40, 1, True),
+    (3, 1, 16, 16, 40, 40, 1, True),
+    (3, 1, 32, 64, 40, 40, 1, False),
+    (3, 1, 64, 64, 20, 20, 1, True),
+    (3, 1, 128, 32, 20, 20, 1, False),
+    (3, 1, 24, 24, 23, 45, 1, False),
+    (3, 1, 48, 48, 8, 8, 0, False),
+    (3, 2, 8, 16, 80, 80, 1, False),
+    (3, 2, 32, 64, 40, 40, 1, False),
+    (3, 2, 64, 128, 40, 40, 1, False),
+    (3, 2, 16, 32, 33, 47, 1, False),
+]
+
+
+@pytest.mark.parametrize("impl", [0, 1], ids=["mfma", "naive"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"k{c[0]}s{c[1]}_{c[2]}to{c[3]}_{c[4]}x{c[5]}" for c in CONV_CASES])
+def test_conv_fp32(eng32, case, impl):
+    k, s, cin, cout, H, W, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(2, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = _act(F.conv2d(x, w, b, stride=s, padding=k // 2), act)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    y = eng32.test_conv(x.numpy(), w.numpy(), b.numpy(), stride=s, act=act, res=None if res is None else res.numpy(), impl=impl)
+    err = np.abs(y - ref.numpy()).max()
+    assert err < 2e-5, f"max abs err {err}"
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"k{c[0]}s{c[1]}_{c[2]}to{c[3]}_{c[4]}x{c[5]}" for c in CONV_CASES])
+def test_conv_fp16(eng16, case):
+    k, s, cin, cout, H, W, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    # inputs rounded to fp16 first: the only differences left are accumulation order and the fp16 output rounding
+    x = torch.randn(2, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k)) ** 0.5).half().float()
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = _act(F.conv2d(x, w, b, stride=s, padding=k // 2), act)
+    res = torch.randn(ref.shape, generator=g).half().float() if use_res else None
+    if use_res:
+        ref = ref + res
+    y = eng16.test_conv(x.numpy(), w.numpy(), b.numpy(), stride=s, act=act, res=None if res is None else res.numpy())
+    err = np.abs(y - ref.numpy())
+    tol = 2e-3 + 2e-3 * np.abs(ref.numpy())  # one fp16 ulp of the output (2^-10 relative) + slack
+    assert (err <= tol).all(), f"max abs err {err.max()}"
+
+
+# ---------------------------------------------------------------------------- post-processing
+def _check_post(eng, out0, orig, ratio, pad, conf, iou, exp_boxes, exp_scores, exp_cls):
+    d = eng.test_postprocess(out0, orig, ratio, pad, conf, iou)
+    assert len(d) == len(exp_boxes), f"kept {len(d)} vs reference {len(exp_boxes)}"
+    if len(d) == 0:
+        return
+    boxes = np.stack([d["x1"], d["y1"], d["x2"], d["y2"]], 1)
+    assert np.array_equal(boxes, exp_boxes.astype(np.float32))
+    assert np.array_equal(d["det_conf"], exp_scores.astype(np.float32))
+    assert np.array_equal(d["det_class"], exp_cls.astype(np.int32))
+
+
+def test_postprocess_reference_goldens(eng32, golden_dir):
+    """decode-filter + NMS kernels vs outputs of the REFERENCE's own NCNNDetector.postprocess."""
+    g = np.load(os.path.join(golden_dir, "ref_postprocess.npz"))
+    i = 0
+    while f"c{i}_out0" in g.files:
+        oh, ow, r, p0, p1, conf, iou = g[f"c{i}_geom"]
+        _check_post(eng32, g[f"c{i}_out0"], (int(oh), int(ow)), r, (p0, p1), conf, iou, g[f"c{i}_boxes"], g[f"c{i}_scores"],
+                    g[f"c{i}_cls"])
+        i += 1
+    assert i == 8
+
+
+def test_nms_reference_goldens(eng32, golden_dir):
+    """NMS kernel vs the REFERENCE's nms_numpy kept indices (boxes fed through an identity geometry)."""
+    g = np.load(os.path.join(golden_dir, "ref_nms.npz"))
+    for key in [k[:-5] for k in g.files if k.endswith("_keep")]:
+        boxes, scores, keep = g[key + "_boxes"], g[key + "_scores"], g[key + "_keep"]
+        n = len(boxes)
+        # encode as cx,cy,w,h such that the kernel's xyxy reconstruction is exact: use integer-friendly values
+        # -> instead compare through the oracle on the same out0 (pinned to the reference in the CPU suite)
+        from oracle import postprocess_ref as P
+        out0 = np.zeros((5, n), np.float32)
+        out0[0] = (boxes[:, 0] + boxes[:, 2]) / 2
+        out0[1] = (boxes[:, 1] + boxes[:, 3]) / 2
+        out0[2] = boxes[:, 2] - boxes[:, 0]
+        out0[3] = boxes[:, 3] - boxes[:, 1]
+        out0[4] = scores
+        thr = float(g[key + "_thr"])
+        eb, es, ec = P.postprocess(out0, (640, 640), 1.0, (0.0, 0.0), 0.0001, thr)
+        _check_post(eng32, out0, (640, 640), 1.0, (0.0, 0.0), 0.0001, thr, eb, es, ec)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("nc", [1, 3])
+def test_postprocess_random_vs_oracle(eng32, seed, nc):
+    from oracle import postprocess_ref as P
+    rng = np.random.default_rng(seed)
+    A = 8400
+    out0 = np.zeros((4 + nc, A), np.float32)
+    centers = rng.uniform(30, 610, size=(40, 2))
+    pick = rng.integers(0, 40, A)
+    out0[0] = centers[pick, 0] + rng.normal(0, 5, A)
+    out0[1] = centers[pick, 1] + rng.normal(0, 5, A)
+    out0[2] = rng.uniform(8, 100, A)
+    out0[3] = rng.uniform(8, 100, A)
+    sc = rng.uniform(0, 1, size=(nc, A)).astype(np.float32) ** 3
+    out0[4:] = sc
+    for conf, geom in ((0.25, ((640, 640), 1.0, (0.0, 0.0))), (0.001, ((681, 1198), 640 / 1198, (0.0, 138.0))),
+                       (0.6, ((2048, 2048), 0.3125, (0.0, 0.0)))):
+        eb, es, ec = P.postprocess(out0, geom[0], geom[1], geom[2], conf, 0.45)
+        _check_post(eng32, out0, geom[0], geom[1], geom[2], conf, 0.45, eb, es, ec)
+
+
+def test_postprocess_ties_follow_documented_rule(eng32):
+    """Equal scores: higher candidate index first (oracle == HIP by definition; SURVEY 'NMS determinism')."""
+    from oracle import postprocess_ref as P
+    rng = np.random.default_rng(5)
+    A = 512
+    out0 = np.zeros((5, A), np.float32)
+    out0[0] = rng.uniform(100, 200, A); out0[1] = rng.uniform(100, 200, A)
+    out0[2] = rng.uniform(20, 60, A); out0[3] = rng.uniform(20, 60, A)
+    out0[4] = rng.choice(np.array([0.3, 0.5, 0.7, 0.9], np.float32), A)
+    eb, es, ec = P.postprocess(out0, (640, 640), 1.0, (0.0, 0.0), 0.25, 0.45)
+    _check_post(eng32, out0, (640, 640), 1.0, (0.0, 0.0), 0.25, 0.45, eb, es, ec)
+
+
+# ---------------------------------------------------------------------------- ROI resize / letterbox
+def test_roi_resize_bit_exact_vs_pillow(eng16):
+    from PIL import Image
+    from oracle import pil_resize_ref as R
+    rng = np.random.default_rng(3)
+    sizes = [(10, 10), (28, 27), (24, 24), (65, 73), (72, 84), (22, 23), (18, 21), (64, 64), (64, 30), (30, 64), (1, 1),
+             (7, 200), (200, 7), (129, 257), (500, 300), (63, 65), (640, 640), (2, 3)]
+    rois = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    out = eng16.test_roi_resize(rois)
+    for roi, got in zip(rois, out):
+        rgb = np.ascontiguousarray(roi[:, :, ::-1])
+        exp = np.array(Image.fromarray(rgb).resize((64, 64), Image.BILINEAR))
+        assert np.array_equal(R.resize_bilinear_u8(rgb, 64, 64), exp)
+        assert np.array_equal(got, exp), f"ROI {roi.shape}: max diff {np.abs(got.astype(int) - exp.astype(int)).max()}"
+
+
+@pytest.mark.parametrize("hw", [(640, 640), (480, 640), (640, 360), (681, 1198), (2048, 2048), (100, 37)])
+def test_letterbox_vs_oracle(eng16, hw):
+    from oracle import postprocess_ref as P
+    rng = np.random.default_rng(hw[0] * 7 + hw[1])
+    img = rng.integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+    exp, r, pad = P.letterbox(img, 640)
+    got, gr, gpad = eng16.test_letterbox(img)
+    assert got.shape == exp.shape == (640, 640, 3)
+    assert abs(gr - r) < 1e-6 and abs(gpad[0] - pad[0]) < 1e-4 and abs(gpad[1] - pad[1]) < 1e-4
+    assert np.array_equal(got, exp), f"max diff {np.abs(got.astype(int) - exp.astype(int)).max()}"
+
+
+# ---------------------------------------------------------------------------- detector forward
+def _oracle_out0(param, binf, imgs_bgr):
+    from oracle import ncnn_ref
+    layers = ncnn_ref.load_model(param, binf)
+    x = torch.from_numpy(imgs_bgr[..., ::-1].astype(np.float32) * np.float32(1 / 255.0)).permute(0, 3, 1, 2).contiguous()
+    return ncnn_ref.run_graph(layers, x)["out0"].numpy(), layers
+
+
+@pytest.mark.parametrize("preset", ["v1", "v2"])
+@pytest.mark.parametrize("impl", [0, 1], ids=["mfma", "naive"])
+def test_detector_fp32_out0(synth_models, preset, impl):
+    """configs[1]: detector only, fp32: out0 within 1e-3 of the CPU path (north_star tolerance):
+    abs 1e-3 on the score row, abs+rel 1e-3 on the box rows (values up to 640 px)."""
+    from litepi import Engine
+    param, binf = synth_models[preset]
+    rng = np.random.default_rng(0)
+    imgs = rng.integers(0, 256, (2, 640, 640, 3), dtype=np.uint8)
+    ref, _ = _oracle_out0(param, binf, imgs)
+    e = Engine(precision="fp32", max_batch=2, conv_impl=impl)
+    try:
+        e.load_detector(param, binf)
+        assert e.num_anchors == 8400 and e.det_classes == 1 and e.reg_max == 16
+        got = e.detect_raw(imgs)
+    finally:
+        e.close()
+    assert got.shape == ref.shape == (2, 5, 8400)
+    err_box = np.abs(got[:, :4] - ref[:, :4])
+    assert (err_box <= 1e-3 + 1e-3 * np.abs(ref[:, :4])).all(), f"box rows: max err {err_box.max()}"
+    err_s = np.abs(got[:, 4] - ref[:, 4]).max()
+    assert err_s <= 1e-3, f"score row: max err {err_s}"
+
+
+@pytest.mark.parametrize("preset", ["v1", "v2"])
+def test_detector_fp16_out0(synth_models, preset):
+    """fp16 storage / fp32 accumulate: not expected to meet the 1e-3 fp32 bound.  Documented
+    bound here: scores within 0.02, boxes within 2 px + 2 % (20+ layers of fp16 rounding)."""
+    from litepi import Engine
+    param, binf = synth_models[preset]
+    rng = np.random.default_rng(1)
+    imgs = rng.integers(0, 256, (2, 640, 640, 3), dtype=np.uint8)
+    ref, _ = _oracle_out0(param, binf, imgs)
+    e = Engine(precision="fp16", max_batch=2)
+    try:
+        e.load_detector(param, binf)
+        got = e.detect_raw(imgs)
+    finally:
+        e.close()
+    err_s = np.abs(got[:, 4] - ref[:, 4])
+    err_b = np.abs(got[:, :4] - ref[:, :4])
+    print(f"{preset} fp16: score err max {err_s.max():.4f} mean {err_s.mean():.5f}; box err max {err_b.max():.3f} mean {err_b.mean():.4f}")
+    assert err_s.max() <= 0.02
+    assert (err_b <= 2.0 + 0.02 * np.abs(ref[:, :4])).all()
+
+
+def test_detector_blobs_fp32(synth_models):
+    """Layer-by-layer bisect aid: a few intermediate blobs (C2f output, SPPF output, FPN output)."""
+    from litepi import Engine
+    from litepi.ncnn_io import read_param_layers
+    from oracle import ncnn_ref
+    param, binf = synth_models["v1"]
+    rng = np.random.default_rng(2)
+    imgs = rng.integers(0, 256, (1, 640, 640, 3), dtype=np.uint8)
+    layers = read_param_layers(param)
+    names = [l["outputs"][0] for l in layers if l["type"] == "Swish"]
+    pick = [names[i] for i in (0, 1, 5, 12, 27, 28, 36, 46)]
+    ol = ncnn_ref.load_model(param, binf)
+    x = torch.from_numpy(imgs[..., ::-1].astype(np.float32) * np.float32(1 / 255.0)).permute(0, 3, 1, 2).contiguous()
+    ref = ncnn_ref.run_graph(ol, x, keep=pick)
+    e = Engine(precision="fp32", max_batch=1)
+    try:
+        e.load_detector(param, binf)
+        e.detect_raw(imgs)
+        for n in pick:
+            if n not in ref:
+                continue
+            try:
+                got = e.debug_blob(n)
+            except Exception:
+                continue  # blob fused away (e.g. the pre-residual activation)
+            err = np.abs(got - ref[n].numpy()).max()
+            assert err < 1e-3, f"blob {n}: max err {err}"
+    finally:
+        e.close()
+
+
+# ---------------------------------------------------------------------------- classifier
+def _rois(rng, n):
+    out = []
+    for _ in range(n):
+        h, w = int(rng.integers(10, 90)), int(rng.integers(10, 90))
+        base = rng.integers(0, 256, (1, 1, 3))
+        img = np.clip(base + rng.normal(0, 40, (h, w, 3)), 0, 255).astype(np.uint8)
+        out.append(img)
+    return out
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("fp16", 3e-2)])
+def test_classifier_vs_oracle(prec, tol):
+    """ShuffleNetV2 logits->softmax vs the torch-CPU restatement on seeded weights (parity unpinned
+    by the reference: no classifier weights/outputs exist there).  fp32: probs within 1e-3."""
+    from litepi import Engine
+    from oracle import shufflenet_ref as S
+    sd = S.seeded_state_dict(91)
+    model = S.build(91, sd)
+    rng = np.random.default_rng(11)
+    rois = _rois(rng, 37)
+    ids_ref, probs_ref = S.predict_batch(model, rois)
+    e = Engine(precision=prec, max_batch=1, max_det=64, num_classes=91, max_rois=64)
+    try:
+        e.load_classifier(sd)
+        ids, probs = e.classify(rois)
+    finally:
+        e.close()
+    err = np.abs(probs - probs_ref).max()
+    print(f"classifier {prec}: max prob err {err:.5f}; argmax agree {np.mean(ids == ids_ref):.3f}")
+    assert err <= tol
+    if prec == "fp32":
+        assert np.array_equal(ids, ids_ref)
+    else:
+        # argmax may flip only where the top-2 margin is inside the fp16 error
+        top2 = np.sort(probs_ref, axis=1)[:, -2:]
+        ok = (ids == ids_ref) | ((top2[:, 1] - top2[:, 0]) < 2 * tol)
+        assert ok.all()
+
+
+# ---------------------------------------------------------------------------- end to end
+def _calibrated_model(tmp_path, preset="v1", target_per_image=8):
+    """Synthetic detector whose class bias is shifted so that ~target anchors/image pass conf 0.25."""
+    from litepi import ncnn_export
+    from oracle import ncnn_ref
+    p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    ncnn_export.export_detector(p, b, preset, seed=77, cls_bias=0.0)
+    rng = np.random.default_rng(123)
+    imgs = rng.integers(0, 256, (2, 640, 640, 3), dtype=np.uint8)
+    ref, _ = _oracle_out0(p, b, imgs)
+    s = np.sort(ref[:, 4].ravel())[::-1]
+    kth = s[target_per_image * 2]
+    logit = np.log(kth / (1 - kth))
+    ncnn_export.shift_cls_bias(p, b, float(np.log(0.25 / 0.75) - logit))
+    return p, b, imgs
+
+
+def test_pipeline_fp32_matches_oracle(tmp_path):
+    """Full path at fp32: identical post-NMS box sets (order included), ROI filter, classifier argmax,
+    result-dict format of HybridPipeline.run."""
+    from litepi import HybridPipeline
+    from oracle import ncnn_ref, pipeline_ref, shufflenet_ref as S
+    p, b, imgs = _calibrated_model(tmp_path)
+    sd = S.seeded_state_dict(91)
+    cls_path = str(tmp_path / "cls.pth")
+    torch.save(sd, cls_path)
+    cpu = pipeline_ref.CpuPipeline(ncnn_ref.load_model(p, b), S.build(91, sd))
+    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp32", max_batch=2, max_det=300)
+    try:
+        assert pipe.classifier.weights_loaded
+        outs = pipe.run_batch([imgs[0], imgs[1]], 0.25, 0.45, 50)
+        single = pipe.run(imgs[0], 0.25, 0.45, 50)
+    finally:
+        pipe.engine.close()
+    total = 0
+    for i in range(2):
+        exp, exp_numdet = cpu.run(imgs[i], 0.25, 0.45, 50)
+        res, met = outs[i]
+        assert met.num_detections == exp_numdet
+        assert len(res) == len(exp), f"image {i}: {len(res)} results vs oracle {len(exp)}"
+        for r, x in zip(res, exp):
+            assert set(r.keys()) == {"bbox", "det_class", "det_conf", "cls_class", "cls_conf", "time_det", "time_cls"}
+            assert abs(r["det_conf"] - x["det_conf"]) <= 1e-3
+            assert np.abs(np.array(r["bbox"]) - np.array(x["bbox"])).max() <= 1  # int truncation of boxes equal within 1e-3 px
+            assert r["det_class"] == x["det_class"] == 0
+            assert r["cls_class"] == x["cls_class"]
+            assert abs(r["cls_conf"] - x["cls_conf"]) <= 2e-3
+        total += len(res)
+    assert total >= 4, "calibration produced too few detections for a meaningful test"
+    assert [r["bbox"] for r in single[0]] == [r["bbox"] for r in outs[0][0]]
+
+
+def test_pipeline_fp16_close_to_oracle(tmp_path):
+    """configs[2] numerics: fp16 path.  Post-NMS sets must match the CPU fp32 path except for
+    candidates whose score is within 0.02 of the conf threshold (documented exclusion band)."""
+    from litepi import HybridPipeline
+    from oracle import ncnn_ref, pipeline_ref, shufflenet_ref as S
+    p, b, imgs = _calibrated_model(tmp_path)
+    sd = S.seeded_state_dict(91)
+    cls_path = str(tmp_path / "cls.pth")
+    torch.save(sd, cls_path)
+    cpu = pipeline_ref.CpuPipeline(ncnn_ref.load_model(p, b), S.build(91, sd))
+    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=2, max_det=300)
+    try:
+        outs = pipe.run_batch([imgs[0], imgs[1]], 0.25, 0.45, 50)
+    finally:
+        pipe.engine.close()
+    for i in range(2):
+        exp, _ = cpu.run(imgs[i], 0.25, 0.45, 50)
+        res = outs[i][0]
+        strong_exp = [x for x in exp if x["det_conf"] > 0.27]
+        matched = 0
+        for x in strong_exp:
+            for r in res:
+                if np.abs(np.array(r["bbox"]) - np.array(x["bbox"])).max() <= 4 and abs(r["det_conf"] - x["det_conf"]) < 0.02:
+                    matched += 1
+                    break
+        assert matched >= len(strong_exp) - 1, f"image {i}: matched {matched} of {len(strong_exp)} confident oracle boxes"
+        assert len([r for r in res if r["det_conf"] > 0.27]) <= len(exp) + 1
+
+
+def test_empty_and_error_behaviour(synth_models, tmp_path):
+    """Reference quirks: load failure -> RuntimeError (e2e.py:213-216); no detections -> float64
+    empties (e2e.py:264); empty classifier batch -> two empty arrays (e2e.py:380-381)."""
+    from litepi import NCNNDetector, PyTorchClassifier
+    with pytest.raises(RuntimeError):
+        NCNNDetector(str(tmp_path / "missing.param"), str(tmp_path / "missing.bin"))
+    param, binf = synth_models["v1"]
+    det = NCNNDetector(param, binf, precision="fp32")
+    try:
+        img = np.zeros((480, 640, 3), np.uint8)
+        boxes, scores, cls = det.detect(img, 0.999, 0.45)
+        assert boxes.shape == (0, 4) and boxes.dtype == np.float64 and scores.shape == (0,) and cls.shape == (0,)
+    finally:
+        det.engine.close()
+    clf = PyTorchClassifier(str(tmp_path / "none.pth"), "shufflenetv2", num_classes=49)
+    try:
+        assert not clf.weights_loaded
+        ids, probs = clf.predict_batch([])
+        assert ids.shape == (0,) and probs.shape == (0,)
+        ids, probs = clf.predict_batch([np.full((20, 30, 3), 90, np.uint8)])
+        assert ids.shape == (1,) and probs.shape == (1, 49) and abs(probs.sum() - 1) < 1e-3
+    finally:
+        clf.engine.close()
+    with pytest.raises(ValueError):
+        PyTorchClassifier("x", "resnet18")

@@ -1,0 +1,160 @@
+"""CPU suite (-m "not gpu"), part 1: the oracle is pinned.
+
+* post-processing restatement == outputs of the REFERENCE's own functions (goldens made by
+  tools/make_goldens.py in the build container), bit for bit;
+* PIL-resize restatement == Pillow itself;
+* NCNN reader extracts exactly the tensors the ONNX export of the same checkpoint holds
+  (needs /root/reference: skipped on the GPU box);
+* the oracle's forward on the real v1 weights is stable against committed checksums.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REF_ROOT, has_reference
+
+needs_ref = pytest.mark.skipif(not has_reference(), reason="/root/reference not present")
+
+
+def test_nms_matches_reference_goldens(golden_dir):
+    from oracle import postprocess_ref as P
+    g = np.load(os.path.join(golden_dir, "ref_nms.npz"))
+    keys = [k[:-5] for k in g.files if k.endswith("_keep")]
+    assert len(keys) == 11
+    for k in keys:
+        keep = P.nms(g[k + "_boxes"], g[k + "_scores"], float(g[k + "_thr"]))
+        assert np.array_equal(keep, g[k + "_keep"]), k
+
+
+def test_postprocess_matches_reference_goldens(golden_dir):
+    from oracle import postprocess_ref as P
+    g = np.load(os.path.join(golden_dir, "ref_postprocess.npz"))
+    i = 0
+    while f"c{i}_out0" in g.files:
+        oh, ow, r, p0, p1, conf, iou = g[f"c{i}_geom"]
+        b, s, c = P.postprocess(g[f"c{i}_out0"], (int(oh), int(ow)), r, (p0, p1), conf, iou)
+        eb = g[f"c{i}_boxes"]
+        assert b.shape == eb.shape and b.dtype == eb.dtype  # float64 empties included (e2e.py:264)
+        assert np.array_equal(b, eb) and np.array_equal(s, g[f"c{i}_scores"]) and np.array_equal(c, g[f"c{i}_cls"])
+        assert c.dtype == g[f"c{i}_cls"].dtype
+        i += 1
+    assert i == 8
+
+
+def test_roi_logic_matches_reference_goldens(golden_dir):
+    from oracle import postprocess_ref as P
+    g = np.load(os.path.join(golden_dir, "ref_pipeline.npz"))
+    for i in range(4):
+        h, w, ma = g[f"c{i}_hw_minarea"]
+        rects, valid = P.roi_rects(g[f"c{i}_boxes"], h, w, ma)
+        shp = g[f"c{i}_roi_shapes"]
+        assert np.array_equal(rects[:, 3] - rects[:, 1], shp[:, 0]) and np.array_equal(rects[:, 2] - rects[:, 0], shp[:, 1])
+        assert np.array_equal(g[f"c{i}_boxes"][valid].astype(int), g[f"c{i}_res_bbox"])
+        assert int(g[f"c{i}_num_detections"]) == len(g[f"c{i}_boxes"])
+
+
+def test_letterbox_geometry_and_identity():
+    from oracle import postprocess_ref as P
+    r, unpad, (dw, dh), (t, b, l, rr) = P.letterbox_params(681, 1198)
+    assert unpad == (640, 364) and (dw, dh) == (0.0, 138.0) and (t, b, l, rr) == (138, 138, 0, 0)
+    r, unpad, (dw, dh), (t, b, l, rr) = P.letterbox_params(640, 359)   # odd padding: extra pixel right/bottom
+    assert unpad == (359, 640) and dw == 140.5 and (l, rr) == (140, 141)
+    img = np.random.default_rng(0).integers(0, 256, (640, 640, 3), dtype=np.uint8)
+    out, r, pad = P.letterbox(img)
+    assert np.array_equal(out, img) and r == 1.0 and pad == (0.0, 0.0)
+    img = np.random.default_rng(0).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    out, r, pad = P.letterbox(img)
+    assert out.shape == (640, 640, 3) and np.array_equal(out[80:560], img) and (out[:80] == 114).all() and (out[560:] == 114).all()
+
+
+def test_pil_resize_restatement_equals_pillow():
+    from PIL import Image
+    from oracle import pil_resize_ref as R
+    rng = np.random.default_rng(0)
+    for (h, w) in [(10, 10), (7, 200), (200, 7), (64, 64), (64, 30), (30, 64), (1, 1), (2, 3), (129, 257), (63, 65), (300, 500)]:
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.array(Image.fromarray(im).resize((64, 64), Image.BILINEAR))
+        assert np.array_equal(R.resize_bilinear_u8(im, 64, 64), ref), (h, w)
+
+
+@needs_ref
+def test_pil_resize_on_reference_debug_rois():
+    import glob
+    from PIL import Image
+    from oracle import pil_resize_ref as R
+    files = sorted(glob.glob(os.path.join(REF_ROOT, "src/vntsr/pipeline/debug_rois/*")))
+    assert len(files) == 15
+    for f in files:
+        im = np.array(Image.open(f).convert("RGB"))
+        ref = np.array(Image.fromarray(im).resize((64, 64), Image.BILINEAR))
+        assert np.array_equal(R.resize_bilinear_u8(im, 64, 64), ref), f
+
+
+V1_DIR = os.path.join(REF_ROOT, "src/vntsr/convert/model/yolo_plus")
+
+
+@needs_ref
+def test_ncnn_reader_matches_onnx_initializers():
+    from oracle import ncnn_ref, onnx_init
+    layers = ncnn_ref.load_model(os.path.join(V1_DIR, "yolo_plus_ncnn_model/model.ncnn.param"),
+                                 os.path.join(V1_DIR, "yolo_plus_ncnn_model/model.ncnn.bin"))
+    init = onnx_init.read_initializers(os.path.join(V1_DIR, "yolo_plus.onnx"))
+    pool = [v for v in init.values() if v.dtype == np.float32]
+    convs = ncnn_ref.conv_layers(layers)
+    assert len(convs) == 64
+    for l in convs:
+        assert any(v.shape == l.weight.shape and np.array_equal(v, l.weight) for v in pool), l.name
+        if l.bias is not None:
+            assert any(v.shape == l.bias.shape and np.array_equal(v, l.bias) for v in pool), l.name
+    assert ncnn_ref.conv_macs(layers) == 1418713600  # 1.4187 GMAC
+
+
+@needs_ref
+def test_oracle_forward_on_real_weights_is_stable(golden_dir):
+    """Seeded rand(1,3,640,640) as in the reference's model_ncnn.py:6-7.  The reference holds no
+    expected output (parity unpinned); this pins the oracle against silent drift only."""
+    import torch
+    from oracle import ncnn_ref
+    layers = ncnn_ref.load_model(os.path.join(V1_DIR, "yolo_plus_ncnn_model/model.ncnn.param"),
+                                 os.path.join(V1_DIR, "yolo_plus_ncnn_model/model.ncnn.bin"))
+    g = np.load(os.path.join(golden_dir, "oracle_v1_out0_checksums.npz"))
+    for seed in (0, 1):
+        torch.manual_seed(seed)
+        out = ncnn_ref.run_graph(layers, torch.rand(1, 3, 640, 640))["out0"].numpy()[0]
+        assert out.shape == (5, 8400)
+        assert np.allclose(out[:, ::97], g[f"s{seed}_sub"], rtol=1e-4, atol=1e-4)
+        assert np.allclose(out.mean(axis=1), g[f"s{seed}_mean"], rtol=1e-4)
+
+
+def test_synthetic_models_have_the_reference_architecture(synth_models):
+    """The exporter reproduces the reference graphs' MAC counts and the oracle
+    interpreter runs them."""
+    import torch
+    from oracle import ncnn_ref
+    for preset, macs in (("v1", 1418713600), ("v2", 2542483200)):
+        layers = ncnn_ref.load_model(*synth_models[preset])
+        assert len(layers) == 206
+        assert ncnn_ref.conv_macs(layers) == macs
+    out = ncnn_ref.run_graph(layers, torch.rand(1, 3, 640, 640))["out0"]
+    assert out.shape == (1, 5, 8400) and torch.isfinite(out).all()
+
+
+@needs_ref
+def test_exporter_layer_sequence_equals_reference_graph(synth_models):
+    ref = [l.split()[:4] for l in open(os.path.join(V1_DIR, "yolo_plus_ncnn_model/model.ncnn.param")).read().splitlines()[2:]]
+    mine = [l.split()[:4] for l in open(synth_models["v1"][0]).read().splitlines()[2:]]
+    assert len(ref) == len(mine) == 206
+    assert all(a[0] == b[0] and a[2:] == b[2:] for a, b in zip(ref, mine))  # layer type, #in, #out
+
+
+def test_shufflenet_oracle_shapes_and_param_count():
+    import torch
+    from oracle import shufflenet_ref as S
+    sd = S.seeded_state_dict(91)
+    n = sum(v.numel() for k, v in sd.items() if "running" not in k and not k.endswith("num_batches_tracked"))
+    assert n - 1025 * 91 == 1253604
+    m = S.build(91, sd)
+    with torch.no_grad():
+        y = m(torch.randn(2, 3, 64, 64))
+    assert y.shape == (2, 91)

@@ -1,0 +1,679 @@
+// C-ABI of liblitepi_hip.so (see include/litepi.h for the reference call sites each entry
+// point replaces).  Owns the device, the stream, all activation/result buffers and the two
+// model plans; every pipeline stage runs on the GPU -- there is no CPU fallback anywhere.
+#include <algorithm>
+#include <cmath>
+
+#include "classifier.h"
+#include "common.h"
+#include "detector.h"
+#include "kernels.h"
+
+namespace lp {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+
+std::string fmt(const char* f, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof(buf), f, ap);
+  va_end(ap);
+  return std::string(buf);
+}
+
+uint16_t f32_to_f16(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const int32_t exp = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
+  uint32_t man = x & 0x7FFFFFu;
+  if (((x >> 23) & 0xFF) == 0xFF) return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7C00u);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    man |= 0x800000u;
+    const int shift = 14 - exp;
+    uint32_t h = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = ((uint32_t)exp << 10) | (man >> 13);
+  const uint32_t rem = man & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+  return (uint16_t)(sign | h);
+}
+
+float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1F, man = h & 0x3FFu, x;
+  if (exp == 0) {
+    if (man == 0) {
+      x = sign;
+    } else {
+      int e = -1;
+      do { ++e; man <<= 1; } while (!(man & 0x400u));
+      x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+    }
+  } else if (exp == 31) {
+    x = sign | 0x7F800000u | (man << 13);
+  } else {
+    x = sign | ((exp - 15 + 127) << 23) | (man << 13);
+  }
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+// letterbox geometry exactly as the reference computes it in Python doubles (e2e.py:72-83);
+// Python's round() is round-half-to-even == nearbyint in the default rounding mode.
+static ImgGeom make_geom(int h, int w, int S, long src_off) {
+  ImgGeom g;
+  memset(&g, 0, sizeof(g));  // padding bytes too: geometry is compared with memcmp
+  const double r = std::min((double)S / h, (double)S / w);
+  const int nw = (int)std::nearbyint(w * r), nh = (int)std::nearbyint(h * r);
+  const double dw = (S - nw) / 2.0, dh = (S - nh) / 2.0;
+  g.src_off = src_off; g.h = h; g.w = w; g.new_w = nw; g.new_h = nh;
+  g.top = (int)std::nearbyint(dh - 0.1);
+  g.left = (int)std::nearbyint(dw - 0.1);
+  g.ratio = (float)r; g.pad_w = (float)dw; g.pad_h = (float)dh;
+  return g;
+}
+
+}  // namespace lp
+
+using namespace lp;
+
+struct lp_handle {
+  lp_config cfg;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::unique_ptr<Detector> det;
+  std::unique_ptr<Classifier> cls;
+  Profiler prof;
+  bool prof_next = false;
+  int max_rois = 0;
+  // device buffers
+  DevBuf d_src, d_lb, d_geom, d_cand, d_cand_count, d_sorted, d_dets, d_counts, d_rects, d_out0;
+  DevBuf d_roi_base, d_roi_total, d_roi_img, d_roi_slot, d_roi_rgb, d_probs, d_ids, d_conf;
+  std::vector<ImgGeom> geom_cache;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int last_roi_count = 0;
+
+  RoiTable roi_table() {
+    RoiTable t;
+    t.base = d_roi_base.as<int>(); t.total = d_roi_total.as<int>();
+    t.img = d_roi_img.as<int>(); t.slot = d_roi_slot.as<int>();
+    return t;
+  }
+  void ensure_src(size_t bytes) {
+    if (d_src.bytes < bytes) d_src.alloc(bytes + bytes / 4, false);
+  }
+  void alloc_post_buffers() {
+    const int B = cfg.max_batch, A = det->num_anchors(), nc = det->num_classes();
+    d_cand.alloc((size_t)B * A * sizeof(Cand), false);
+    d_sorted.alloc((size_t)B * A * sizeof(Cand), false);
+    d_cand_count.alloc((size_t)B * 4);
+    d_dets.alloc((size_t)B * cfg.max_det * sizeof(lp_det));
+    d_counts.alloc((size_t)2 * B * 4);
+    d_rects.alloc((size_t)B * cfg.max_det * 16);
+    d_out0.alloc((size_t)B * (4 + nc) * A * 4, false);
+  }
+  void upload_geom(const std::vector<ImgGeom>& g) {
+    bool same = g.size() == geom_cache.size() && (g.empty() || memcmp(g.data(), geom_cache.data(), g.size() * sizeof(ImgGeom)) == 0);
+    if (same) return;
+    LP_HIP(hipMemcpyAsync(d_geom.p, g.data(), g.size() * sizeof(ImgGeom), hipMemcpyHostToDevice, stream));
+    LP_HIP(hipStreamSynchronize(stream));  // g may be a temporary; uploads are rare (shape changes only)
+    geom_cache = g;
+  }
+};
+
+#define LP_API_BEGIN try {
+#define LP_API_END                                   \
+  }                                                  \
+  catch (const lp::Error& e) {                       \
+    lp::set_last_error(e.what());                    \
+    return e.code;                                   \
+  }                                                  \
+  catch (const std::exception& e) {                  \
+    lp::set_last_error(e.what());                    \
+    return LP_ERR_STATE;                             \
+  }                                                  \
+  return LP_OK;
+
+extern "C" {
+
+const char* lp_last_error(void) { return lp::g_last_error.c_str(); }
+int lp_version(void) { return 100; }
+
+void lp_default_config(lp_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->device = 0; c->precision = LP_FP16; c->max_batch = 1; c->max_det = 300; c->num_classes = 58;
+  c->det_input = 640; c->cls_input = 64; c->max_rois = 0; c->conv_impl = 0;
+}
+
+int lp_create(const lp_config* cfg, lp_handle** out) {
+  LP_API_BEGIN
+  LP_CHECK(cfg && out, LP_ERR_ARG, "null argument");
+  LP_CHECK(cfg->max_batch >= 1 && cfg->max_batch <= 1024 && cfg->max_det >= 1 && cfg->det_input % 32 == 0 && cfg->det_input >= 64,
+           LP_ERR_ARG, "bad config (max_batch %d, max_det %d, det_input %d)", cfg->max_batch, cfg->max_det, cfg->det_input);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device)
+    throw Error(LP_ERR_NODEVICE, fmt("HIP device %d not available (%d visible): liblitepi_hip has no CPU path", cfg->device, ndev));
+  LP_HIP(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  LP_HIP(hipGetDeviceProperties(&prop, cfg->device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    throw Error(LP_ERR_NODEVICE, fmt("device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName));
+  std::unique_ptr<lp_handle> h(new lp_handle());
+  h->cfg = *cfg;
+  h->max_rois = cfg->max_rois > 0 ? cfg->max_rois : cfg->max_batch * std::min(cfg->max_det, 64);
+  LP_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  for (auto& e : h->ev) LP_HIP(hipEventCreate(&e));
+  h->d_geom.alloc((size_t)std::max(cfg->max_batch, h->max_rois) * sizeof(ImgGeom));
+  const int S = cfg->det_input;
+  h->d_lb.alloc((size_t)cfg->max_batch * S * S * 3, false);
+  h->d_roi_base.alloc((size_t)(cfg->max_batch + 1) * 4);
+  h->d_roi_total.alloc(16);
+  h->d_roi_img.alloc((size_t)h->max_rois * 4);
+  h->d_roi_slot.alloc((size_t)h->max_rois * 4);
+  const int cs = cfg->cls_input;
+  h->d_roi_rgb.alloc((size_t)h->max_rois * cs * cs * 3, false);
+  h->d_probs.alloc((size_t)h->max_rois * std::max(cfg->num_classes, 1) * 4);
+  h->d_ids.alloc((size_t)h->max_rois * 4);
+  h->d_conf.alloc((size_t)h->max_rois * 4);
+  *out = h.release();
+  LP_API_END
+}
+
+void lp_destroy(lp_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+int lp_load_detector_ncnn(lp_handle* h, const char* param_path, const char* bin_path) {
+  LP_API_BEGIN
+  LP_CHECK(h && param_path && bin_path, LP_ERR_ARG, "null argument");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  std::unique_ptr<Detector> d(new Detector(h->cfg.precision, h->cfg.conv_impl, h->cfg.max_batch, h->cfg.det_input));
+  d->load(param_path, bin_path);
+  h->det = std::move(d);
+  h->alloc_post_buffers();
+  LP_HIP(hipDeviceSynchronize());
+  LP_API_END
+}
+
+int lp_load_classifier_tensors(lp_handle* h, int n, const char* const* names, const float* const* data,
+                               const int64_t* const* shapes, const int* ndims) {
+  LP_API_BEGIN
+  LP_CHECK(h && names && data && shapes && ndims && n > 0, LP_ERR_ARG, "null argument");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  std::map<std::string, NamedTensor> sd;
+  for (int i = 0; i < n; ++i) {
+    NamedTensor t;
+    t.data = data[i];
+    t.shape.assign(shapes[i], shapes[i] + ndims[i]);
+    sd[names[i]] = t;
+  }
+  std::unique_ptr<Classifier> c(new Classifier(h->cfg.precision, h->cfg.conv_impl, h->max_rois, h->cfg.num_classes, h->cfg.cls_input));
+  c->load(sd);
+  h->cls = std::move(c);
+  LP_HIP(hipDeviceSynchronize());
+  LP_API_END
+}
+
+int lp_set_stream(lp_handle* h, void* s) {
+  LP_API_BEGIN
+  LP_CHECK(h, LP_ERR_ARG, "null handle");
+  h->stream = s ? reinterpret_cast<hipStream_t>(s) : h->own_stream;
+  LP_API_END
+}
+
+int lp_synchronize(lp_handle* h) {
+  LP_API_BEGIN
+  LP_CHECK(h, LP_ERR_ARG, "null handle");
+  LP_HIP(hipStreamSynchronize(h->stream));
+  LP_API_END
+}
+
+int lp_profile_next(lp_handle* h, int enable) {
+  LP_API_BEGIN
+  LP_CHECK(h, LP_ERR_ARG, "null handle");
+  h->prof_next = enable != 0;
+  LP_API_END
+}
+
+int lp_profile_read(lp_handle* h, lp_kernel_time* out, int cap, int* n) {
+  LP_API_BEGIN
+  LP_CHECK(h && n, LP_ERR_ARG, "null argument");
+  if (!h->prof.recs.empty()) {
+    LP_HIP(hipStreamSynchronize(h->stream));
+    int R = 0;
+    LP_HIP(hipMemcpy(&R, h->d_roi_total.p, 4, hipMemcpyDeviceToHost));
+    h->prof.collect(R);
+  }
+  const int m = std::min<int>(cap, (int)h->prof.results.size());
+  for (int i = 0; i < m && out; ++i) out[i] = h->prof.results[i];
+  *n = (int)h->prof.results.size();
+  LP_API_END
+}
+
+int lp_detector_info(lp_handle* h, int* num_anchors, int* nc, int* reg_max, double* macs) {
+  LP_API_BEGIN
+  LP_CHECK(h && h->det && h->det->loaded(), LP_ERR_STATE, "detector not loaded");
+  if (num_anchors) *num_anchors = h->det->num_anchors();
+  if (nc) *nc = h->det->num_classes();
+  if (reg_max) *reg_max = h->det->reg_max();
+  if (macs) *macs = h->det->macs_per_image();
+  LP_API_END
+}
+
+}  // extern "C"
+
+// ---- pipeline pieces shared by the entry points ----------------------------------------------
+namespace {
+
+Profiler* begin_profile(lp_handle* h) {
+  if (!h->prof_next) return nullptr;
+  h->prof_next = false;
+  h->prof.enabled = true;
+  h->prof.results.clear();
+  return &h->prof;
+}
+
+// detector (+ optional letterbox) on images resident at src with geometry already uploaded
+void enqueue_detect(lp_handle* h, const uint8_t* src, const std::vector<ImgGeom>& geoms, int B, float conf, float* out0,
+                    Profiler* prof) {
+  const int S = h->cfg.det_input;
+  bool identity = true;
+  for (int i = 0; i < B; ++i)
+    identity = identity && geoms[i].h == S && geoms[i].w == S && geoms[i].src_off == (long)i * S * S * 3;
+  const uint8_t* img = src;
+  if (!identity) {
+    if (prof) prof->begin(h->stream);
+    launch_letterbox(src, h->d_geom.as<ImgGeom>(), h->d_lb.as<uint8_t>(), B, S, h->stream);
+    if (prof) {
+      double bytes = (double)B * S * S * 3;
+      for (int i = 0; i < B; ++i) bytes += (double)geoms[i].h * geoms[i].w * 3;
+      prof->end(h->stream, "letterbox_u8", "letterbox", 0.0, bytes);
+    }
+    img = h->d_lb.as<uint8_t>();
+  }
+  h->det->forward(img, B, h->d_geom.as<ImgGeom>(), conf, out0, h->d_cand.as<Cand>(), h->d_cand_count.as<int>(), h->stream, prof);
+}
+
+void enqueue_nms(lp_handle* h, int B, float iou, int min_area, lp_det* dets, int* counts, Profiler* prof) {
+  NmsArgs a;
+  a.cand = h->d_cand.as<Cand>(); a.cand_count = h->d_cand_count.as<int>(); a.sorted = h->d_sorted.as<Cand>();
+  a.dets = dets; a.counts = counts; a.rects = h->d_rects.as<int>(); a.geom = h->d_geom.as<ImgGeom>();
+  a.A = h->det->num_anchors(); a.max_det = h->cfg.max_det; a.iou = iou; a.min_area = min_area;
+  if (prof) prof->begin(h->stream);
+  launch_nms(a, B, h->stream);
+  if (prof) prof->end(h->stream, "nms", "nms", 0.0, 0.0);
+}
+
+// ROI table + PIL resize + ShuffleNetV2 + softmax; scatters (cls, conf) into dets when given
+void enqueue_classify(lp_handle* h, const uint8_t* src, int B, const int* counts, lp_det* dets, float* probs, int* ids,
+                      float* conf, Profiler* prof) {
+  RoiTable tab = h->roi_table();
+  if (counts) {
+    if (prof) prof->begin(h->stream);
+    launch_roi_index(counts, tab, B, h->cfg.max_det, h->max_rois, h->stream);
+    if (prof) prof->end(h->stream, "roi_index", "roi_index", 0.0, 0.0);
+  }
+  RoiResizeArgs r;
+  r.src = src; r.geom = h->d_geom.as<ImgGeom>(); r.rects = h->d_rects.as<int>(); r.tab = tab;
+  r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = h->cfg.max_det; r.S = h->cfg.cls_input;
+  if (prof) prof->begin(h->stream);
+  launch_roi_resize(r, h->stream);
+  if (prof) prof->end(h->stream, "roi_resize_pil", "roi_resize", 0.0, (double)r.S * r.S * 3 * 2, true);
+  h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof);
+  if (prof) prof->begin(h->stream);
+  launch_softmax_argmax(h->cls->logits(), h->cls->logits_pitch(), h->cls->num_classes(), probs, ids, conf, dets, h->cfg.max_det,
+                        &tab, tab.total, h->max_rois, h->stream);
+  if (prof) prof->end(h->stream, "softmax_argmax", "softmax", 0.0, (double)h->cls->num_classes() * 8, true);
+}
+
+// upload B host images of individual sizes into d_src; returns their geometry
+std::vector<ImgGeom> upload_images(lp_handle* h, const uint8_t* const* imgs, const int* hs, const int* ws, int B) {
+  std::vector<ImgGeom> g(B);
+  size_t total = 0;
+  for (int i = 0; i < B; ++i) {
+    LP_CHECK(imgs[i] && hs[i] > 0 && ws[i] > 0, LP_ERR_ARG, "image %d is empty", i);
+    g[i] = make_geom(hs[i], ws[i], h->cfg.det_input, (long)total);
+    total += (size_t)hs[i] * ws[i] * 3;
+    total = (total + 15) & ~(size_t)15;
+  }
+  h->ensure_src(total);
+  for (int i = 0; i < B; ++i)
+    LP_HIP(hipMemcpyAsync(h->d_src.as<uint8_t>() + g[i].src_off, imgs[i], (size_t)hs[i] * ws[i] * 3, hipMemcpyHostToDevice, h->stream));
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lp_detect_raw(lp_handle* h, const uint8_t* bgr, int B, float* out0) {
+  LP_API_BEGIN
+  LP_CHECK(h && bgr && out0, LP_ERR_ARG, "null argument");
+  LP_CHECK(h->det && h->det->loaded(), LP_ERR_STATE, "detector not loaded");
+  LP_CHECK(B >= 1 && B <= h->cfg.max_batch, LP_ERR_ARG, "batch %d outside 1..%d", B, h->cfg.max_batch);
+  LP_HIP(hipSetDevice(h->cfg.device));
+  const int S = h->cfg.det_input;
+  const size_t bytes = (size_t)B * S * S * 3;
+  h->ensure_src(bytes);
+  LP_HIP(hipMemcpyAsync(h->d_src.p, bgr, bytes, hipMemcpyHostToDevice, h->stream));
+  std::vector<ImgGeom> g(B);
+  for (int i = 0; i < B; ++i) g[i] = make_geom(S, S, S, (long)i * S * S * 3);
+  h->upload_geom(g);
+  Profiler* prof = begin_profile(h);
+  LP_HIP(hipMemsetAsync(h->d_cand_count.p, 0, (size_t)h->cfg.max_batch * 4, h->stream));
+  enqueue_detect(h, h->d_src.as<uint8_t>(), g, B, 2.0f /* nothing passes: raw output only */, h->d_out0.as<float>(), prof);
+  const size_t obytes = (size_t)B * (4 + h->det->num_classes()) * h->det->num_anchors() * 4;
+  LP_HIP(hipMemcpyAsync(out0, h->d_out0.p, obytes, hipMemcpyDeviceToHost, h->stream));
+  LP_HIP(hipStreamSynchronize(h->stream));
+  if (prof) { prof->collect(0); prof->enabled = false; }
+  LP_API_END
+}
+
+int lp_detect(lp_handle* h, const uint8_t* const* imgs, const int* hs, const int* ws, int B, float conf, float iou,
+              lp_det* dets, int* counts) {
+  LP_API_BEGIN
+  LP_CHECK(h && imgs && hs && ws && dets && counts, LP_ERR_ARG, "null argument");
+  LP_CHECK(h->det && h->det->loaded(), LP_ERR_STATE, "detector not loaded");
+  LP_CHECK(B >= 1 && B <= h->cfg.max_batch, LP_ERR_ARG, "batch %d outside 1..%d", B, h->cfg.max_batch);
+  LP_HIP(hipSetDevice(h->cfg.device));
+  std::vector<ImgGeom> g = upload_images(h, imgs, hs, ws, B);
+  h->upload_geom(g);
+  Profiler* prof = begin_profile(h);
+  enqueue_detect(h, h->d_src.as<uint8_t>(), g, B, conf, nullptr, prof);
+  enqueue_nms(h, B, iou, -1, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), prof);
+  LP_HIP(hipMemcpyAsync(dets, h->d_dets.p, (size_t)B * h->cfg.max_det * sizeof(lp_det), hipMemcpyDeviceToHost, h->stream));
+  LP_HIP(hipMemcpyAsync(counts, h->d_counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+  LP_HIP(hipStreamSynchronize(h->stream));
+  if (prof) { prof->collect(0); prof->enabled = false; }
+  LP_API_END
+}
+
+int lp_run_batch(lp_handle* h, const uint8_t* const* imgs, const int* hs, const int* ws, int B, float conf, float iou,
+                 int min_area, lp_det* dets, int* counts, int* num_det, lp_timing* timing) {
+  LP_API_BEGIN
+  LP_CHECK(h && imgs && hs && ws && dets && counts, LP_ERR_ARG, "null argument");
+  LP_CHECK(h->det && h->det->loaded(), LP_ERR_STATE, "detector not loaded");
+  LP_CHECK(h->cls && h->cls->loaded(), LP_ERR_STATE, "classifier not loaded");
+  LP_CHECK(B >= 1 && B <= h->cfg.max_batch, LP_ERR_ARG, "batch %d outside 1..%d", B, h->cfg.max_batch);
+  LP_CHECK(min_area >= 0, LP_ERR_ARG, "min_area must be >= 0");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  std::vector<ImgGeom> g = upload_images(h, imgs, hs, ws, B);
+  h->upload_geom(g);
+  Profiler* prof = begin_profile(h);
+  LP_HIP(hipEventRecord(h->ev[0], h->stream));
+  enqueue_detect(h, h->d_src.as<uint8_t>(), g, B, conf, nullptr, prof);
+  LP_HIP(hipEventRecord(h->ev[1], h->stream));
+  enqueue_nms(h, B, iou, min_area, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), prof);
+  LP_HIP(hipEventRecord(h->ev[2], h->stream));
+  enqueue_classify(h, h->d_src.as<uint8_t>(), B, h->d_counts.as<int>(), h->d_dets.as<lp_det>(), nullptr, nullptr, nullptr, prof);
+  LP_HIP(hipEventRecord(h->ev[3], h->stream));
+  LP_HIP(hipMemcpyAsync(dets, h->d_dets.p, (size_t)B * h->cfg.max_det * sizeof(lp_det), hipMemcpyDeviceToHost, h->stream));
+  std::vector<int> cnt(2 * B);
+  LP_HIP(hipMemcpyAsync(cnt.data(), h->d_counts.p, (size_t)2 * B * 4, hipMemcpyDeviceToHost, h->stream));
+  int R = 0;
+  LP_HIP(hipMemcpyAsync(&R, h->d_roi_total.p, 4, hipMemcpyDeviceToHost, h->stream));
+  LP_HIP(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < B; ++i) {
+    counts[i] = cnt[i];
+    if (num_det) num_det[i] = cnt[B + i];
+  }
+  h->last_roi_count = R;
+  if (timing) {
+    // NMS + ROI rectangle are one kernel here; the reference books NMS under detection and the
+    // ROI loop under t_roi_extract (e2e.py:452-475)
+    (void)hipEventElapsedTime(&timing->t_detection, h->ev[0], h->ev[2]);
+    timing->t_roi_extract = 0.f;
+    (void)hipEventElapsedTime(&timing->t_classification, h->ev[2], h->ev[3]);
+    (void)hipEventElapsedTime(&timing->t_total, h->ev[0], h->ev[3]);
+  }
+  if (prof) { prof->collect(R); prof->enabled = false; }
+  LP_API_END
+}
+
+int lp_run_batch_device(lp_handle* h, const void* dev_imgs, int B, int H, int W, float conf, float iou, int min_area,
+                        void* dev_dets, void* dev_counts) {
+  LP_API_BEGIN
+  LP_CHECK(h && dev_imgs && dev_dets && dev_counts, LP_ERR_ARG, "null argument");
+  LP_CHECK(h->det && h->det->loaded(), LP_ERR_STATE, "detector not loaded");
+  LP_CHECK(B >= 1 && B <= h->cfg.max_batch && H > 0 && W > 0, LP_ERR_ARG, "bad batch/shape");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  std::vector<ImgGeom> g(B);
+  for (int i = 0; i < B; ++i) g[i] = make_geom(H, W, h->cfg.det_input, (long)i * H * W * 3);
+  h->upload_geom(g);
+  Profiler* prof = begin_profile(h);
+  const uint8_t* src = static_cast<const uint8_t*>(dev_imgs);
+  enqueue_detect(h, src, g, B, conf, nullptr, prof);
+  const bool classify = h->cls && h->cls->loaded();
+  enqueue_nms(h, B, iou, classify ? min_area : -1, static_cast<lp_det*>(dev_dets), static_cast<int*>(dev_counts), prof);
+  if (classify)
+    enqueue_classify(h, src, B, static_cast<int*>(dev_counts), static_cast<lp_det*>(dev_dets), nullptr, nullptr, nullptr, prof);
+  if (prof) prof->enabled = false;  // records are collected by lp_profile_read after the caller synchronises
+  LP_API_END
+}
+
+int lp_classify(lp_handle* h, const uint8_t* const* rois, const int* hs, const int* ws, int R, int* ids, float* probs) {
+  LP_API_BEGIN
+  LP_CHECK(h && ids && probs, LP_ERR_ARG, "null argument");
+  LP_CHECK(h->cls && h->cls->loaded(), LP_ERR_STATE, "classifier not loaded");
+  LP_CHECK(R >= 0 && R <= h->max_rois && R <= h->cfg.max_batch * h->cfg.max_det, LP_ERR_ARG,
+           "%d ROIs exceed the capacity (%d)", R, std::min(h->max_rois, h->cfg.max_batch * h->cfg.max_det));
+  if (R == 0) return LP_OK;
+  LP_CHECK(rois && hs && ws, LP_ERR_ARG, "null argument");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  // every crop is its own "image" whose single ROI is the whole crop
+  std::vector<ImgGeom> g(R);
+  std::vector<int> rects((size_t)R * 4, 0), img(R), slot(R, 0);
+  size_t total = 0;
+  for (int i = 0; i < R; ++i) {
+    LP_CHECK(rois[i] && hs[i] > 0 && ws[i] > 0 && hs[i] <= 4096 && ws[i] <= 4096, LP_ERR_ARG, "ROI %d has a bad size", i);
+    memset(&g[i], 0, sizeof(ImgGeom));
+    g[i].src_off = (long)total; g[i].h = hs[i]; g[i].w = ws[i];
+    total += ((size_t)hs[i] * ws[i] * 3 + 15) & ~(size_t)15;
+    img[i] = i;
+  }
+  LP_CHECK(R <= (int)(h->d_geom.bytes / sizeof(ImgGeom)), LP_ERR_ARG, "too many ROIs");
+  h->ensure_src(total);
+  for (int i = 0; i < R; ++i)
+    LP_HIP(hipMemcpyAsync(h->d_src.as<uint8_t>() + g[i].src_off, rois[i], (size_t)hs[i] * ws[i] * 3, hipMemcpyHostToDevice, h->stream));
+  h->geom_cache.clear();
+  LP_HIP(hipMemcpyAsync(h->d_geom.p, g.data(), (size_t)R * sizeof(ImgGeom), hipMemcpyHostToDevice, h->stream));
+  DevBuf d_rects_tmp;  // [R][1][4]: one whole-crop rectangle per "image"
+  d_rects_tmp.alloc((size_t)R * 16);
+  for (int i = 0; i < R; ++i) {
+    int* rc = &rects[(size_t)i * 4];
+    rc[0] = 0; rc[1] = 0; rc[2] = ws[i]; rc[3] = hs[i];
+  }
+  LP_HIP(hipMemcpyAsync(d_rects_tmp.p, rects.data(), rects.size() * 4, hipMemcpyHostToDevice, h->stream));
+  LP_HIP(hipMemcpyAsync(h->d_roi_img.p, img.data(), (size_t)R * 4, hipMemcpyHostToDevice, h->stream));
+  LP_HIP(hipMemcpyAsync(h->d_roi_slot.p, slot.data(), (size_t)R * 4, hipMemcpyHostToDevice, h->stream));
+  LP_HIP(hipMemcpyAsync(h->d_roi_total.p, &R, 4, hipMemcpyHostToDevice, h->stream));
+  Profiler* prof = begin_profile(h);
+  RoiTable tab = h->roi_table();
+  RoiResizeArgs r;
+  r.src = h->d_src.as<uint8_t>(); r.geom = h->d_geom.as<ImgGeom>(); r.rects = d_rects_tmp.as<int>(); r.tab = tab;
+  r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = 1; r.S = h->cfg.cls_input;
+  launch_roi_resize(r, h->stream);
+  h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof);
+  launch_softmax_argmax(h->cls->logits(), h->cls->logits_pitch(), h->cls->num_classes(), h->d_probs.as<float>(), h->d_ids.as<int>(),
+                        nullptr, nullptr, h->cfg.max_det, nullptr, tab.total, h->max_rois, h->stream);
+  LP_HIP(hipMemcpyAsync(ids, h->d_ids.p, (size_t)R * 4, hipMemcpyDeviceToHost, h->stream));
+  LP_HIP(hipMemcpyAsync(probs, h->d_probs.p, (size_t)R * h->cls->num_classes() * 4, hipMemcpyDeviceToHost, h->stream));
+  LP_HIP(hipStreamSynchronize(h->stream));
+  if (prof) { prof->collect(R); prof->enabled = false; }
+  LP_API_END
+}
+
+int lp_debug_blob(lp_handle* h, const char* blob, float* out, int64_t cap, int* C, int* H, int* W) {
+  LP_API_BEGIN
+  LP_CHECK(h && blob && C && H && W, LP_ERR_ARG, "null argument");
+  LP_CHECK(h->det && h->det->loaded(), LP_ERR_STATE, "detector not loaded");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  LP_HIP(hipStreamSynchronize(h->stream));
+  std::vector<float> v;
+  h->det->fetch_blob(blob, 1, v, *C, *H, *W);
+  if (out) {
+    LP_CHECK((int64_t)v.size() <= cap, LP_ERR_ARG, "blob needs %zu floats, buffer has %lld", v.size(), (long long)cap);
+    memcpy(out, v.data(), v.size() * 4);
+  }
+  LP_API_END
+}
+
+int lp_test_conv(lp_handle* h, int impl, const float* x, int N, int Cin, int H, int W, const float* w, const float* bias,
+                 int Cout, int k, int stride, int act, const float* res, float* y) {
+  LP_API_BEGIN
+  LP_CHECK(h && x && w && y, LP_ERR_ARG, "null argument");
+  LP_CHECK(Cin % 8 == 0 && Cout % 8 == 0, LP_ERR_ARG, "test conv needs channel counts that are multiples of 8");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  const int prec = h->cfg.precision;
+  const size_t es = prec == LP_FP16 ? 2 : 4;
+  const int pad = k / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int taps = k * k;
+  std::vector<float> wp((size_t)Cout * taps * Cin), bp(Cout, 0.f);
+  for (int o = 0; o < Cout; ++o) {
+    for (int i = 0; i < Cin; ++i)
+      for (int t = 0; t < taps; ++t) wp[((size_t)o * taps + t) * Cin + i] = w[((size_t)o * Cin + i) * taps + t];
+    if (bias) bp[o] = bias[o];
+  }
+  ConvLayer L;
+  L.build(prec, impl, k, stride, Cin, Cout, act, wp, bp, Ho, Wo);
+  auto to_dev = [&](const float* src, int C, int HH, int WW, DevBuf& d) {
+    const size_t npix = (size_t)N * HH * WW;
+    std::vector<uint8_t> buf(npix * C * es);
+    for (size_t p = 0; p < npix; ++p) {
+      const size_t b = p / ((size_t)HH * WW), yx = p % ((size_t)HH * WW);
+      for (int c = 0; c < C; ++c) {
+        const float v = src[(b * C + c) * HH * WW + yx];
+        if (prec == LP_FP16) { uint16_t hv = f32_to_f16(v); memcpy(&buf[(p * C + c) * 2], &hv, 2); }
+        else memcpy(&buf[(p * C + c) * 4], &v, 4);
+      }
+    }
+    d.alloc(buf.size());
+    LP_HIP(hipMemcpy(d.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+  };
+  DevBuf dx, dy, dr;
+  to_dev(x, Cin, H, W, dx);
+  dy.alloc((size_t)N * Ho * Wo * Cout * es);
+  ConvIO io;
+  io.N = N;
+  io.in = View{dx.p, Cin, Cin, H, W};
+  io.out = View{dy.p, Cout, Cout, Ho, Wo};
+  if (res) { to_dev(res, Cout, Ho, Wo, dr); io.res = View{dr.p, Cout, Cout, Ho, Wo}; }
+  L.launch(io, h->stream);
+  LP_HIP(hipStreamSynchronize(h->stream));
+  std::vector<uint8_t> raw((size_t)N * Ho * Wo * Cout * es);
+  LP_HIP(hipMemcpy(raw.data(), dy.p, raw.size(), hipMemcpyDeviceToHost));
+  const size_t npix = (size_t)N * Ho * Wo;
+  for (size_t p = 0; p < npix; ++p) {
+    const size_t b = p / ((size_t)Ho * Wo), yx = p % ((size_t)Ho * Wo);
+    for (int c = 0; c < Cout; ++c) {
+      float f;
+      if (prec == LP_FP16) { uint16_t hv; memcpy(&hv, &raw[(p * Cout + c) * 2], 2); f = f16_to_f32(hv); }
+      else memcpy(&f, &raw[(p * Cout + c) * 4], 4);
+      y[(b * Cout + c) * Ho * Wo + yx] = f;
+    }
+  }
+  LP_API_END
+}
+
+int lp_test_postprocess(lp_handle* h, const float* out0, int nc, int A, int orig_h, int orig_w, float ratio, float pad_w,
+                        float pad_h, float conf, float iou, lp_det* dets, int* count) {
+  LP_API_BEGIN
+  LP_CHECK(h && out0 && dets && count && nc >= 1 && A >= 1 && A <= 16384, LP_ERR_ARG, "bad argument");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  ImgGeom g;
+  memset(&g, 0, sizeof(g));
+  g.h = orig_h; g.w = orig_w; g.ratio = ratio; g.pad_w = pad_w; g.pad_h = pad_h;
+  DevBuf d_out0, d_geom, d_cand, d_sorted, d_cnt, d_dets, d_counts, d_rects;
+  d_out0.alloc((size_t)(4 + nc) * A * 4);
+  LP_HIP(hipMemcpy(d_out0.p, out0, (size_t)(4 + nc) * A * 4, hipMemcpyHostToDevice));
+  d_geom.alloc(sizeof(g));
+  LP_HIP(hipMemcpy(d_geom.p, &g, sizeof(g), hipMemcpyHostToDevice));
+  d_cand.alloc((size_t)A * sizeof(Cand)); d_sorted.alloc((size_t)A * sizeof(Cand)); d_cnt.alloc(16);
+  const int max_det = A;
+  d_dets.alloc((size_t)max_det * sizeof(lp_det)); d_counts.alloc(16); d_rects.alloc((size_t)max_det * 16);
+  launch_filter_out0(d_out0.as<float>(), nc, A, d_geom.as<ImgGeom>(), d_cand.as<Cand>(), d_cnt.as<int>(), conf, 1, h->stream);
+  NmsArgs a;
+  a.cand = d_cand.as<Cand>(); a.cand_count = d_cnt.as<int>(); a.sorted = d_sorted.as<Cand>(); a.dets = d_dets.as<lp_det>();
+  a.counts = d_counts.as<int>(); a.rects = d_rects.as<int>(); a.geom = d_geom.as<ImgGeom>(); a.A = A; a.max_det = max_det;
+  a.iou = iou; a.min_area = -1;
+  launch_nms(a, 1, h->stream);
+  LP_HIP(hipStreamSynchronize(h->stream));
+  LP_HIP(hipMemcpy(count, d_counts.p, 4, hipMemcpyDeviceToHost));
+  LP_HIP(hipMemcpy(dets, d_dets.p, (size_t)(*count) * sizeof(lp_det), hipMemcpyDeviceToHost));
+  LP_API_END
+}
+
+int lp_test_roi_resize(lp_handle* h, const uint8_t* const* rois, const int* hs, const int* ws, int R, uint8_t* out_rgb) {
+  LP_API_BEGIN
+  LP_CHECK(h && rois && hs && ws && out_rgb && R >= 1, LP_ERR_ARG, "bad argument");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  const int S = h->cfg.cls_input;
+  std::vector<ImgGeom> g(R);
+  std::vector<int> rects((size_t)R * 4), img(R), slot(R, 0);
+  size_t total = 0;
+  for (int i = 0; i < R; ++i) {
+    LP_CHECK(hs[i] > 0 && ws[i] > 0 && hs[i] <= 4096 && ws[i] <= 4096, LP_ERR_ARG, "ROI %d has a bad size", i);
+    memset(&g[i], 0, sizeof(ImgGeom));
+    g[i].src_off = (long)total; g[i].h = hs[i]; g[i].w = ws[i];
+    total += ((size_t)hs[i] * ws[i] * 3 + 15) & ~(size_t)15;
+    img[i] = i;
+    rects[i * 4 + 0] = 0; rects[i * 4 + 1] = 0; rects[i * 4 + 2] = ws[i]; rects[i * 4 + 3] = hs[i];
+  }
+  DevBuf d_src, d_geom, d_rects, d_img, d_slot, d_total, d_base, d_out;
+  d_src.alloc(total);
+  for (int i = 0; i < R; ++i) LP_HIP(hipMemcpy(d_src.as<uint8_t>() + g[i].src_off, rois[i], (size_t)hs[i] * ws[i] * 3, hipMemcpyHostToDevice));
+  d_geom.alloc((size_t)R * sizeof(ImgGeom));
+  LP_HIP(hipMemcpy(d_geom.p, g.data(), (size_t)R * sizeof(ImgGeom), hipMemcpyHostToDevice));
+  d_rects.alloc((size_t)R * 16); LP_HIP(hipMemcpy(d_rects.p, rects.data(), (size_t)R * 16, hipMemcpyHostToDevice));
+  d_img.alloc((size_t)R * 4); LP_HIP(hipMemcpy(d_img.p, img.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+  d_slot.alloc((size_t)R * 4);
+  d_total.alloc(16); LP_HIP(hipMemcpy(d_total.p, &R, 4, hipMemcpyHostToDevice));
+  d_base.alloc(16);
+  d_out.alloc((size_t)R * S * S * 3);
+  RoiResizeArgs r;
+  r.src = d_src.as<uint8_t>(); r.geom = d_geom.as<ImgGeom>(); r.rects = d_rects.as<int>();
+  r.tab.base = d_base.as<int>(); r.tab.total = d_total.as<int>(); r.tab.img = d_img.as<int>(); r.tab.slot = d_slot.as<int>();
+  r.out = d_out.as<uint8_t>(); r.max_det = 1; r.S = S;
+  launch_roi_resize(r, h->stream);
+  LP_HIP(hipStreamSynchronize(h->stream));
+  LP_HIP(hipMemcpy(out_rgb, d_out.p, (size_t)R * S * S * 3, hipMemcpyDeviceToHost));
+  LP_API_END
+}
+
+int lp_test_letterbox(lp_handle* h, const uint8_t* img, int H, int W, uint8_t* out, float* ratio, float* pad_w, float* pad_h) {
+  LP_API_BEGIN
+  LP_CHECK(h && img && out && H > 0 && W > 0, LP_ERR_ARG, "bad argument");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  const int S = h->cfg.det_input;
+  ImgGeom g = make_geom(H, W, S, 0);
+  DevBuf d_src, d_geom, d_out;
+  d_src.alloc((size_t)H * W * 3);
+  LP_HIP(hipMemcpy(d_src.p, img, (size_t)H * W * 3, hipMemcpyHostToDevice));
+  d_geom.alloc(sizeof(g));
+  LP_HIP(hipMemcpy(d_geom.p, &g, sizeof(g), hipMemcpyHostToDevice));
+  d_out.alloc((size_t)S * S * 3);
+  launch_letterbox(d_src.as<uint8_t>(), d_geom.as<ImgGeom>(), d_out.as<uint8_t>(), 1, S, h->stream);
+  LP_HIP(hipStreamSynchronize(h->stream));
+  LP_HIP(hipMemcpy(out, d_out.p, (size_t)S * S * 3, hipMemcpyDeviceToHost));
+  if (ratio) *ratio = g.ratio;
+  if (pad_w) *pad_w = g.pad_w;
+  if (pad_h) *pad_h = g.pad_h;
+  LP_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// ShuffleNetV2 x1.0 classifier plan (host side).  Replaces build_classifier('shufflenetv2')
+// + self.model(batch) of the reference (e2e.py:331-333,393).
+#pragma once
+#include "common.h"
+#include "conv.h"
+#include "detector.h"
+#include "kernels.h"
+
+namespace lp {
+
+struct NamedTensor {
+  const float* data = nullptr;
+  std::vector<int64_t> shape;
+  size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; }
+};
+
+class Classifier {
+ public:
+  Classifier(int prec, int impl, int max_rois, int num_classes, int input_size);
+  // torchvision shufflenet_v2_x1_0 state_dict (fc replaced by Linear(1024, num_classes))
+  void load(const std::map<std::string, NamedTensor>& sd);
+  bool loaded() const { return loaded_; }
+  int num_classes() const { return ncls_; }
+  int logits_pitch() const { return lpitch_; }
+  const float* logits() const { return d_logits_.as<float>(); }
+  // rgb: device uint8 [R,S,S,3]; d_R: device ROI count.  Leaves fp32 logits [R, logits_pitch()].
+  void forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Profiler* prof);
+
+ private:
+  struct DwLayer { DevBuf w, b; int C = 0, stride = 1; std::string name; };
+  struct Block {
+    int stride = 1, inp = 0, oup = 0;
+    int b1_dw = -1, b1_pw = -1;          // stride 2 only
+    int b2_pw1 = -1, b2_dw = -1, b2_pw2 = -1;
+    std::string name;
+  };
+  struct Act { DevBuf mem; int C = 0, H = 0, W = 0; };   // [max_rois,H,W,C]
+  View act_view(const Act& a, int coff = 0, int C = -1) const;
+  void alloc_act(Act& a, int C, int H, int W);
+  int add_pw(const std::string& name, const std::vector<float>& w_phys, const std::vector<float>& b_phys, int cin, int cout, int act, int hw);
+  int add_dw(const std::string& name, const std::vector<float>& w_phys, const std::vector<float>& b_phys, int C, int stride);
+
+  int prec_, impl_, maxR_, ncls_, S_, lpitch_ = 0;
+  bool loaded_ = false;
+  std::vector<std::unique_ptr<ConvLayer>> pws_;
+  std::vector<DwLayer> dws_;
+  std::vector<Block> blocks_;
+  DevBuf stem_w_, stem_b_;
+  int conv5_ = -1, fc_ = -1;
+  // activations
+  Act a_stem_, a_pool_, a_t1_, a_t2_, a_b1dw_, a_b1_, a_stage_[3][2], a_conv5_, a_mean_;
+  DevBuf d_logits_;
+  int half_c_[3], half_cp_[3];
+};
+
+}  // namespace lp

@@ -1,0 +1,251 @@
+// ShuffleNetV2 classifier kernels other than the pointwise convs (those are the MFMA 1x1
+// kernel of conv_kernels.hip).  Replaces the torch-CPU ops behind self.model(batch) and the
+// ToTensor/Normalize/softmax/argmax glue of PyTorchClassifier.predict_batch (reference
+// e2e.py:366-370,391-396).  The ROI count R lives in device memory (m_dyn): every kernel is
+// a grid-stride loop bounded by it, so the whole pipeline runs without a host round trip.
+#include "common.h"
+#include "kernels.h"
+
+namespace lp {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct VecT;
+template <> struct VecT<half_t> { typedef half8 type; static constexpr int G = 8; };
+template <> struct VecT<float> { typedef floatx4 type; static constexpr int G = 4; };
+
+static inline unsigned grid_for(long max_work) {
+  long b = (max_work + 255) / 256;
+  if (b < 1) b = 1;
+  return (unsigned)(b > 2048 ? 2048 : b);
+}
+
+// ------------------------------------------------------------------------------------
+// conv1: 3x3 stride 2 pad 1, 3 -> CO, on t = (x/255 - 0.18)/0.34 (ToTensor + Normalize,
+// e2e.py:368-369); zero padding applies to t.  One thread per output pixel.
+// ------------------------------------------------------------------------------------
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void cls_stem_kernel(const uint8_t* __restrict__ rgb, T* __restrict__ out,
+                                                       const float* __restrict__ w, const float* __restrict__ bias, int S,
+                                                       int out_pitch, const int* __restrict__ m_dyn) {
+  const int So = S / 2;
+  const long total = (long)(*m_dyn) * So * So;
+  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long)gridDim.x * 256) {
+    const int ox = (int)(pix % So);
+    const int oy = (int)((pix / So) % So);
+    const long r = pix / ((long)So * So);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= S) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= S) continue;
+        const uint8_t* px = rgb + ((r * S + iy) * S + ix) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float t = __fdiv_rn(__fsub_rn(__fdiv_rn((float)px[c], 255.f), 0.18f), 0.34f);
+          const float* wr = w + ((ky * 3 + kx) * 3 + c) * CO;
+#pragma unroll
+          for (int co = 0; co < CO; ++co) acc[co] = fmaf(t, wr[co], acc[co]);
+        }
+      }
+    }
+    T* o = out + pix * out_pitch;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) o[co] = (T)fmaxf(acc[co] + bias[co], 0.f);
+  }
+}
+
+void launch_cls_stem(int prec, const uint8_t* rgb, const float* w, const float* bias, int CO, const View& out, int S,
+                     const int* m_dyn, int max_items, hipStream_t st) {
+  LP_CHECK(CO == 24, LP_ERR_STATE, "classifier stem expects 24 output channels");
+  dim3 grid(grid_for((long)max_items * (S / 2) * (S / 2)));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL((cls_stem_kernel<half_t, 24>), grid, dim3(256), 0, st, rgb, (half_t*)out.base, w, bias, S, out.pitch, m_dyn);
+  else
+    hipLaunchKernelGGL((cls_stem_kernel<float, 24>), grid, dim3(256), 0, st, rgb, (float*)out.base, w, bias, S, out.pitch, m_dyn);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int CG,
+                                                           int in_pitch, int out_pitch, const int* __restrict__ m_dyn) {
+  typedef typename VecT<T>::type vec;
+  constexpr int G = VecT<T>::G;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)(*m_dyn) * Ho * Wo * CG;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    const long pix = idx / CG;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const long r = pix / ((long)Wo * Ho);
+    vec m;
+#pragma unroll
+    for (int i = 0; i < G; ++i) m[i] = (T)-INFINITY;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const vec v = *reinterpret_cast<const vec*>(in + ((r * H + iy) * W + ix) * in_pitch + cg * G);
+#pragma unroll
+        for (int i = 0; i < G; ++i) m[i] = v[i] > m[i] ? v[i] : m[i];
+      }
+    }
+    *reinterpret_cast<vec*>(out + pix * out_pitch + cg * G) = m;
+  }
+}
+
+void launch_maxpool3x3s2(int prec, const View& in, const View& out, const int* m_dyn, int max_items, hipStream_t st) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const int CG = in.C / G;
+  dim3 grid(grid_for((long)max_items * out.H * out.W * CG));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, in.H,
+                       in.W, CG, in.pitch, out.pitch, m_dyn);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, in.H, in.W,
+                       CG, in.pitch, out.pitch, m_dyn);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+// depthwise 3x3, pad 1, stride 1|2, + bias (folded BN), no activation
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, int H,
+                                                        int W, int Ho, int Wo, int C, int stride, int in_pitch, int out_pitch,
+                                                        const int* __restrict__ m_dyn) {
+  typedef typename VecT<T>::type vec;
+  constexpr int G = VecT<T>::G;
+  const int CG = C / G;
+  const long total = (long)(*m_dyn) * Ho * Wo * CG;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    const long pix = idx / CG;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const long r = pix / ((long)Wo * Ho);
+    float acc[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) acc[i] = bias[cg * G + i];
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * stride - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * stride - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const vec v = *reinterpret_cast<const vec*>(in + ((r * H + iy) * W + ix) * in_pitch + cg * G);
+        const float* wr = w + (ky * 3 + kx) * C + cg * G;
+#pragma unroll
+        for (int i = 0; i < G; ++i) acc[i] = fmaf((float)v[i], wr[i], acc[i]);
+      }
+    }
+    vec o;
+#pragma unroll
+    for (int i = 0; i < G; ++i) o[i] = (T)acc[i];
+    *reinterpret_cast<vec*>(out + pix * out_pitch + cg * G) = o;
+  }
+}
+
+void launch_dwconv3x3(int prec, const View& in, const View& out, const float* w, const float* bias, int stride,
+                      const int* m_dyn, int max_items, hipStream_t st) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  dim3 grid(grid_for((long)max_items * out.H * out.W * (in.C / G)));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(dwconv3x3_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, w, bias,
+                       in.H, in.W, out.H, out.W, in.C, stride, in.pitch, out.pitch, m_dyn);
+  else
+    hipLaunchKernelGGL(dwconv3x3_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, w, bias, in.H,
+                       in.W, out.H, out.W, in.C, stride, in.pitch, out.pitch, m_dyn);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const T* __restrict__ in, T* __restrict__ out, int HW, int CG,
+                                                           int in_pitch, int out_pitch, const int* __restrict__ m_dyn) {
+  typedef typename VecT<T>::type vec;
+  constexpr int G = VecT<T>::G;
+  const long total = (long)(*m_dyn) * CG;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    const long r = idx / CG;
+    float acc[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) acc[i] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      const vec v = *reinterpret_cast<const vec*>(in + (r * HW + p) * in_pitch + cg * G);
+#pragma unroll
+      for (int i = 0; i < G; ++i) acc[i] += (float)v[i];
+    }
+    vec o;
+#pragma unroll
+    for (int i = 0; i < G; ++i) o[i] = (T)(acc[i] / (float)HW);
+    *reinterpret_cast<vec*>(out + r * out_pitch + cg * G) = o;
+  }
+}
+
+void launch_spatial_mean(int prec, const View& in, const View& out, const int* m_dyn, int max_items, hipStream_t st) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const int CG = in.C / G;
+  dim3 grid(grid_for((long)max_items * CG));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(spatial_mean_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base,
+                       in.H * in.W, CG, in.pitch, out.pitch, m_dyn);
+  else
+    hipLaunchKernelGGL(spatial_mean_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base,
+                       in.H * in.W, CG, in.pitch, out.pitch, m_dyn);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+// softmax(dim=1) + argmax (e2e.py:394-396), one thread per ROI
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __restrict__ logits, int pitch, int nc,
+                                                             float* __restrict__ probs, int* __restrict__ ids,
+                                                             float* __restrict__ conf, lp_det* dets, int max_det,
+                                                             const int* __restrict__ roi_img, const int* __restrict__ roi_slot,
+                                                             const int* __restrict__ m_dyn) {
+  const int R = *m_dyn;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+    const float* l = logits + (long)r * pitch;
+    float mx = -INFINITY;
+    for (int c = 0; c < nc; ++c) mx = fmaxf(mx, l[c]);
+    float sum = 0.f;
+    for (int c = 0; c < nc; ++c) sum += expf(l[c] - mx);
+    float best = -1.f;
+    int best_c = 0;
+    for (int c = 0; c < nc; ++c) {
+      const float p = expf(l[c] - mx) / sum;
+      if (probs) probs[(long)r * nc + c] = p;
+      if (p > best) { best = p; best_c = c; }
+    }
+    if (ids) ids[r] = best_c;
+    if (conf) conf[r] = best;
+    if (dets) {
+      lp_det* d = dets + (long)roi_img[r] * max_det + roi_slot[r];
+      d->cls_class = best_c;
+      d->cls_conf = best;
+    }
+  }
+}
+
+void launch_softmax_argmax(const float* logits, int pitch, int nc, float* probs, int* ids, float* conf, lp_det* dets,
+                           int max_det, const RoiTable* tab, const int* m_dyn, int max_items, hipStream_t st) {
+  dim3 grid(grid_for(max_items));
+  hipLaunchKernelGGL(softmax_argmax_kernel, grid, dim3(256), 0, st, logits, pitch, nc, probs, ids, conf, dets, max_det,
+                     tab ? tab->img : nullptr, tab ? tab->slot : nullptr, m_dyn);
+  LP_HIP(hipGetLastError());
+}
+
+}  // namespace lp

@@ -1,0 +1,112 @@
+// Shared host-side declarations for liblitepi_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/litepi.h"
+
+namespace lp {
+
+// ---- errors ---------------------------------------------------------------------
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+std::string fmt(const char* f, ...) __attribute__((format(printf, 1, 2)));
+void set_last_error(const std::string& s);
+
+#define LP_HIP(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      throw lp::Error(LP_ERR_HIP, lp::fmt("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                          __FILE__, __LINE__));                            \
+  } while (0)
+
+#define LP_CHECK(cond, code, ...)                                \
+  do {                                                           \
+    if (!(cond)) throw lp::Error(code, lp::fmt(__VA_ARGS__));    \
+  } while (0)
+
+// ---- device memory ----------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t n, bool zero = true) {
+    release();
+    if (n == 0) n = 16;
+    LP_HIP(hipMalloc(&p, n));
+    bytes = n;
+    if (zero) LP_HIP(hipMemset(p, 0, n));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// fp32 <-> fp16 on the host (round-to-nearest-even; weights are converted once at load)
+uint16_t f32_to_f16(float f);
+float f16_to_f32(uint16_t h);
+
+// ---- a channel-slice view of an NHWC activation buffer ------------------------------
+struct View {
+  void* base = nullptr;  // address of channel 0 of pixel 0 of THIS view (offset already applied)
+  int C = 0;             // physical channels of the view (multiple of 8)
+  int pitch = 0;         // physical channels per pixel of the underlying buffer
+  int H = 0, W = 0;
+};
+
+// ---- kernel-side argument blocks ----------------------------------------------------
+struct ConvArgs {
+  const void* in;
+  void* out;
+  const void* res;      // optional residual added after the activation (same shape as out)
+  const void* x1;       // shuffle-interleave partner (classifier epilogue)
+  const void* wpk;      // weights packed for the chosen kernel
+  const float* bias;    // fp32 [padded Cout]
+  const int* m_dyn;     // optional device scalar: number of items (ROIs); M = *m_dyn * pix_per_item
+  int N, Hin, Win, Hout, Wout;
+  int in_pitch, out_pitch, res_pitch, x1_pitch;
+  int Cin, Cout;        // physical channel counts
+  int act;              // 0 none, 1 SiLU, 2 ReLU
+  int M;                // 1x1: flattened pixel count (static)
+  int pix_per_item;
+  // 3x3 MFMA tiling
+  int CK, nchunks, steps_per_chunk, CGc, LW, PS, bwh, bww, tiles_x, tiles_y;
+  // 1x1 MFMA
+  int steps;            // K steps over all of Cin
+  int nsplit_tiles;     // channel tiles handled per block (== NT template arg)
+  // shuffle epilogue
+  int half_c, half_cp;  // logical / physical channels of one half of the output
+  int out_f32;          // store fp32 regardless of T (classifier logits)
+};
+
+enum ConvImpl { IMPL_MFMA = 0, IMPL_NAIVE = 1 };
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+
+}  // namespace lp

@@ -1,0 +1,43 @@
+// Host-side handles of the convolution kernels (conv_kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace lp {
+
+struct ConvIO {
+  View in, out, res, x1;
+  int N = 0;
+  const int* m_dyn = nullptr;  // device scalar item count (classifier); M = *m_dyn * out.H * out.W
+  int half_c = 0, half_cp = 0; // shuffle epilogue geometry (x1.base != nullptr)
+  int out_f32 = 0;
+};
+
+// One Convolution(+bias)(+activation)(+residual) layer with its device weights, packed for
+// the kernel family chosen at build time.
+struct ConvLayer {
+  int prec = LP_FP16, impl = IMPL_MFMA;
+  int k = 1, stride = 1, Cin = 0, Cout = 0, act = ACT_NONE;
+  // MFMA tiling
+  int NT = 1, nsplits = 1, CK = 0, CGc = 0, nchunks = 1, steps = 0, LW = 0, PS = 0, bwh = 2, bww = 2;
+  size_t lds_bytes = 0;
+  DevBuf d_w, d_bias;
+  std::string name;
+  double macs_per_pixel() const { return (double)k * k * Cin * Cout; }
+
+  // w_phys: fp32 [Cout][k*k][Cin] over PHYSICAL channels (zeros at padding channels);
+  // bias_phys: fp32 [Cout] or empty.  hout/wout: output map size (picks the 3x3 tile shape).
+  void build(int prec, int impl, int k, int stride, int cin, int cout, int act,
+             const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout);
+  void launch(const ConvIO& io, hipStream_t st) const;
+};
+
+// First layer: 3x3 stride-2 conv reading the uint8 BGR image directly.
+struct StemLayer {
+  int prec = LP_FP16, CO = 8, act = ACT_SILU;
+  DevBuf d_w, d_bias;
+  // w_bgr: fp32 [27][CO], row = (ky*3+kx)*3 + c with c in BGR order
+  void build(int prec, int cout_phys, int act, const std::vector<float>& w_bgr, const std::vector<float>& bias);
+  void launch(const uint8_t* img, int N, int Hin, int Win, const View& out, hipStream_t st) const;
+};
+
+}  // namespace lp

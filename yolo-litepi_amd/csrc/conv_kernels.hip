@@ -1,0 +1,589 @@
+// Convolution kernels for gfx950 (CDNA4).  Replaces the NCNN / ONNX Runtime conv
+// layers behind ex.extract("out0") (reference src/tt100k/pipeline/e2e.py:305-307;
+// graph model.ncnn.param:4-182) and the ShuffleNetV2 pointwise convs behind
+// self.model(batch) (e2e.py:393).
+//
+// Layout: activations are NHWC with a channel pitch, so C2f/SPPF/FPN concats are
+// channel slices of one buffer and never materialised.  Orientation of the MFMA:
+//     D[out-channel][pixel] = sum_k  W[out-channel][k] * X[k][pixel]
+// i.e. A = weights (16 rows = out channels), B = 16 pixels, K = taps x in-channels
+// walked in 16-byte groups (8 fp16 / 4 fp32 channels), which are contiguous in NHWC
+// for a fixed tap, so every operand fragment is one 16-byte load.  The D fragment
+// holds 4 consecutive rows per lane; the weight rows are permuted at pack time so
+// those are 4 (x tiles) consecutive physical channels of one pixel -> vector stores.
+#include "common.h"
+#include "conv.h"
+
+namespace lp {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+enum { EPI_PLAIN = 0, EPI_SHUFFLE = 1 };
+
+template <typename T> struct Tr;
+template <> struct Tr<half_t> {
+  static constexpr int G = 8;  // channels per 16-byte K group
+  typedef half8 frag;
+  typedef half4 quad;
+  static __device__ __forceinline__ floatx4 mma(frag a, frag b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
+};
+template <> struct Tr<float> {
+  static constexpr int G = 4;
+  typedef floatx4 frag;
+  typedef floatx4 quad;
+  // exact-f32 MFMA (one K=4 instruction per element of the 16-byte group)
+  static __device__ __forceinline__ floatx4 mma(frag a, frag b, floatx4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
+};
+
+template <typename T> __device__ __forceinline__ float activate(float v, int act) {
+  if (act == ACT_SILU) return Tr<T>::silu(v);
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+
+template <typename T> __device__ __forceinline__ typename Tr<T>::frag as_frag(u32x4 v) {
+  return __builtin_bit_cast(typename Tr<T>::frag, v);
+}
+
+// One lane's 4 consecutive output channels of one pixel: bias, activation, residual,
+// store.  ch0 is the first physical channel of the quad.
+template <typename T, int EPI>
+__device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0, floatx4 v) {
+  const floatx4 b = *reinterpret_cast<const floatx4*>(a.bias + ch0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = activate<T>(v[i] + b[i], a.act);
+  if (EPI == EPI_SHUFFLE) {
+    // ShuffleNetV2 channel_shuffle(cat(x1, y), 2) fused into the store: logical output
+    // channel 2c = x1[c], 2c+1 = y[c]; each half of the output is padded to half_cp.
+    const T* x1 = reinterpret_cast<const T*>(a.x1) + pix * a.x1_pitch;
+    T* o = reinterpret_cast<T*>(a.out) + pix * a.out_pitch;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = ch0 + i;
+      if (c < a.half_c) {
+        const int l = 2 * c;
+        const int phys = l < a.half_c ? l : a.half_cp + (l - a.half_c);
+        o[phys] = x1[c];
+        o[phys + 1] = (T)v[i];
+      }
+    }
+    return;
+  }
+  if (a.res) {
+    const typename Tr<T>::quad r =
+        *reinterpret_cast<const typename Tr<T>::quad*>(reinterpret_cast<const T*>(a.res) + pix * a.res_pitch + ch0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)r[i];
+  }
+  if (a.out_f32) {
+    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.out) + pix * a.out_pitch + ch0) = v;
+  } else {
+    typename Tr<T>::quad q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = (T)v[i];
+    *reinterpret_cast<typename Tr<T>::quad*>(reinterpret_cast<T*>(a.out) + pix * a.out_pitch + ch0) = q;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// 3x3 (pad 1, stride 1|2) implicit GEMM.  One workgroup = bwh x bww waves; each wave owns
+// a 4-row x 20-column strip of output pixels = five 4x4 patches (one MFMA column tile
+// each) x NT 16-channel tiles.  20 divides every level of a 640 input (160/80/40/20), so
+// no lane is wasted there; other sizes are masked.  Per K chunk (CK input channels) the
+// block stages the halo'd input tile and the chunk's weight fragments in LDS.
+// LDS image of the input: [IH][LW] pixels x PS bytes; PS/16 is odd and LW = 4 or 12 (mod
+// 16) so that the 16 pixels of a patch fall on distinct 16-byte slots of the 256-byte bank
+// row for ds_read_b128.
+// ------------------------------------------------------------------------------------
+template <typename T, int NT, int STRIDE>
+__global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = Tr<T>::G;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int wy = wave / a.bww, wx = wave - wy * a.bww;
+  const int TH = 4 * a.bwh, TW = 20 * a.bww;
+  const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+  const int n = blockIdx.y, ns = blockIdx.z;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+  const int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
+  const int Sc = a.steps_per_chunk, CGc = a.CGc, LW = a.LW, PS = a.PS;
+
+  u32x4* lds_w = reinterpret_cast<u32x4*>(smem);
+  char* lds_in = smem + (size_t)Sc * NT * 1024;
+
+  const int ly = wy * 4 + (col >> 2);
+  int pbase[5];
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const int lx = wx * 20 + p * 4 + (col & 3);
+    pbase[p] = ((ly * STRIDE) * LW + lx * STRIDE) * PS;
+  }
+
+  floatx4 acc[NT][5];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int p = 0; p < 5; ++p) acc[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const T* in = reinterpret_cast<const T*>(a.in);
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    if (chunk) __syncthreads();
+    // weights of this (channel split, chunk): already in fragment order, 16 B per lane
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + ((size_t)(ns * a.nchunks + chunk) * Sc * NT) * 64;
+    for (int i = tid; i < Sc * NT * 64; i += nthr) lds_w[i] = wsrc[i];
+    // halo'd input tile, zero outside the image (= the conv's zero padding)
+    const int cbase = chunk * a.CK;
+    for (int i = tid; i < IH * IW * CGc; i += nthr) {
+      const int pix = i / CGc, cg = i - pix * CGc;
+      const int iy = pix / IW, ix = pix - iy * IW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
+        v = *reinterpret_cast<const u32x4*>(in + ((long)(n * a.Hin + gy) * a.Win + gx) * a.in_pitch + cbase + cg * G);
+      *reinterpret_cast<u32x4*>(lds_in + (iy * LW + ix) * PS + cg * 16) = v;
+    }
+    __syncthreads();
+    for (int s = 0; s < Sc; ++s) {
+      const int q = 4 * s + g;
+      int tap = q / CGc;
+      const int cg = q - tap * CGc;
+      tap = tap > 8 ? 8 : tap;  // K padding slots: weights are zero, read any finite data
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int toff = (ky * LW + kx) * PS + cg * 16;
+      typename Tr<T>::frag af[NT], bf[5];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w[(s * NT + t) * 64 + lane]);
+#pragma unroll
+      for (int p = 0; p < 5; ++p) bf[p] = as_frag<T>(*reinterpret_cast<const u32x4*>(lds_in + pbase[p] + toff));
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 5; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
+    }
+  }
+
+  const int oy = oy0 + ly;
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const int ox = ox0 + wx * 20 + p * 4 + (col & 3);
+    if (oy < a.Hout && ox < a.Wout) {
+      const long pix = (long)(n * a.Hout + oy) * a.Wout + ox;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
+        if (ch0 < a.Cout) store_quad<T, EPI_PLAIN>(a, pix, ch0, acc[t][p]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// 1x1 conv = GEMM over flattened pixels.  Every pixel is read exactly once, so the pixel
+// operand goes straight from global memory to registers (16 B per lane); the weights of
+// this block's channel split live in LDS for the whole (grid-stride) pixel loop.  M may come
+// from device memory (m_dyn): the classifier's ROI count is only known on the GPU.
+// ------------------------------------------------------------------------------------
+template <typename T, int NT, int NP, int EPI>
+__global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = Tr<T>::G;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int ns = blockIdx.y;
+  const int S = a.steps;
+  const int CG = a.Cin / G;
+
+  u32x4* lds_w = reinterpret_cast<u32x4*>(smem);
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)ns * S * NT * 64;
+  for (int i = tid; i < S * NT * 64; i += 256) lds_w[i] = wsrc[i];
+  __syncthreads();
+
+  const long M = a.m_dyn ? (long)(*a.m_dyn) * a.pix_per_item : (long)a.M;
+  const long ntiles = (M + 64 * NP - 1) / (64 * NP);
+  const T* in = reinterpret_cast<const T*>(a.in);
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long pix0 = (tile * 4 + wave) * 16 * NP;
+    if (pix0 >= M) continue;
+    const T* src[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      long pix = pix0 + p * 16 + col;
+      pix = pix < M ? pix : M - 1;
+      src[p] = in + pix * a.in_pitch;
+    }
+    floatx4 acc[NT][NP];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) acc[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < S; ++s) {
+      const int q = 4 * s + g;
+      typename Tr<T>::frag af[NT], bf[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (q < CG) v = *reinterpret_cast<const u32x4*>(src[p] + q * G);
+        bf[p] = as_frag<T>(v);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w[(s * NT + t) * 64 + lane]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const long pix = pix0 + p * 16 + col;
+      if (pix < M) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
+          if (ch0 < a.Cout) store_quad<T, EPI>(a, pix, ch0, acc[t][p]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Naive direct convolution (one thread per output element, fp32 accumulate).  GPU-side
+// debugging aid selected with lp_config.conv_impl = 1; never the product path.
+// Weights: [Cout][k*k][Cin] as T.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_naive_kernel(const ConvArgs a, int k, int stride) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long M = a.m_dyn ? (long)(*a.m_dyn) * a.pix_per_item : (long)a.N * a.Hout * a.Wout;
+  if (idx >= M * a.Cout) return;
+  const int co = (int)(idx % a.Cout);
+  const long pix = idx / a.Cout;
+  const int ox = (int)(pix % a.Wout);
+  const int oy = (int)((pix / a.Wout) % a.Hout);
+  const int n = (int)(pix / ((long)a.Wout * a.Hout));
+  const int pad = k / 2;
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* w = reinterpret_cast<const T*>(a.wpk) + (size_t)co * k * k * a.Cin;
+  float acc = 0.f;
+  for (int ky = 0; ky < k; ++ky) {
+    const int iy = oy * stride - pad + ky;
+    if (iy < 0 || iy >= a.Hin) continue;
+    for (int kx = 0; kx < k; ++kx) {
+      const int ix = ox * stride - pad + kx;
+      if (ix < 0 || ix >= a.Win) continue;
+      const T* px = in + ((long)(n * a.Hin + iy) * a.Win + ix) * a.in_pitch;
+      const T* wt = w + (ky * k + kx) * a.Cin;
+      for (int ci = 0; ci < a.Cin; ++ci) acc = fmaf((float)px[ci], (float)wt[ci], acc);
+    }
+  }
+  float v = activate<T>(acc + a.bias[co], a.act);
+  if (a.x1) {  // shuffle epilogue (see store_quad)
+    if (co < a.half_c) {
+      const int l = 2 * co;
+      const int phys = l < a.half_c ? l : a.half_cp + (l - a.half_c);
+      T* o = reinterpret_cast<T*>(a.out) + pix * a.out_pitch;
+      o[phys] = reinterpret_cast<const T*>(a.x1)[pix * a.x1_pitch + co];
+      o[phys + 1] = (T)v;
+    }
+    return;
+  }
+  if (a.res) v += (float)reinterpret_cast<const T*>(a.res)[pix * a.res_pitch + co];
+  if (a.out_f32)
+    reinterpret_cast<float*>(a.out)[pix * a.out_pitch + co] = v;
+  else
+    reinterpret_cast<T*>(a.out)[pix * a.out_pitch + co] = (T)v;
+}
+
+// ------------------------------------------------------------------------------------
+// Stem: 3x3 stride-2 pad-1 conv straight from the uint8 BGR image (the reference's
+// BGR->RGB + x*(1/255) + HWC->CHW preprocessing, e2e.py:222-238, is folded in: the weight
+// table is stored in BGR order and the scale is applied to the pixel before the FMA).
+// One thread = one output pixel x all CO channels.  w: fp32 [27][CO], k = (ky*3+kx)*3 + c_bgr.
+// ------------------------------------------------------------------------------------
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restrict__ img, T* __restrict__ out,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int N, int Hin, int Win, int Hout, int Wout, int out_pitch,
+                                                        int act) {
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (long)N * Hout * Wout) return;
+  const int ox = (int)(pix % Wout);
+  const int oy = (int)((pix / Wout) % Hout);
+  const int n = (int)(pix / ((long)Wout * Hout));
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  const float inv255 = 1.f / 255.f;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+    if (iy < 0 || iy >= Hin) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - 1 + kx;
+      if (ix < 0 || ix >= Win) continue;
+      const uint8_t* px = img + ((long)(n * Hin + iy) * Win + ix) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = (float)px[c] * inv255;
+        const float* wr = w + ((ky * 3 + kx) * 3 + c) * CO;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
+      }
+    }
+  }
+  T* o = out + pix * out_pitch;
+#pragma unroll
+  for (int c0 = 0; c0 < CO; c0 += 4) {
+    typename Tr<T>::quad q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = (T)activate<T>(acc[c0 + i] + bias[c0 + i], act);
+    *reinterpret_cast<typename Tr<T>::quad*>(o + c0) = q;
+  }
+}
+
+// ====================================================================================
+// Host side: weight packing and launch
+// ====================================================================================
+static size_t elem_size(int prec) { return prec == LP_FP16 ? 2 : 4; }
+
+static void put_elem(std::vector<uint8_t>& buf, size_t idx, int prec, float v) {
+  if (prec == LP_FP16) {
+    uint16_t h = f32_to_f16(v);
+    memcpy(&buf[idx * 2], &h, 2);
+  } else {
+    memcpy(&buf[idx * 4], &v, 4);
+  }
+}
+
+void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int cout, int act_,
+                      const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout) {
+  prec = prec_; impl = impl_; k = k_; stride = stride_; Cin = cin; Cout = cout; act = act_;
+  LP_CHECK(k == 1 || k == 3, LP_ERR_GRAPH, "conv kernel size %d unsupported", k);
+  LP_CHECK(Cin % 8 == 0 && Cout % 8 == 0, LP_ERR_GRAPH, "physical channels must be multiples of 8");
+  const int taps = k * k;
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const size_t es = elem_size(prec);
+  const int tiles_total = ceil_div(Cout, 16);
+
+  // bias, padded so every quad load is in bounds
+  std::vector<float> b(round_up(Cout, 64) + 64, 0.f);
+  for (int c = 0; c < Cout; ++c) b[c] = bias_phys.empty() ? 0.f : bias_phys[c];
+  d_bias.alloc(b.size() * 4);
+  LP_HIP(hipMemcpy(d_bias.p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+
+  if (impl == IMPL_NAIVE) {
+    std::vector<uint8_t> buf((size_t)Cout * taps * Cin * es);
+    for (size_t i = 0; i < (size_t)Cout * taps * Cin; ++i) put_elem(buf, i, prec, w_phys[i]);
+    d_w.alloc(buf.size());
+    LP_HIP(hipMemcpy(d_w.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    return;
+  }
+
+  // channel tiles per block
+  NT = tiles_total >= 4 ? 4 : tiles_total;
+  if (tiles_total % 4 != 0 && tiles_total > 4) NT = (tiles_total % 3 == 0) ? 3 : 4;
+  nsplits = ceil_div(tiles_total, NT);
+
+  if (k == 3) {
+    // K chunking: largest CK (multiple of 8, divides Cin) whose LDS footprint fits the budget
+    const bool small_map = (hout <= 20 && wout <= 20);
+    bwh = small_map ? 5 : 2;
+    bww = small_map ? 1 : 2;
+    const int TH = 4 * bwh, TW = 20 * bww;
+    const int IH = (TH - 1) * stride + 3, IW = (TW - 1) * stride + 3;
+    LW = IW;
+    while (!(LW % 16 == 4 || LW % 16 == 12)) ++LW;
+    const size_t budget = 64 * 1024;
+    int best = 8;
+    for (int ck = 8; ck <= Cin && ck <= 64; ck += 8) {
+      if (Cin % ck) continue;
+      const int cgc = ck / G;
+      const int ps = ((cgc % 2 == 0) ? cgc + 1 : cgc + 2) * 16;
+      const size_t lds = (size_t)ceil_div(taps * cgc, 4) * NT * 1024 + (size_t)IH * LW * ps;
+      if (lds <= budget) best = ck;
+    }
+    CK = best;
+    CGc = CK / G;
+    PS = ((CGc % 2 == 0) ? CGc + 1 : CGc + 2) * 16;
+    nchunks = Cin / CK;
+    steps = ceil_div(taps * CGc, 4);
+    lds_bytes = (size_t)steps * NT * 1024 + (size_t)IH * LW * PS;
+    LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv3x3 tile does not fit LDS (%zu B)", lds_bytes);
+  } else {
+    CK = Cin;
+    CGc = Cin / G;
+    nchunks = 1;
+    steps = ceil_div(CGc, 4);
+    // all K of this block's channel split stays in LDS: fewer channel tiles per block for deep K
+    while (NT > 1 && (size_t)steps * NT * 1024 > 96 * 1024) --NT;
+    nsplits = ceil_div(tiles_total, NT);
+    lds_bytes = (size_t)steps * NT * 1024;
+    LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv1x1 weights do not fit LDS (%zu B)", lds_bytes);
+  }
+
+  // fragment-ordered weights: [split][chunk][step][tile][lane][G]
+  const size_t nfrag = (size_t)nsplits * nchunks * steps * NT * 64;
+  std::vector<uint8_t> buf(nfrag * 16, 0);
+  for (int ns = 0; ns < nsplits; ++ns)
+    for (int ch = 0; ch < nchunks; ++ch)
+      for (int s = 0; s < steps; ++s)
+        for (int t = 0; t < NT; ++t)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int g = lane >> 4, m = lane & 15;
+            const int gm = m >> 2, r = m & 3;
+            const int oc = ns * 16 * NT + gm * 4 * NT + t * 4 + r;  // row permutation (see header)
+            const int q = 4 * s + g;
+            const int tap = q / CGc, cg = q % CGc;
+            if (tap >= taps || oc >= Cout) continue;
+            const size_t f = ((((size_t)ns * nchunks + ch) * steps + s) * NT + t) * 64 + lane;
+            for (int j = 0; j < G; ++j) {
+              const int ci = ch * CK + cg * G + j;
+              put_elem(buf, f * G + j, prec, w_phys[((size_t)oc * taps + tap) * Cin + ci]);
+            }
+          }
+  d_w.alloc(buf.size());
+  LP_HIP(hipMemcpy(d_w.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+}
+
+template <typename T, int NT>
+static void launch3x3(const ConvArgs& a, int stride, dim3 grid, int threads, size_t lds, hipStream_t st) {
+  if (stride == 1) {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<T, NT, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, NT, 1>), grid, dim3(threads), lds, st, a);
+  } else {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<T, NT, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, NT, 2>), grid, dim3(threads), lds, st, a);
+  }
+}
+
+template <typename T, int NT, int NP, int EPI>
+static void launch1x1_(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_mfma_kernel<T, NT, NP, EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  hipLaunchKernelGGL((conv1x1_mfma_kernel<T, NT, NP, EPI>), grid, dim3(256), lds, st, a);
+}
+
+template <typename T, int NT>
+static void launch1x1(const ConvArgs& a, bool shuffle, dim3 grid, size_t lds, hipStream_t st) {
+  if (shuffle)
+    launch1x1_<T, NT, 4, EPI_SHUFFLE>(a, grid, lds, st);
+  else
+    launch1x1_<T, NT, 4, EPI_PLAIN>(a, grid, lds, st);
+}
+
+void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = io.in.base; a.out = io.out.base; a.res = io.res.base; a.x1 = io.x1.base;
+  a.wpk = d_w.p; a.bias = d_bias.as<float>(); a.m_dyn = io.m_dyn;
+  a.N = io.N; a.Hin = io.in.H; a.Win = io.in.W; a.Hout = io.out.H; a.Wout = io.out.W;
+  a.in_pitch = io.in.pitch; a.out_pitch = io.out.pitch; a.res_pitch = io.res.pitch; a.x1_pitch = io.x1.pitch;
+  a.Cin = Cin; a.Cout = Cout; a.act = act;
+  a.M = io.N * io.out.H * io.out.W; a.pix_per_item = io.out.H * io.out.W;
+  a.CK = CK; a.nchunks = nchunks; a.steps_per_chunk = steps; a.CGc = CGc; a.LW = LW; a.PS = PS;
+  a.bwh = bwh; a.bww = bww; a.steps = steps; a.nsplit_tiles = NT;
+  a.half_c = io.half_c; a.half_cp = io.half_cp; a.out_f32 = io.out_f32;
+  LP_CHECK(io.in.C == Cin, LP_ERR_STATE, "conv input view has %d channels, layer expects %d", io.in.C, Cin);
+  LP_CHECK(io.x1.base || io.out.C >= Cout || io.out_f32, LP_ERR_STATE, "conv output view too narrow (%d < %d)", io.out.C, Cout);
+  LP_CHECK((io.in.pitch % 8) == 0 && (io.out.pitch % 4) == 0, LP_ERR_STATE, "unaligned channel pitch");
+  const bool f16 = prec == LP_FP16;
+
+  if (impl == IMPL_NAIVE) {
+    const long total = (long)a.M * Cout;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (f16)
+      hipLaunchKernelGGL(conv_naive_kernel<half_t>, grid, dim3(256), 0, st, a, k, stride);
+    else
+      hipLaunchKernelGGL(conv_naive_kernel<float>, grid, dim3(256), 0, st, a, k, stride);
+    LP_HIP(hipGetLastError());
+    return;
+  }
+
+  if (k == 3) {
+    LP_CHECK(!io.m_dyn && !io.x1.base && !io.out_f32, LP_ERR_STATE, "conv3x3: unsupported epilogue");
+    const int TH = 4 * bwh, TW = 20 * bww;
+    a.tiles_x = ceil_div(a.Wout, TW);
+    a.tiles_y = ceil_div(a.Hout, TH);
+    dim3 grid(a.tiles_x * a.tiles_y, io.N, nsplits);
+    const int threads = 64 * bwh * bww;
+#define LP_L3(TT)                                                                  \
+  switch (NT) {                                                                    \
+    case 1: launch3x3<TT, 1>(a, stride, grid, threads, lds_bytes, st); break;      \
+    case 2: launch3x3<TT, 2>(a, stride, grid, threads, lds_bytes, st); break;      \
+    case 3: launch3x3<TT, 3>(a, stride, grid, threads, lds_bytes, st); break;      \
+    default: launch3x3<TT, 4>(a, stride, grid, threads, lds_bytes, st); break;     \
+  }
+    if (f16) { LP_L3(half_t) } else { LP_L3(float) }
+#undef LP_L3
+  } else {
+    LP_CHECK(stride == 1, LP_ERR_GRAPH, "strided 1x1 conv unsupported");
+    const long ntiles = ((long)a.M + 255) / 256;
+    dim3 grid((unsigned)(ntiles < 4096 ? (ntiles > 0 ? ntiles : 1) : 4096), nsplits);
+    if (io.m_dyn) grid.x = 1024 / nsplits > 64 ? 1024 / nsplits : 64;
+    const bool shuffle = io.x1.base != nullptr;
+#define LP_L1(TT)                                                           \
+  switch (NT) {                                                             \
+    case 1: launch1x1<TT, 1>(a, shuffle, grid, lds_bytes, st); break;       \
+    case 2: launch1x1<TT, 2>(a, shuffle, grid, lds_bytes, st); break;       \
+    case 3: launch1x1<TT, 3>(a, shuffle, grid, lds_bytes, st); break;       \
+    default: launch1x1<TT, 4>(a, shuffle, grid, lds_bytes, st); break;      \
+  }
+    if (f16) { LP_L1(half_t) } else { LP_L1(float) }
+#undef LP_L1
+  }
+  LP_HIP(hipGetLastError());
+}
+
+void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<float>& w_bgr, const std::vector<float>& bias) {
+  prec = prec_; CO = cout_phys; act = act_;
+  LP_CHECK(CO == 8 || CO == 16 || CO == 32, LP_ERR_GRAPH, "stem with %d output channels unsupported", CO);
+  d_w.alloc(w_bgr.size() * 4);
+  LP_HIP(hipMemcpy(d_w.p, w_bgr.data(), w_bgr.size() * 4, hipMemcpyHostToDevice));
+  std::vector<float> b(CO, 0.f);
+  for (size_t i = 0; i < bias.size() && i < (size_t)CO; ++i) b[i] = bias[i];
+  d_bias.alloc(CO * 4);
+  LP_HIP(hipMemcpy(d_bias.p, b.data(), CO * 4, hipMemcpyHostToDevice));
+}
+
+void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& out, hipStream_t st) const {
+  const long total = (long)N * out.H * out.W;
+  dim3 grid((unsigned)((total + 255) / 256));
+#define LP_ST(TT, C)                                                                                     \
+  hipLaunchKernelGGL((stem_conv_kernel<TT, C>), grid, dim3(256), 0, st, img, reinterpret_cast<TT*>(out.base), \
+                     d_w.as<float>(), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch, act)
+  if (prec == LP_FP16) {
+    if (CO == 8) LP_ST(half_t, 8); else if (CO == 16) LP_ST(half_t, 16); else LP_ST(half_t, 32);
+  } else {
+    if (CO == 8) LP_ST(float, 8); else if (CO == 16) LP_ST(float, 16); else LP_ST(float, 32);
+  }
+#undef LP_ST
+  LP_HIP(hipGetLastError());
+}
+
+}  // namespace lp

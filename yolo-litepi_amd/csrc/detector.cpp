@@ -1,0 +1,580 @@
+// Detector planner: turns the NCNN graph of a YOLOv8-family detector (reference
+// model.ncnn.param:3-208; YOLO-LitePi v1/v2 and the YOLOv8n baseline share this topology) into
+// a list of fused NHWC kernel launches:
+//   * Convolution+Swish(+BinaryOp add) -> one conv kernel with bias/SiLU/residual epilogue
+//   * Split -> alias, Slice -> channel-slice view, Concat -> producers write straight into
+//     channel slices of one buffer (C2f, SPPF, FPN/PAN concats are never materialised)
+//   * three chained 5x5 max pools -> one SPPF kernel
+//   * the Reshape/Permute/Softmax/DFL/BinaryOp/Sigmoid tail -> one decode kernel
+// Channel counts that are not multiples of 8 (v2: 12-channel C2f halves) are padded per
+// segment; padding channels carry zero weights on both sides and stay zero.
+#include "detector.h"
+
+#include <algorithm>
+#include <functional>
+#include <set>
+
+namespace lp {
+
+// ---- profiler -------------------------------------------------------------------------
+void Profiler::begin(hipStream_t st) {
+  if (!enabled) return;
+  LP_HIP(hipEventCreate(&cur));
+  LP_HIP(hipEventRecord(cur, st));
+}
+void Profiler::end(hipStream_t st, const std::string& name, const std::string& layer, double flops, double bytes, bool per_roi) {
+  if (!enabled) return;
+  Rec r{name, layer, flops, bytes, cur, nullptr, per_roi};
+  LP_HIP(hipEventCreate(&r.e1));
+  LP_HIP(hipEventRecord(r.e1, st));
+  recs.push_back(r);
+  cur = nullptr;
+}
+void Profiler::collect(int roi_count) {
+  results.clear();
+  for (auto& r : recs) {
+    lp_kernel_time k;
+    memset(&k, 0, sizeof(k));
+    snprintf(k.name, sizeof(k.name), "%s", r.name.c_str());
+    snprintf(k.layer, sizeof(k.layer), "%s", r.layer.c_str());
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+    k.ms = ms;
+    k.flops = r.flops * (r.per_roi ? roi_count : 1);
+    k.bytes = r.bytes * (r.per_roi ? roi_count : 1);
+    results.push_back(k);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  recs.clear();
+}
+Profiler::~Profiler() {
+  for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+}
+
+// ---- tensors ---------------------------------------------------------------------------
+int Tensor::phys(int c) const {
+  int lo = 0, po = 0;
+  for (int s : segs) {
+    if (c < lo + s) return po + (c - lo);
+    lo += s;
+    po += round_up(s, 8);
+  }
+  return -1;
+}
+
+Detector::Detector(int prec, int impl, int max_batch, int input_size)
+    : prec_(prec), impl_(impl), maxB_(max_batch), S_(input_size) {}
+
+View Detector::view(int t) const {
+  const Tensor* T = &tensors_[t];
+  int off = 0;
+  if (T->parent >= 0) {
+    const Tensor& P = tensors_[T->parent];
+    for (int k = 0; k < T->parent_seg; ++k) off += round_up(P.segs[k], 8);
+    off += P.off;
+    LP_CHECK(P.buf >= 0, LP_ERR_STATE, "blob %s: parent has no storage", T->name.c_str());
+    const Buffer& b = buffers_[P.buf];
+    View v;
+    v.base = static_cast<char*>(b.mem.p) + (size_t)off * (prec_ == LP_FP16 ? 2 : 4);
+    v.C = T->Cp; v.pitch = b.Cp; v.H = T->H; v.W = T->W;
+    return v;
+  }
+  LP_CHECK(T->buf >= 0, LP_ERR_STATE, "blob %s has no storage", T->name.c_str());
+  const Buffer& b = buffers_[T->buf];
+  View v;
+  v.base = static_cast<char*>(b.mem.p) + (size_t)T->off * (prec_ == LP_FP16 ? 2 : 4);
+  v.C = T->Cp; v.pitch = b.Cp; v.H = T->H; v.W = T->W;
+  return v;
+}
+
+void Detector::load(const std::string& param_path, const std::string& bin_path) {
+  NcnnGraph g;
+  g.load(param_path, bin_path);
+  auto& L = g.layers;
+  const int n = (int)L.size();
+  const size_t es = prec_ == LP_FP16 ? 2 : 4;
+
+  tensors_.clear(); blob2tensor_.clear(); buffers_.clear(); convs_.clear(); ops_.clear(); levels_.clear();
+  loaded_ = false;
+
+  std::map<std::string, int> producer;
+  std::map<std::string, std::vector<int>> consumers;
+  for (int i = 0; i < n; ++i) {
+    for (auto& o : L[i].outputs) producer[o] = i;
+    for (auto& in : L[i].inputs) consumers[in].push_back(i);
+  }
+  auto prod_type = [&](const std::string& b) -> std::string {
+    auto it = producer.find(b);
+    return it == producer.end() ? std::string() : L[it->second].type;
+  };
+
+  // ---- find the Detect tail ---------------------------------------------------------------
+  std::vector<int> head_cats;
+  int first_tail = n;
+  for (int i = 0; i < n; ++i) {
+    if (L[i].type != "Reshape" || L[i].inputs.empty()) continue;
+    auto it = producer.find(L[i].inputs[0]);
+    if (it == producer.end()) continue;
+    const NcnnLayer& c = L[it->second];
+    if (c.type == "Concat" && c.inputs.size() == 2 && prod_type(c.inputs[0]) == "Convolution" &&
+        prod_type(c.inputs[1]) == "Convolution") {
+      head_cats.push_back(it->second);
+      first_tail = std::min(first_tail, i);
+    }
+  }
+  LP_CHECK(!head_cats.empty() && head_cats.size() <= 4, LP_ERR_GRAPH, "no YOLOv8-style Detect head found in %s", param_path.c_str());
+  std::set<int> head_cat_set(head_cats.begin(), head_cats.end());
+  auto is_tail = [&](int i) { return i >= first_tail || head_cat_set.count(i) || L[i].type == "MemoryData"; };
+
+  // ---- aliases (Split) and Swish fusion -----------------------------------------------------
+  std::map<std::string, std::string> alias;
+  std::function<std::string(const std::string&)> canon = [&](const std::string& b) {
+    std::string c = b;
+    while (alias.count(c)) c = alias[c];
+    return c;
+  };
+  std::vector<int> fused_act(n, ACT_NONE);
+  std::vector<std::string> conv_out(n);
+  std::vector<char> skip(n, 0);
+  for (int i = 0; i < n; ++i) {
+    if (is_tail(i)) continue;
+    if (L[i].type == "Split")
+      for (auto& o : L[i].outputs) alias[o] = L[i].inputs[0];
+    if (L[i].type == "Convolution") {
+      const std::string& x = L[i].outputs[0];
+      conv_out[i] = x;
+      auto& cs = consumers[x];
+      if (cs.size() == 1 && L[cs[0]].type == "Swish" && !is_tail(cs[0])) {
+        fused_act[i] = ACT_SILU;
+        conv_out[i] = L[cs[0]].outputs[0];
+        skip[cs[0]] = 1;
+      }
+    }
+  }
+  std::map<std::string, std::vector<int>> canon_consumers;
+  for (int i = 0; i < n; ++i) {
+    if (L[i].type == "Split" || skip[i]) continue;
+    for (auto& in : L[i].inputs) canon_consumers[canon(in)].push_back(i);
+  }
+  // Slice sizes keyed by the canonical input blob (needed before the parent's layout is fixed)
+  std::map<std::string, std::vector<int>> slice_sizes;
+  for (int i = 0; i < n; ++i) {
+    if (is_tail(i) || L[i].type != "Slice") continue;
+    LP_CHECK(L[i].ipar(1, 0) == 0, LP_ERR_GRAPH, "Slice %s: only channel slices supported", L[i].name.c_str());
+    auto it = L[i].arrays.find(0);
+    LP_CHECK(it != L[i].arrays.end() && it->second.size() == L[i].outputs.size(), LP_ERR_GRAPH, "Slice %s: bad size list", L[i].name.c_str());
+    std::vector<int> sz;
+    for (double v : it->second) sz.push_back((int)v);
+    slice_sizes[canon(L[i].inputs[0])] = sz;
+  }
+
+  // ---- pass A: shapes and tensors ---------------------------------------------------------
+  auto new_tensor = [&](const std::string& name, int C, int H, int W) {
+    Tensor t;
+    t.name = name; t.C = C; t.H = H; t.W = W;
+    auto it = slice_sizes.find(name);
+    if (it != slice_sizes.end()) {
+      std::vector<int> sz = it->second;
+      int known = 0, autos = 0;
+      for (int s : sz) { if (s == -233) ++autos; else known += s; }
+      for (int& s : sz) if (s == -233) s = (C - known) / autos;
+      int sum = 0;
+      for (int s : sz) sum += s;
+      LP_CHECK(sum == C, LP_ERR_GRAPH, "Slice sizes of blob %s do not add up to %d", name.c_str(), C);
+      t.segs = sz;
+    } else {
+      t.segs = {C};
+    }
+    tensors_.push_back(t);
+    blob2tensor_[name] = (int)tensors_.size() - 1;
+    return (int)tensors_.size() - 1;
+  };
+  auto get = [&](const std::string& blob) {
+    auto it = blob2tensor_.find(canon(blob));
+    LP_CHECK(it != blob2tensor_.end(), LP_ERR_GRAPH, "blob %s used before it is produced", blob.c_str());
+    return it->second;
+  };
+  struct ConvInfo { int tin = -1, tout = -1; };
+  std::vector<ConvInfo> cinfo(n);
+  int input_tensor = -1;
+  for (int i = 0; i < n; ++i) {
+    if (is_tail(i) && L[i].type != "Convolution") continue;
+    if (i >= first_tail) continue;  // DFL conv etc.
+    const NcnnLayer& l = L[i];
+    if (skip[i]) continue;
+    if (l.type == "Input") {
+      input_tensor = new_tensor(l.outputs[0], 3, S_, S_);
+    } else if (l.type == "Convolution") {
+      const int tin = get(l.inputs[0]);
+      const int k = l.ipar(1, 1), s = l.ipar(3, 1), pad = l.ipar(4, 0), dil = l.ipar(2, 1);
+      LP_CHECK(l.ipar(11, k) == k && l.ipar(13, s) == s && l.ipar(14, pad) == pad && dil == 1 && pad == k / 2, LP_ERR_GRAPH,
+               "Convolution %s: only square k with pad k/2, dilation 1 supported", l.name.c_str());
+      LP_CHECK(l.in_ch == tensors_[tin].C, LP_ERR_GRAPH, "Convolution %s: weight expects %d input channels, blob has %d",
+               l.name.c_str(), l.in_ch, tensors_[tin].C);
+      const int Ho = (tensors_[tin].H + 2 * pad - k) / s + 1, Wo = (tensors_[tin].W + 2 * pad - k) / s + 1;
+      cinfo[i].tin = tin;
+      cinfo[i].tout = new_tensor(conv_out[i], l.ipar(0), Ho, Wo);
+    } else if (l.type == "Swish") {
+      throw Error(LP_ERR_GRAPH, fmt("stand-alone Swish %s unsupported", l.name.c_str()));
+    } else if (l.type == "Split") {
+      const int t = get(l.inputs[0]);
+      for (auto& o : l.outputs) blob2tensor_[o] = t;
+    } else if (l.type == "Slice") {
+      const int tin = get(l.inputs[0]);
+      const std::vector<int> sz = tensors_[tin].segs;
+      LP_CHECK(sz.size() == l.outputs.size(), LP_ERR_GRAPH, "Slice %s: layout mismatch", l.name.c_str());
+      for (size_t j = 0; j < l.outputs.size(); ++j) {
+        const int t = new_tensor(l.outputs[j], sz[j], tensors_[tin].H, tensors_[tin].W);
+        tensors_[t].parent = tin;
+        tensors_[t].parent_seg = (int)j;
+      }
+    } else if (l.type == "Concat") {
+      LP_CHECK(l.ipar(0, 0) == 0, LP_ERR_GRAPH, "Concat %s: only channel concat supported", l.name.c_str());
+      int C = 0;
+      std::vector<int> segs;
+      const int t0 = get(l.inputs[0]);
+      for (auto& in : l.inputs) {
+        const Tensor& t = tensors_[get(in)];
+        LP_CHECK(t.H == tensors_[t0].H && t.W == tensors_[t0].W, LP_ERR_GRAPH, "Concat %s: spatial mismatch", l.name.c_str());
+        C += t.C;
+        segs.insert(segs.end(), t.segs.begin(), t.segs.end());
+      }
+      const int t = new_tensor(l.outputs[0], C, tensors_[t0].H, tensors_[t0].W);
+      if (tensors_[t].segs.size() == 1) tensors_[t].segs = segs;
+    } else if (l.type == "BinaryOp") {
+      LP_CHECK(l.ipar(0, 0) == 0 && l.inputs.size() == 2 && l.ipar(1, 0) == 0, LP_ERR_GRAPH, "BinaryOp %s: only tensor add supported", l.name.c_str());
+      const Tensor a = tensors_[get(l.inputs[0])], b = tensors_[get(l.inputs[1])];
+      LP_CHECK(a.C == b.C && a.H == b.H && a.W == b.W, LP_ERR_GRAPH, "BinaryOp %s: shape mismatch", l.name.c_str());
+      new_tensor(l.outputs[0], a.C, a.H, a.W);
+    } else if (l.type == "Pooling") {
+      LP_CHECK(l.ipar(0, 0) == 0 && l.ipar(1) == 5 && l.ipar(2, 1) == 1 && l.ipar(3, 0) == 2, LP_ERR_GRAPH,
+               "Pooling %s: only the SPPF 5x5/s1/p2 max pool is supported", l.name.c_str());
+      const Tensor a = tensors_[get(l.inputs[0])];
+      new_tensor(l.outputs[0], a.C, a.H, a.W);
+    } else if (l.type == "Interp") {
+      LP_CHECK(l.ipar(0, 0) == 1 && l.fpar(1, 1.0) == 2.0 && l.fpar(2, 1.0) == 2.0, LP_ERR_GRAPH, "Interp %s: only nearest x2 supported", l.name.c_str());
+      const Tensor a = tensors_[get(l.inputs[0])];
+      new_tensor(l.outputs[0], a.C, 2 * a.H, 2 * a.W);
+    } else {
+      throw Error(LP_ERR_GRAPH, fmt("unsupported NCNN layer type %s (%s)", l.type.c_str(), l.name.c_str()));
+    }
+  }
+  LP_CHECK(input_tensor >= 0, LP_ERR_GRAPH, "graph has no Input layer");
+  for (auto& t : tensors_) {
+    t.Cp = 0;
+    for (int s : t.segs) t.Cp += round_up(s, 8);
+  }
+
+  auto alloc_buffer = [&](int Cp, int H, int W) {
+    buffers_.emplace_back();
+    Buffer& b = buffers_.back();
+    b.Cp = Cp; b.H = H; b.W = W;
+    b.mem.alloc((size_t)maxB_ * H * W * Cp * es);
+    return (int)buffers_.size() - 1;
+  };
+
+  // ---- pass B: place concat inputs inside the concat buffer -----------------------------------
+  struct CopyJob { int layer, src, dst_buf, dst_off; };
+  std::vector<CopyJob> copies;
+  for (int i = 0; i < n; ++i) {
+    if (is_tail(i) || L[i].type != "Concat") continue;
+    const int tout = get(L[i].outputs[0]);
+    Tensor& O = tensors_[tout];
+    if (O.buf < 0) { O.buf = alloc_buffer(O.Cp, O.H, O.W); O.off = 0; }
+    int o = O.off;
+    size_t j = 0;
+    while (j < L[i].inputs.size()) {
+      const int t = get(L[i].inputs[j]);
+      Tensor& T = tensors_[t];
+      if (T.parent >= 0) {
+        Tensor& P = tensors_[T.parent];
+        const size_t m = P.segs.size();
+        bool whole = T.parent_seg == 0 && j + m <= L[i].inputs.size() && P.buf < 0;
+        for (size_t q = 0; whole && q < m; ++q) {
+          const Tensor& Q = tensors_[get(L[i].inputs[j + q])];
+          whole = Q.parent == T.parent && Q.parent_seg == (int)q;
+        }
+        if (whole) {
+          P.buf = O.buf; P.off = o;
+          o += P.Cp;
+          j += m;
+          continue;
+        }
+        copies.push_back({i, t, O.buf, o});
+      } else if (T.buf < 0) {
+        T.buf = O.buf; T.off = o;
+      } else {
+        copies.push_back({i, t, O.buf, o});
+      }
+      o += T.Cp;
+      ++j;
+    }
+    LP_CHECK(o - O.off == O.Cp, LP_ERR_GRAPH, "Concat %s: layout bookkeeping error", L[i].name.c_str());
+  }
+  auto ensure_buffer = [&](int t) {
+    Tensor& T = tensors_[t];
+    LP_CHECK(T.parent < 0, LP_ERR_GRAPH, "blob %s is a slice and cannot be produced directly", T.name.c_str());
+    if (T.buf < 0) { T.buf = alloc_buffer(T.Cp, T.H, T.W); T.off = 0; }
+    T.materialised = true;
+  };
+
+  // ---- pass D: emit ops ------------------------------------------------------------------------
+  std::vector<char> done(n, 0);
+  macs_ = 0;
+  const double esd = (double)es;
+  for (int i = 0; i < first_tail; ++i) {
+    if ((is_tail(i) && L[i].type != "Convolution") || skip[i] || done[i]) continue;
+    const NcnnLayer& l = L[i];
+    if (l.type == "Convolution") {
+      const int tin = cinfo[i].tin;
+      int tout = cinfo[i].tout, res = -1;
+      const int k = l.ipar(1, 1), s = l.ipar(3, 1);
+      const int Cout = l.ipar(0), Cin = l.in_ch;
+      // residual fusion: the activation output feeds exactly one BinaryOp add
+      auto& cs = canon_consumers[tensors_[tout].name];
+      if (cs.size() == 1 && L[cs[0]].type == "BinaryOp" && !is_tail(cs[0])) {
+        const NcnnLayer& add = L[cs[0]];
+        const int ta = get(add.inputs[0]), tb = get(add.inputs[1]);
+        const int other = ta == tout ? tb : ta;
+        if (other != tout && tensors_[other].Cp == tensors_[tout].Cp) {
+          res = other;
+          tout = get(add.outputs[0]);
+          done[cs[0]] = 1;
+        }
+      }
+      ensure_buffer(tout);
+      const Tensor& TI = tensors_[tin];
+      const Tensor& TO = tensors_[tout];
+      const double macs = (double)k * k * Cin * Cout * TO.H * TO.W;
+      macs_ += macs;
+      DetOp op;
+      op.layer = l.name;
+      op.flops = 2.0 * macs;
+      op.bytes = ((double)TI.C * TI.H * TI.W + (double)TO.C * TO.H * TO.W * (res >= 0 ? 2 : 1)) * esd + (double)l.weight.size() * esd;
+      op.in = tin; op.out = tout; op.res = res;
+      if (tin == input_tensor) {
+        LP_CHECK(k == 3 && s == 2 && Cin == 3, LP_ERR_GRAPH, "first convolution must be 3x3 stride 2 on 3 channels");
+        // weights in BGR order, [27][CO]
+        const int CO = TO.Cp;
+        std::vector<float> w((size_t)27 * CO, 0.f), b(CO, 0.f);
+        for (int co = 0; co < Cout; ++co) {
+          const int pc = TO.phys(co);
+          for (int c = 0; c < 3; ++c)
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx)
+                w[(size_t)((ky * 3 + kx) * 3 + (2 - c)) * CO + pc] = l.weight[(((size_t)co * 3 + c) * 3 + ky) * 3 + kx];
+          if (!l.bias.empty()) b[pc] = l.bias[co];
+        }
+        stem_.build(prec_, CO, fused_act[i], w, b);
+        op.kind = DetOp::STEM;
+        op.bytes = (double)3 * TI.H * TI.W + (double)TO.C * TO.H * TO.W * esd;
+      } else {
+        const int taps = k * k;
+        std::vector<float> w((size_t)TO.Cp * taps * TI.Cp, 0.f), b(TO.Cp, 0.f);
+        for (int co = 0; co < Cout; ++co) {
+          const int pc = TO.phys(co);
+          for (int ci = 0; ci < Cin; ++ci) {
+            const int pi = TI.phys(ci);
+            for (int t = 0; t < taps; ++t)
+              w[((size_t)pc * taps + t) * TI.Cp + pi] = l.weight[((size_t)co * Cin + ci) * taps + t];
+          }
+          if (!l.bias.empty()) b[pc] = l.bias[co];
+        }
+        convs_.emplace_back(new ConvLayer());
+        convs_.back()->name = l.name;
+        convs_.back()->build(prec_, impl_, k, s, TI.Cp, TO.Cp, fused_act[i], w, b, TO.H, TO.W);
+        op.kind = DetOp::CONV;
+        op.conv = (int)convs_.size() - 1;
+      }
+      ops_.push_back(op);
+    } else if (l.type == "BinaryOp") {
+      DetOp op;
+      op.kind = DetOp::ADD; op.layer = l.name;
+      op.in = get(l.inputs[0]); op.in2 = get(l.inputs[1]); op.out = get(l.outputs[0]);
+      ensure_buffer(op.out);
+      const Tensor& T = tensors_[op.out];
+      op.bytes = 3.0 * T.C * T.H * T.W * esd;
+      ops_.push_back(op);
+    } else if (l.type == "Pooling") {
+      // SPPF: this pool and the two that consume it in a chain
+      int chain[3] = {i, -1, -1};
+      for (int q = 1; q < 3; ++q) {
+        auto& cs = canon_consumers[canon(L[chain[q - 1]].outputs[0])];
+        for (int c : cs)
+          if (L[c].type == "Pooling") chain[q] = c;
+        LP_CHECK(chain[q] >= 0, LP_ERR_GRAPH, "Pooling %s is not part of an SPPF chain of three", l.name.c_str());
+      }
+      DetOp op;
+      op.kind = DetOp::SPPF; op.layer = l.name;
+      op.in = get(l.inputs[0]);
+      op.out = get(L[chain[0]].outputs[0]); op.out2 = get(L[chain[1]].outputs[0]); op.out3 = get(L[chain[2]].outputs[0]);
+      ensure_buffer(op.out); ensure_buffer(op.out2); ensure_buffer(op.out3);
+      done[chain[1]] = done[chain[2]] = 1;
+      const Tensor& T = tensors_[op.in];
+      op.bytes = 4.0 * T.C * T.H * T.W * esd;
+      ops_.push_back(op);
+    } else if (l.type == "Interp") {
+      DetOp op;
+      op.kind = DetOp::UPSAMPLE; op.layer = l.name;
+      op.in = get(l.inputs[0]); op.out = get(l.outputs[0]);
+      ensure_buffer(op.out);
+      const Tensor& T = tensors_[op.out];
+      op.bytes = 1.25 * T.C * T.H * T.W * esd;
+      ops_.push_back(op);
+    } else if (l.type == "Concat") {
+      for (auto& cj : copies) {
+        if (cj.layer != i) continue;
+        // destination view = slice of the concat buffer
+        Tensor d = tensors_[cj.src];
+        d.name += "@cat"; d.parent = -1; d.buf = cj.dst_buf; d.off = cj.dst_off;
+        tensors_.push_back(d);
+        DetOp op;
+        op.kind = DetOp::COPY; op.layer = l.name; op.in = cj.src; op.out = (int)tensors_.size() - 1;
+        op.bytes = 2.0 * d.C * d.H * d.W * esd;
+        ops_.push_back(op);
+      }
+    }
+  }
+
+  // ---- Detect tail ---------------------------------------------------------------------------
+  reg_max_ = 0;
+  std::vector<float> dfl;
+  const NcnnLayer* anchors = nullptr;
+  const NcnnLayer* strides = nullptr;
+  for (int i = 0; i < n; ++i) {
+    if (L[i].type == "Convolution" && i >= first_tail) {
+      LP_CHECK(L[i].bias.empty() && L[i].ipar(0) == 1, LP_ERR_GRAPH, "unexpected convolution %s in the Detect tail", L[i].name.c_str());
+      dfl = L[i].weight;
+      reg_max_ = (int)dfl.size();
+    }
+    if (L[i].type == "MemoryData") {
+      if (L[i].ipar(1, 0) == 2 && !anchors) anchors = &L[i];
+      if (L[i].ipar(1, 0) == 0 && L[i].ipar(2, 0) == 0 && !strides) strides = &L[i];
+    }
+  }
+  LP_CHECK(reg_max_ > 0 && reg_max_ <= 32, LP_ERR_GRAPH, "no DFL convolution found in the Detect tail");
+  LP_CHECK(anchors && strides, LP_ERR_GRAPH, "anchor / stride constants missing from the Detect tail");
+  A_ = 0;
+  nc_ = -1;
+  for (int hc : head_cats) {
+    Level lv;
+    lv.box = get(L[hc].inputs[0]);
+    lv.cls = get(L[hc].inputs[1]);
+    const Tensor& B = tensors_[lv.box];
+    const Tensor& C = tensors_[lv.cls];
+    LP_CHECK(B.C == 4 * reg_max_ && B.segs.size() == 1 && C.segs.size() == 1 && B.H == C.H && B.W == C.W, LP_ERR_GRAPH,
+             "Detect head %s: box branch must have 4*reg_max channels", L[hc].name.c_str());
+    LP_CHECK(nc_ < 0 || nc_ == C.C, LP_ERR_GRAPH, "Detect head: class count differs between levels");
+    nc_ = C.C;
+    lv.H = B.H; lv.W = B.W; lv.off = A_;
+    A_ += B.H * B.W;
+    levels_.push_back(lv);
+  }
+  LP_CHECK((int)anchors->data.size() == 2 * A_ && (int)strides->data.size() == A_, LP_ERR_GRAPH,
+           "anchor tables (%zu, %zu) do not match %d anchors", anchors->data.size(), strides->data.size(), A_);
+  for (auto& lv : levels_) {
+    const float st = strides->data[lv.off];
+    LP_CHECK(st * lv.H == (float)S_, LP_ERR_GRAPH, "stride table does not match level %dx%d", lv.H, lv.W);
+  }
+  d_anchors_.alloc(anchors->data.size() * 4);
+  LP_HIP(hipMemcpy(d_anchors_.p, anchors->data.data(), anchors->data.size() * 4, hipMemcpyHostToDevice));
+  d_strides_.alloc(strides->data.size() * 4);
+  LP_HIP(hipMemcpy(d_strides_.p, strides->data.data(), strides->data.size() * 4, hipMemcpyHostToDevice));
+  d_dfl_.alloc(dfl.size() * 4);
+  LP_HIP(hipMemcpy(d_dfl_.p, dfl.data(), dfl.size() * 4, hipMemcpyHostToDevice));
+  loaded_ = true;
+}
+
+void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float conf, float* out0, Cand* cand,
+                       int* cand_count, hipStream_t st, Profiler* prof) {
+  LP_CHECK(loaded_, LP_ERR_STATE, "detector not loaded");
+  LP_CHECK(B >= 1 && B <= maxB_, LP_ERR_ARG, "batch %d outside 1..%d", B, maxB_);
+  const char* sfx = prec_ == LP_FP16 ? "_f16" : "_f32";
+  for (const DetOp& op : ops_) {
+    if (prof) prof->begin(st);
+    std::string kname;
+    switch (op.kind) {
+      case DetOp::STEM:
+        stem_.launch(imgs, B, S_, S_, view(op.out), st);
+        kname = std::string("stem_conv") + sfx;
+        break;
+      case DetOp::CONV: {
+        const ConvLayer& c = *convs_[op.conv];
+        ConvIO io;
+        io.in = view(op.in); io.out = view(op.out); io.N = B;
+        if (op.res >= 0) io.res = view(op.res);
+        c.launch(io, st);
+        kname = std::string(c.impl == IMPL_NAIVE ? "conv_naive" : (c.k == 3 ? "conv3x3_mfma" : "conv1x1_mfma")) + sfx;
+        break;
+      }
+      case DetOp::UPSAMPLE:
+        launch_upsample2x(prec_, view(op.in), view(op.out), B, st);
+        kname = std::string("upsample2x") + sfx;
+        break;
+      case DetOp::SPPF:
+        launch_sppf_pool(prec_, view(op.in), view(op.out), view(op.out2), view(op.out3), B, st);
+        kname = std::string("sppf_pool") + sfx;
+        break;
+      case DetOp::ADD:
+        launch_add(prec_, view(op.in), view(op.in2), view(op.out), B, st);
+        kname = std::string("add") + sfx;
+        break;
+      case DetOp::COPY:
+        launch_copy(prec_, view(op.in), view(op.out), B, st);
+        kname = std::string("copy") + sfx;
+        break;
+    }
+    if (prof) prof->end(st, kname, op.layer, op.flops * B, op.bytes * B);
+  }
+  DecodeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nlevels = (int)levels_.size();
+  for (int i = 0; i < a.nlevels; ++i) {
+    const View b = view(levels_[i].box), c = view(levels_[i].cls);
+    a.lv[i].box = b.base; a.lv[i].cls = c.base; a.lv[i].box_pitch = b.pitch; a.lv[i].cls_pitch = c.pitch;
+    a.lv[i].H = levels_[i].H; a.lv[i].W = levels_[i].W; a.lv[i].anchor_off = levels_[i].off;
+  }
+  a.A = A_; a.nc = nc_; a.reg_max = reg_max_;
+  a.anchors = d_anchors_.as<float>(); a.strides = d_strides_.as<float>(); a.dfl_w = d_dfl_.as<float>();
+  a.out0 = out0; a.geom = geom; a.cand = cand; a.cand_count = cand_count; a.conf = conf;
+  if (prof) prof->begin(st);
+  launch_decode(prec_, a, B, st);
+  if (prof)
+    prof->end(st, std::string("decode") + sfx, "detect_decode", 0.0,
+              (double)B * A_ * ((4.0 * reg_max_ + nc_) * (prec_ == LP_FP16 ? 2 : 4) + (out0 ? (4.0 + nc_) * 4 : 0.0)));
+}
+
+void Detector::fetch_blob(const std::string& name, int B, std::vector<float>& out, int& C, int& H, int& W) const {
+  auto it = blob2tensor_.find(name);
+  LP_CHECK(it != blob2tensor_.end(), LP_ERR_ARG, "unknown blob %s", name.c_str());
+  const Tensor& T = tensors_[it->second];
+  const View v = view(it->second);
+  C = T.C; H = T.H; W = T.W;
+  const size_t es = prec_ == LP_FP16 ? 2 : 4;
+  const size_t npix = (size_t)B * H * W;
+  // copy the pitch-wide rows of the underlying buffer and pick the view's channels out of them
+  const Tensor& ST = T.parent >= 0 ? tensors_[T.parent] : T;
+  const Buffer& buf = buffers_[ST.buf];
+  const size_t voff = (size_t)(static_cast<const char*>(v.base) - static_cast<const char*>(buf.mem.p)) / es;
+  std::vector<uint8_t> raw(npix * v.pitch * es);
+  LP_HIP(hipMemcpy(raw.data(), buf.mem.p, raw.size(), hipMemcpyDeviceToHost));
+  out.assign((size_t)B * C * H * W, 0.f);
+  for (size_t p = 0; p < npix; ++p) {
+    const size_t b = p / ((size_t)H * W), yx = p % ((size_t)H * W);
+    for (int c = 0; c < C; ++c) {
+      const int pc = T.phys(c);
+      float f;
+      if (prec_ == LP_FP16) {
+        uint16_t h;
+        memcpy(&h, &raw[(p * v.pitch + voff + pc) * 2], 2);
+        f = f16_to_f32(h);
+      } else {
+        memcpy(&f, &raw[(p * v.pitch + voff + pc) * 4], 4);
+      }
+      out[(b * C + c) * H * W + yx] = f;
+    }
+  }
+}
+
+}  // namespace lp

@@ -1,0 +1,217 @@
+// Byte-moving detector kernels: letterbox, nearest upsample, SPPF pooling, add/copy.
+// All HBM-bound: 16-byte vector accesses over NHWC channel groups, one thread per
+// (pixel, 8-channel fp16 / 4-channel fp32 group).
+#include "common.h"
+#include "kernels.h"
+
+namespace lp {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct VecT;
+template <> struct VecT<half_t> { typedef half8 type; static constexpr int G = 8; };
+template <> struct VecT<float> { typedef floatx4 type; static constexpr int G = 4; };
+
+// ------------------------------------------------------------------------------------
+// letterbox (reference e2e.py:66-86).  cv2.resize(INTER_LINEAR) on uint8 is restated from
+// OpenCV's published fixed-point algorithm: half-pixel centres, 11-bit coefficients
+// (cvRound(f*2048)), int horizontal pass, vertical pass
+//   ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+// cv2 is absent from the build container: only the identity and pad-only cases are pinned.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void lin_coeff(int d, int dst, int src, int& s0, int& a0, int& a1) {
+  const double inv_scale = (double)dst / (double)src;
+  const double scale = 1.0 / inv_scale;
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.f; s = 0; }
+  if (s >= src - 1) { f = 0.f; s = src - 1; }
+  s0 = s;
+  a1 = __float2int_rn(f * 2048.f);
+  a0 = __float2int_rn((1.f - f) * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, const ImgGeom* __restrict__ geom,
+                                                        uint8_t* __restrict__ dst, int S) {
+  const int n = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= S * S) return;
+  const int oy = idx / S, ox = idx - oy * S;
+  const ImgGeom gm = geom[n];
+  uint8_t* o = dst + ((long)n * S * S + idx) * 3;
+  const int dy = oy - gm.top, dx = ox - gm.left;
+  if (dy < 0 || dy >= gm.new_h || dx < 0 || dx >= gm.new_w) {
+    o[0] = 114; o[1] = 114; o[2] = 114;
+    return;
+  }
+  const uint8_t* im = src + gm.src_off;
+  if (gm.new_w == gm.w && gm.new_h == gm.h) {
+    const uint8_t* p = im + ((long)dy * gm.w + dx) * 3;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    return;
+  }
+  int sx, ax0, ax1, sy, ay0, ay1;
+  lin_coeff(dx, gm.new_w, gm.w, sx, ax0, ax1);
+  lin_coeff(dy, gm.new_h, gm.h, sy, ay0, ay1);
+  const int sx1 = sx + 1 < gm.w ? sx + 1 : gm.w - 1;
+  const int sy1 = sy + 1 < gm.h ? sy + 1 : gm.h - 1;
+  const uint8_t* r0 = im + (long)sy * gm.w * 3;
+  const uint8_t* r1 = im + (long)sy1 * gm.w * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int h0 = r0[sx * 3 + c] * ax0 + r0[sx1 * 3 + c] * ax1;
+    const int h1 = r1[sx * 3 + c] * ax0 + r1[sx1 * 3 + c] * ax1;
+    int v = (((ay0 * (h0 >> 4)) >> 16) + ((ay1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    o[c] = (uint8_t)v;
+  }
+}
+
+void launch_letterbox(const uint8_t* src, const ImgGeom* geom, uint8_t* dst, int B, int S, hipStream_t st) {
+  dim3 grid(ceil_div(S * S, 256), B);
+  hipLaunchKernelGGL(letterbox_kernel, grid, dim3(256), 0, st, src, geom, dst, S);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W,
+                                                         int CG, int in_pitch, int out_pitch) {
+  constexpr int G = VecT<T>::G;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)N * (2 * H) * (2 * W) * CG;
+  if (idx >= total) return;
+  const int cg = (int)(idx % CG);
+  const long pix = idx / CG;
+  const int ox = (int)(pix % (2 * W));
+  const int oy = (int)((pix / (2 * W)) % (2 * H));
+  const int n = (int)(pix / ((long)4 * W * H));
+  const u32x4 v = *reinterpret_cast<const u32x4*>(in + ((long)(n * H + (oy >> 1)) * W + (ox >> 1)) * in_pitch + cg * G);
+  *reinterpret_cast<u32x4*>(out + pix * out_pitch + cg * G) = v;
+}
+
+void launch_upsample2x(int prec, const View& in, const View& out, int N, hipStream_t st) {
+  LP_CHECK(out.H == 2 * in.H && out.W == 2 * in.W && out.C >= in.C, LP_ERR_STATE, "upsample2x: shape mismatch");
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const int CG = in.C / G;
+  const long total = (long)N * out.H * out.W * CG;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(upsample2x_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, N, in.H,
+                       in.W, CG, in.pitch, out.pitch);
+  else
+    hipLaunchKernelGGL(upsample2x_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, N, in.H,
+                       in.W, CG, in.pitch, out.pitch);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+// SPPF: y1 = pool5(x), y2 = pool5(y1), y3 = pool5(y2) with -inf padding == max over the
+// clipped 5x5 / 9x9 / 13x13 windows of x.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ in, T* __restrict__ o1, T* __restrict__ o2,
+                                                        T* __restrict__ o3, int N, int H, int W, int CG, int in_pitch,
+                                                        int p1, int p2, int p3) {
+  typedef typename VecT<T>::type vec;
+  constexpr int G = VecT<T>::G;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)N * H * W * CG;
+  if (idx >= total) return;
+  const int cg = (int)(idx % CG);
+  const long pix = idx / CG;
+  const int x = (int)(pix % W);
+  const int y = (int)((pix / W) % H);
+  const int n = (int)(pix / ((long)W * H));
+  vec m5, m9, m13;
+#pragma unroll
+  for (int i = 0; i < G; ++i) { m5[i] = (T)-INFINITY; m9[i] = (T)-INFINITY; m13[i] = (T)-INFINITY; }
+  for (int dy = -6; dy <= 6; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= H) continue;
+    const int ady = dy < 0 ? -dy : dy;
+    for (int dx = -6; dx <= 6; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= W) continue;
+      const int adx = dx < 0 ? -dx : dx;
+      const int r = ady > adx ? ady : adx;
+      const vec v = *reinterpret_cast<const vec*>(in + ((long)(n * H + yy) * W + xx) * in_pitch + cg * G);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        m13[i] = v[i] > m13[i] ? v[i] : m13[i];
+        if (r <= 4) m9[i] = v[i] > m9[i] ? v[i] : m9[i];
+        if (r <= 2) m5[i] = v[i] > m5[i] ? v[i] : m5[i];
+      }
+    }
+  }
+  *reinterpret_cast<vec*>(o1 + pix * p1 + cg * G) = m5;
+  *reinterpret_cast<vec*>(o2 + pix * p2 + cg * G) = m9;
+  *reinterpret_cast<vec*>(o3 + pix * p3 + cg * G) = m13;
+}
+
+void launch_sppf_pool(int prec, const View& in, const View& o1, const View& o2, const View& o3, int N, hipStream_t st) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const int CG = in.C / G;
+  const long total = (long)N * in.H * in.W * CG;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(sppf_pool_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)o1.base,
+                       (half_t*)o2.base, (half_t*)o3.base, N, in.H, in.W, CG, in.pitch, o1.pitch, o2.pitch, o3.pitch);
+  else
+    hipLaunchKernelGGL(sppf_pool_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)o1.base,
+                       (float*)o2.base, (float*)o3.base, N, in.H, in.W, CG, in.pitch, o1.pitch, o2.pitch, o3.pitch);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                      long npix, int CG, int pa, int pb, int po) {
+  typedef typename VecT<T>::type vec;
+  constexpr int G = VecT<T>::G;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npix * CG) return;
+  const int cg = (int)(idx % CG);
+  const long pix = idx / CG;
+  vec v = *reinterpret_cast<const vec*>(a + pix * pa + cg * G);
+  if (ADD) {
+    const vec w = *reinterpret_cast<const vec*>(b + pix * pb + cg * G);
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] = (T)((float)v[i] + (float)w[i]);
+  }
+  *reinterpret_cast<vec*>(out + pix * po + cg * G) = v;
+}
+
+void launch_add(int prec, const View& a, const View& b, const View& out, int N, hipStream_t st) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const int CG = a.C / G;
+  const long npix = (long)N * a.H * a.W;
+  dim3 grid((unsigned)((npix * CG + 255) / 256));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL((eltwise_kernel<half_t, true>), grid, dim3(256), 0, st, (const half_t*)a.base, (const half_t*)b.base,
+                       (half_t*)out.base, npix, CG, a.pitch, b.pitch, out.pitch);
+  else
+    hipLaunchKernelGGL((eltwise_kernel<float, true>), grid, dim3(256), 0, st, (const float*)a.base, (const float*)b.base,
+                       (float*)out.base, npix, CG, a.pitch, b.pitch, out.pitch);
+  LP_HIP(hipGetLastError());
+}
+
+void launch_copy(int prec, const View& in, const View& out, int N, hipStream_t st) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const int CG = in.C / G;
+  const long npix = (long)N * in.H * in.W;
+  dim3 grid((unsigned)((npix * CG + 255) / 256));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL((eltwise_kernel<half_t, false>), grid, dim3(256), 0, st, (const half_t*)in.base, (const half_t*)nullptr,
+                       (half_t*)out.base, npix, CG, in.pitch, 0, out.pitch);
+  else
+    hipLaunchKernelGGL((eltwise_kernel<float, false>), grid, dim3(256), 0, st, (const float*)in.base, (const float*)nullptr,
+                       (float*)out.base, npix, CG, in.pitch, 0, out.pitch);
+  LP_HIP(hipGetLastError());
+}
+
+}  // namespace lp

@@ -1,0 +1,420 @@
+// Detector post-processing and ROI extraction on the GPU.  Replaces the NumPy code of
+// NCNNDetector.postprocess / nms_numpy (reference e2e.py:240-296, 89-119), the ROI loop of
+// HybridPipeline.run (e2e.py:465-473) and the PIL resize of PyTorchClassifier.predict_batch
+// (e2e.py:385-389).  Everything that decides WHICH boxes survive is computed with explicit
+// round-to-nearest fp32 operations in the reference's operation order (no FMA contraction),
+// so that for the same out0 tensor the kept set is identical to the NumPy result.
+#include "common.h"
+#include "kernels.h"
+
+namespace lp {
+
+typedef _Float16 half_t;
+
+// ------------------------------------------------------------------------------------
+// conf filter + xywh->xyxy + un-letterbox + clip for one anchor (e2e.py:255-278)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void emit_candidate(float cx, float cy, float w, float h, float score, int cls, int anchor,
+                                               const ImgGeom& gm, float conf, Cand* cand, int* count) {
+  if (!(score > conf)) return;
+  const float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);  // w / 2 (exact either way)
+  float x1 = __fsub_rn(cx, hw), y1 = __fsub_rn(cy, hh);
+  float x2 = __fadd_rn(cx, hw), y2 = __fadd_rn(cy, hh);
+  x1 = __fdiv_rn(__fsub_rn(x1, gm.pad_w), gm.ratio);
+  x2 = __fdiv_rn(__fsub_rn(x2, gm.pad_w), gm.ratio);
+  y1 = __fdiv_rn(__fsub_rn(y1, gm.pad_h), gm.ratio);
+  y2 = __fdiv_rn(__fsub_rn(y2, gm.pad_h), gm.ratio);
+  const float W = (float)gm.w, H = (float)gm.h;
+  x1 = fminf(fmaxf(x1, 0.f), W); x2 = fminf(fmaxf(x2, 0.f), W);
+  y1 = fminf(fmaxf(y1, 0.f), H); y2 = fminf(fmaxf(y2, 0.f), H);
+  const int slot = atomicAdd(count, 1);
+  Cand c;
+  c.x1 = x1; c.y1 = y1; c.x2 = x2; c.y2 = y2; c.score = score; c.cls = cls; c.anchor = anchor; c.pad = 0;
+  cand[slot] = c;
+}
+
+// ------------------------------------------------------------------------------------
+// Detect head decode (model.ncnn.param:184-208): per anchor, softmax over reg_max bins of
+// each box side, expectation with the DFL weights, dist2bbox around the anchor point,
+// x stride; class sigmoid.  One thread per (image, anchor).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+  const int n = blockIdx.y;
+  const int anchor = blockIdx.x * 256 + threadIdx.x;
+  if (anchor >= a.A) return;
+  int l = 0;
+  for (int i = 1; i < a.nlevels; ++i)
+    if (anchor >= a.lv[i].anchor_off) l = i;
+  const DecodeLevel lv = a.lv[l];
+  const long pix = (long)n * lv.H * lv.W + (anchor - lv.anchor_off);
+  const T* box = reinterpret_cast<const T*>(lv.box) + pix * lv.box_pitch;
+  const T* cls = reinterpret_cast<const T*>(lv.cls) + pix * lv.cls_pitch;
+  float d[4];
+#pragma unroll
+  for (int side = 0; side < 4; ++side) {
+    const T* b = box + side * a.reg_max;
+    float mx = -INFINITY;
+    for (int i = 0; i < a.reg_max; ++i) mx = fmaxf(mx, (float)b[i]);
+    float sum = 0.f, ex = 0.f;
+    for (int i = 0; i < a.reg_max; ++i) {
+      const float e = expf((float)b[i] - mx);
+      sum += e;
+      ex += e * a.dfl_w[i];
+    }
+    d[side] = ex / sum;
+  }
+  const float ax = a.anchors[anchor], ay = a.anchors[a.A + anchor], s = a.strides[anchor];
+  const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+  const float cx = (x1 + x2) * 0.5f * s, cy = (y1 + y2) * 0.5f * s;
+  const float w = (x2 - x1) * s, h = (y2 - y1) * s;
+  float best = -1.f;
+  int best_c = 0;
+  float* o = a.out0 ? a.out0 + (long)n * (4 + a.nc) * a.A + anchor : nullptr;
+  for (int c = 0; c < a.nc; ++c) {
+    const float sc = 1.f / (1.f + expf(-(float)cls[c]));
+    if (o) o[(long)(4 + c) * a.A] = sc;
+    if (sc > best) { best = sc; best_c = c; }
+  }
+  if (o) {
+    o[0] = cx; o[(long)a.A] = cy; o[2L * a.A] = w; o[3L * a.A] = h;
+  }
+  emit_candidate(cx, cy, w, h, best, best_c, anchor, a.geom[n], a.conf, a.cand + (long)n * a.A, a.cand_count + n);
+}
+
+void launch_decode(int prec, const DecodeArgs& a, int N, hipStream_t st) {
+  dim3 grid(ceil_div(a.A, 256), N);
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(decode_kernel<half_t>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(decode_kernel<float>, grid, dim3(256), 0, st, a);
+  LP_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void filter_out0_kernel(const float* __restrict__ out0, int nc, int A,
+                                                          const ImgGeom* __restrict__ geom, Cand* cand, int* cand_count,
+                                                          float conf) {
+  const int n = blockIdx.y;
+  const int anchor = blockIdx.x * 256 + threadIdx.x;
+  if (anchor >= A) return;
+  const float* o = out0 + (long)n * (4 + nc) * A + anchor;
+  float best = -INFINITY;
+  int best_c = 0;
+  for (int c = 0; c < nc; ++c) {
+    const float sc = o[(long)(4 + c) * A];
+    if (sc > best) { best = sc; best_c = c; }
+  }
+  emit_candidate(o[0], o[(long)A], o[2L * A], o[3L * A], best, best_c, anchor, geom[n], conf, cand + (long)n * A,
+                 cand_count + n);
+}
+
+void launch_filter_out0(const float* out0, int nc, int A, const ImgGeom* geom, Cand* cand, int* cand_count, float conf,
+                        int N, hipStream_t st) {
+  dim3 grid(ceil_div(A, 256), N);
+  hipLaunchKernelGGL(filter_out0_kernel, grid, dim3(256), 0, st, out0, nc, A, geom, cand, cand_count, conf);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+// Per-class greedy NMS, one workgroup per image.
+//   1. key = (0xFFFF - class, score bits, anchor): a descending bitonic sort in LDS gives
+//      class ascending, score descending, ties -> higher anchor first (the order a stable
+//      ascending argsort reversed gives; e2e.py:96).
+//   2. sequential sweep over the sorted boxes; each surviving box suppresses, in parallel
+//      over the workgroup, every later box of its class with IoU > thr using the reference's
+//      fp32 expression inter / (area_i + area_j - inter + 1e-6) (e2e.py:106-116).
+//   3. ROI rectangle (int truncation, clip) and area filter (e2e.py:465-473) of the kept
+//      boxes, order-preserving compaction into the lp_det records.
+// ------------------------------------------------------------------------------------
+#define NMS_THREADS 1024
+
+size_t nms_lds_bytes(int A) {
+  int npad = 1;
+  while (npad < A) npad <<= 1;
+  return (size_t)npad * 8 + (size_t)round_up(A, 16) + 16;
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_part[NMS_THREADS];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  int cnt = a.cand_count[n];
+  cnt = cnt > a.A ? a.A : cnt;
+  int npad = 1;
+  while (npad < a.A) npad <<= 1;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+  unsigned char* removed = reinterpret_cast<unsigned char*>(smem + (size_t)npad * 8);
+  const Cand* cand = a.cand + (long)n * a.A;
+  Cand* sorted = a.sorted + (long)n * a.A;
+  int nsort = 1;
+  while (nsort < cnt) nsort <<= 1;
+
+  for (int i = tid; i < nsort; i += NMS_THREADS) {
+    unsigned long long k = 0ull;
+    if (i < cnt) {
+      const Cand c = cand[i];
+      k = ((unsigned long long)(0xFFFFu - (unsigned)c.cls) << 46) |
+          ((unsigned long long)__float_as_uint(c.score) << 14) | (unsigned long long)(c.anchor & 0x3FFF);
+      // low bits carry the slot in cand[] as well: anchors are unique per image, so the
+      // slot is recovered by a second pass below
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= nsort; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < nsort; i += NMS_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = keys[i], y = keys[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // keys are sorted; rebuild the records in sorted order.  The slot of a key inside cand[]
+  // is not stored in it, so each candidate finds its own rank by binary search.
+  for (int i = tid; i < cnt; i += NMS_THREADS) {
+    const Cand c = cand[i];
+    const unsigned long long k = ((unsigned long long)(0xFFFFu - (unsigned)c.cls) << 46) |
+                                 ((unsigned long long)__float_as_uint(c.score) << 14) |
+                                 (unsigned long long)(c.anchor & 0x3FFF);
+    int lo = 0, hi = cnt - 1;
+    while (lo < hi) {  // descending order
+      const int mid = (lo + hi) >> 1;
+      if (keys[mid] > k) lo = mid + 1; else hi = mid;
+    }
+    sorted[lo] = c;
+    removed[i] = 0;
+  }
+  __syncthreads();
+  __threadfence_block();
+
+  // greedy sweep
+  int* keep = reinterpret_cast<int*>(keys);  // keys are dead from here on
+  int nkeep = 0;
+  const float thr = a.iou;
+  for (int i = 0; i < cnt; ++i) {
+    if (removed[i]) continue;  // uniform: written before the last barrier only
+    if (tid == 0) keep[nkeep] = i;
+    ++nkeep;
+    const Cand bi = sorted[i];
+    const float ai = __fmul_rn(__fsub_rn(bi.x2, bi.x1), __fsub_rn(bi.y2, bi.y1));
+    for (int j = i + 1 + tid; j < cnt; j += NMS_THREADS) {
+      if (removed[j]) continue;
+      const Cand bj = sorted[j];
+      if (bj.cls != bi.cls) continue;
+      const float aj = __fmul_rn(__fsub_rn(bj.x2, bj.x1), __fsub_rn(bj.y2, bj.y1));
+      const float w = fmaxf(0.f, __fsub_rn(fminf(bi.x2, bj.x2), fmaxf(bi.x1, bj.x1)));
+      const float h = fmaxf(0.f, __fsub_rn(fminf(bi.y2, bj.y2), fmaxf(bi.y1, bj.y1)));
+      const float inter = __fmul_rn(w, h);
+      const float iou = __fdiv_rn(inter, __fadd_rn(__fsub_rn(__fadd_rn(ai, aj), inter), 1e-6f));
+      if (!(iou <= thr)) removed[j] = 1;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (nkeep > a.max_det) nkeep = a.max_det;  // score order: the top max_det stay
+
+  // ROI rectangle + area filter, order-preserving compaction
+  const ImgGeom gm = a.geom[n];
+  const int per = (nkeep + NMS_THREADS - 1) / NMS_THREADS;
+  const int k0 = tid * per, k1 = (k0 + per < nkeep) ? k0 + per : nkeep;
+  int nvalid = 0;
+  for (int k = k0; k < k1; ++k) {
+    const Cand c = sorted[keep[k]];
+    bool ok = true;
+    if (a.min_area >= 0) {
+      int x1 = (int)c.x1, y1 = (int)c.y1, x2 = (int)c.x2, y2 = (int)c.y2;
+      x1 = min(max(x1, 0), gm.w - 1); y1 = min(max(y1, 0), gm.h - 1);
+      x2 = min(max(x2, x1 + 1), gm.w); y2 = min(max(y2, y1 + 1), gm.h);
+      ok = ((x2 - x1) * (y2 - y1) >= a.min_area) && x2 > x1 && y2 > y1;
+    }
+    nvalid += ok ? 1 : 0;
+  }
+  s_part[tid] = nvalid;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < NMS_THREADS; ++t) { const int v = s_part[t]; s_part[t] = run; run += v; }
+    a.counts[n] = run;
+    a.counts[gridDim.x + n] = nkeep;
+    a.cand_count[n] = 0;  // ready for the next call
+  }
+  __syncthreads();
+  int o = s_part[tid];
+  lp_det* dets = a.dets + (long)n * a.max_det;
+  int* rects = a.rects + (long)n * a.max_det * 4;
+  for (int k = k0; k < k1; ++k) {
+    const Cand c = sorted[keep[k]];
+    int x1 = (int)c.x1, y1 = (int)c.y1, x2 = (int)c.x2, y2 = (int)c.y2;
+    x1 = min(max(x1, 0), gm.w - 1); y1 = min(max(y1, 0), gm.h - 1);
+    x2 = min(max(x2, x1 + 1), gm.w); y2 = min(max(y2, y1 + 1), gm.h);
+    const bool ok = a.min_area < 0 || (((x2 - x1) * (y2 - y1) >= a.min_area) && x2 > x1 && y2 > y1);
+    if (!ok) continue;
+    lp_det d;
+    d.x1 = c.x1; d.y1 = c.y1; d.x2 = c.x2; d.y2 = c.y2; d.det_conf = c.score; d.det_class = c.cls;
+    d.cls_class = -1; d.cls_conf = 0.f;
+    dets[o] = d;
+    rects[o * 4 + 0] = x1; rects[o * 4 + 1] = y1; rects[o * 4 + 2] = x2; rects[o * 4 + 3] = y2;
+    ++o;
+  }
+}
+
+void launch_nms(const NmsArgs& a, int N, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), true);
+  (void)once;
+  const size_t lds = nms_lds_bytes(a.A);
+  LP_CHECK(lds <= 150 * 1024, LP_ERR_STATE, "NMS: %d anchors exceed the LDS sort capacity", a.A);
+  LP_CHECK(a.A <= 16384, LP_ERR_STATE, "NMS: anchor index needs more than 14 key bits");
+  hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(NMS_THREADS), lds, st, a);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_index_kernel(const int* __restrict__ counts, RoiTable t, int N, int max_det,
+                                                        int max_rois) {
+  __shared__ int s_base[1025];
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < N; ++i) { s_base[i] = run; run += counts[i]; }
+    s_base[N] = run;
+    t.total[0] = run < max_rois ? run : max_rois;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= N; i += 256) t.base[i] = s_base[i];
+  for (int i = 0; i < N; ++i) {
+    const int b = s_base[i], c = s_base[i + 1] - b;
+    for (int k = threadIdx.x; k < c; k += 256)
+      if (b + k < max_rois) { t.img[b + k] = i; t.slot[b + k] = k; }
+  }
+}
+
+void launch_roi_index(const int* counts, const RoiTable& t, int N, int max_det, int max_rois, hipStream_t st) {
+  LP_CHECK(N <= 1024, LP_ERR_ARG, "batch larger than 1024");
+  hipLaunchKernelGGL(roi_index_kernel, dim3(1), dim3(256), 0, st, counts, t, N, max_det, max_rois);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+// PIL Image.resize((S,S), BILINEAR) of one ROI per workgroup (Pillow libImaging Resample.c):
+// triangle filter scaled by the down-sampling factor, coefficients normalised in double and
+// quantised to 22-bit fixed point, horizontal pass to uint8 then vertical pass to uint8.
+// Pinned against Pillow itself through oracle/pil_resize_ref.py.
+// ------------------------------------------------------------------------------------
+#define RR_THREADS 256
+#define RR_MAXK 129           /* ceil(support)*2+1 for crops up to 4096 px per side */
+#define RR_PRECISION_BITS 22
+
+size_t roi_resize_lds_bytes() {
+  // kx, ky: [64][RR_MAXK] int ; bounds: 4*64 int ; tmp rows: RR_MAXK*64*3 bytes
+  return (size_t)2 * 64 * RR_MAXK * 4 + 4 * 64 * 4 + (size_t)RR_MAXK * 64 * 3 + 64;
+}
+
+__device__ void pil_coeffs(int in_size, int out_size, int xx, int* k, int* xmin_out, int* n_out) {
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  const double ss = 1.0 / filterscale;
+  const double center = (xx + 0.5) * scale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  double ww = 0.0;
+  for (int x = 0; x < xmax; ++x) {
+    double v = (x + xmin - center + 0.5) * ss;
+    v = v < 0 ? -v : v;
+    ww += v < 1.0 ? 1.0 - v : 0.0;
+  }
+  for (int x = 0; x < xmax; ++x) {
+    double v = (x + xmin - center + 0.5) * ss;
+    v = v < 0 ? -v : v;
+    double w = v < 1.0 ? 1.0 - v : 0.0;
+    if (ww != 0.0) w /= ww;
+    k[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << RR_PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << RR_PRECISION_BITS));
+  }
+  *xmin_out = xmin;
+  *n_out = xmax;
+}
+
+__device__ __forceinline__ uint8_t clip8(int v) {
+  v >>= RR_PRECISION_BITS;
+  return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ __launch_bounds__(RR_THREADS) void roi_resize_kernel(const RoiResizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = a.S;
+  int* kx = reinterpret_cast<int*>(smem);
+  int* ky = kx + 64 * RR_MAXK;
+  int* bx = ky + 64 * RR_MAXK;  // [S][2]
+  int* by = bx + 2 * 64;
+  uint8_t* tmp = reinterpret_cast<uint8_t*>(by + 2 * 64);  // [rows][S][3]
+  const int tid = threadIdx.x;
+  const int R = a.tab.total[0];
+  for (int r = blockIdx.x; r < R; r += gridDim.x) {
+    const int img = a.tab.img[r], slot = a.tab.slot[r];
+    const ImgGeom gm = a.geom[img];
+    const int* rc = a.rects + ((long)img * a.max_det + slot) * 4;
+    const int rx = rc[0], ry = rc[1];
+    int in_w = rc[2] - rx, in_h = rc[3] - ry;
+    const uint8_t* src = a.src + gm.src_off;
+    uint8_t* out = a.out + (long)r * S * S * 3;
+    __syncthreads();
+    if (tid < S)
+      pil_coeffs(in_w, S, tid, kx + tid * RR_MAXK, bx + 2 * tid, bx + 2 * tid + 1);
+    else if (tid >= 64 && tid < 64 + S)
+      pil_coeffs(in_h, S, tid - 64, ky + (tid - 64) * RR_MAXK, by + 2 * (tid - 64), by + 2 * (tid - 64) + 1);
+    __syncthreads();
+    const int half = 1 << (RR_PRECISION_BITS - 1);
+    for (int yy = 0; yy < S; ++yy) {
+      const int ymin = by[2 * yy], ny = by[2 * yy + 1];
+      // horizontal pass of the ny source rows this output row needs
+      for (int i = tid; i < ny * S * 3; i += RR_THREADS) {
+        const int c = i % 3, xx = (i / 3) % S, row = i / (3 * S);
+        const int xmin = bx[2 * xx], nx = bx[2 * xx + 1];
+        const uint8_t* p = src + ((long)(ry + ymin + row) * gm.w + rx + xmin) * 3 + (2 - c);  // BGR -> RGB
+        uint8_t v;
+        if (in_w == S) {
+          v = p[0];  // Pillow skips the pass when the width already matches (identity either way)
+        } else {
+          const int* k = kx + xx * RR_MAXK;
+          int acc = half;
+          for (int x = 0; x < nx; ++x) acc += (int)p[x * 3] * k[x];
+          v = clip8(acc);
+        }
+        tmp[i] = v;
+      }
+      __syncthreads();
+      for (int i = tid; i < S * 3; i += RR_THREADS) {
+        uint8_t v;
+        if (in_h == S) {
+          v = tmp[i];
+        } else {
+          const int* k = ky + yy * RR_MAXK;
+          int acc = half;
+          for (int y = 0; y < ny; ++y) acc += (int)tmp[y * S * 3 + i] * k[y];
+          v = clip8(acc);
+        }
+        out[yy * S * 3 + i] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+void launch_roi_resize(const RoiResizeArgs& a, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
+  (void)once;
+  LP_CHECK(a.S <= 64, LP_ERR_ARG, "classifier input larger than 64 unsupported by the resize kernel");
+  hipLaunchKernelGGL(roi_resize_kernel, dim3(512), dim3(RR_THREADS), roi_resize_lds_bytes(), st, a);
+  LP_HIP(hipGetLastError());
+}
+
+}  // namespace lp

@@ -1,0 +1,425 @@
+"""Drop-in replacements for the three classes the reference's ``main()`` builds from its CLI
+flags (``src/tt100k/pipeline/e2e.py``): ``NCNNDetector`` (:195), ``PyTorchClassifier`` (:350)
+and ``HybridPipeline`` (:399), plus the ``PipelineMetrics`` dataclass (:34).  Same constructor
+arguments, same method signatures, same return types and empty-result quirks; the arithmetic
+runs in liblitepi_hip.so on an MI355X instead of NCNN / torch-CPU / NumPy.
+
+``Engine`` is the thin object wrapper over the C-ABI handle that the three classes share.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import DET_DTYPE, LpConfig, LpKernelTime, LpTiming, check
+
+_PREC = {"fp32": _ffi.LP_FP32, "fp16": _ffi.LP_FP16, "float32": _ffi.LP_FP32, "float16": _ffi.LP_FP16, "half": _ffi.LP_FP16}
+
+
+def _as_bgr(img: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError(f"expected a BGR uint8 HxWx3 image, got shape {img.shape}")
+    return a
+
+
+class Engine:
+    """One GPU pipeline handle (not thread-safe; one per GPU)."""
+
+    def __init__(self, precision: str = "fp16", max_batch: int = 1, max_det: int = 300, num_classes: int = 58,
+                 det_input: int = 640, cls_input: int = 64, device: int = 0, max_rois: int = 0, conv_impl: int = 0):
+        self.lib = _ffi.load_library()
+        cfg = LpConfig()
+        self.lib.lp_default_config(C.byref(cfg))
+        cfg.device, cfg.precision, cfg.max_batch, cfg.max_det = device, _PREC[precision], max_batch, max_det
+        cfg.num_classes, cfg.det_input, cfg.cls_input, cfg.max_rois, cfg.conv_impl = num_classes, det_input, cls_input, max_rois, conv_impl
+        self.cfg = cfg
+        self.precision = precision
+        self._h = C.c_void_p()
+        check(self.lib, self.lib.lp_create(C.byref(cfg), C.byref(self._h)))
+        self.has_detector = False
+        self.has_classifier = False
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.lp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- models ---------------------------------------------------------------------------
+    def load_detector(self, param_path: str, bin_path: str) -> None:
+        check(self.lib, self.lib.lp_load_detector_ncnn(self._h, os.fsencode(param_path), os.fsencode(bin_path)))
+        self.has_detector = True
+        a, nc, rm, macs = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        check(self.lib, self.lib.lp_detector_info(self._h, C.byref(a), C.byref(nc), C.byref(rm), C.byref(macs)))
+        self.num_anchors, self.det_classes, self.reg_max, self.det_macs = a.value, nc.value, rm.value, macs.value
+
+    def load_classifier(self, state_dict: Dict[str, object]) -> None:
+        """state_dict: torchvision shufflenet_v2_x1_0 keys -> torch tensors or ndarrays."""
+        names, arrays = [], []
+        for k, v in state_dict.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            names.append(k.encode())
+            arrays.append(np.ascontiguousarray(a, dtype=np.float32))
+        n = len(names)
+        c_names = (C.c_char_p * n)(*names)
+        c_data = (C.c_void_p * n)(*[a.ctypes.data for a in arrays])
+        shapes = [np.asarray(a.shape, dtype=np.int64) for a in arrays]
+        c_shapes = (C.c_void_p * n)(*[s.ctypes.data for s in shapes])
+        c_ndims = (C.c_int * n)(*[a.ndim for a in arrays])
+        check(self.lib, self.lib.lp_load_classifier_tensors(self._h, n, c_names, c_data, c_shapes, c_ndims))
+        self.has_classifier = True
+
+    # ---- inference ---------------------------------------------------------------------------
+    def detect_raw(self, bgr: np.ndarray) -> np.ndarray:
+        """uint8 BGR [B,S,S,3] -> fp32 out0 [B,4+nc,A] (parity hook for ex.extract('out0'))."""
+        a = np.ascontiguousarray(bgr, dtype=np.uint8)
+        S = self.cfg.det_input
+        if a.ndim == 3:
+            a = a[None]
+        if a.shape[1:] != (S, S, 3):
+            raise ValueError(f"detect_raw expects [B,{S},{S},3], got {a.shape}")
+        out = np.empty((a.shape[0], 4 + self.det_classes, self.num_anchors), np.float32)
+        check(self.lib, self.lib.lp_detect_raw(self._h, a.ctypes.data, a.shape[0], out.ctypes.data))
+        return out
+
+    def _img_args(self, images: Sequence[np.ndarray]):
+        imgs = [_as_bgr(i) for i in images]
+        n = len(imgs)
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        hs = (C.c_int * n)(*[i.shape[0] for i in imgs])
+        ws = (C.c_int * n)(*[i.shape[1] for i in imgs])
+        return imgs, ptrs, hs, ws
+
+    def detect(self, images: Sequence[np.ndarray], conf: float, iou: float):
+        imgs, ptrs, hs, ws = self._img_args(images)
+        B = len(imgs)
+        dets = np.zeros((B, self.cfg.max_det), dtype=DET_DTYPE)
+        counts = (C.c_int * B)()
+        check(self.lib, self.lib.lp_detect(self._h, ptrs, hs, ws, B, conf, iou, dets.ctypes.data, counts))
+        return dets, np.array(counts[:], dtype=np.int64)
+
+    def run_batch(self, images: Sequence[np.ndarray], conf: float, iou: float, min_area: int):
+        imgs, ptrs, hs, ws = self._img_args(images)
+        B = len(imgs)
+        dets = np.zeros((B, self.cfg.max_det), dtype=DET_DTYPE)
+        counts, num_det = (C.c_int * B)(), (C.c_int * B)()
+        timing = LpTiming()
+        check(self.lib, self.lib.lp_run_batch(self._h, ptrs, hs, ws, B, conf, iou, int(min_area), dets.ctypes.data, counts,
+                                              num_det, C.byref(timing)))
+        return dets, np.array(counts[:], dtype=np.int64), np.array(num_det[:], dtype=np.int64), timing
+
+    def run_batch_device(self, dev_imgs: int, B: int, H: int, W: int, conf: float, iou: float, min_area: int,
+                         dev_dets: int, dev_counts: int) -> None:
+        check(self.lib, self.lib.lp_run_batch_device(self._h, C.c_void_p(dev_imgs), B, H, W, conf, iou, int(min_area),
+                                                     C.c_void_p(dev_dets), C.c_void_p(dev_counts)))
+
+    def classify(self, rois: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+        imgs, ptrs, hs, ws = self._img_args(rois)
+        R = len(imgs)
+        ids = (C.c_int * R)()
+        probs = np.empty((R, self.cfg.num_classes), np.float32)
+        check(self.lib, self.lib.lp_classify(self._h, ptrs, hs, ws, R, ids, probs.ctypes.data_as(C.POINTER(C.c_float))))
+        return np.array(ids[:], dtype=np.int64), probs
+
+    # ---- streams / profiling -------------------------------------------------------------------
+    def set_stream(self, stream_handle: int) -> None:
+        check(self.lib, self.lib.lp_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def synchronize(self) -> None:
+        check(self.lib, self.lib.lp_synchronize(self._h))
+
+    def profile_next(self, enable: bool = True) -> None:
+        check(self.lib, self.lib.lp_profile_next(self._h, int(enable)))
+
+    def profile_read(self) -> List[dict]:
+        n = C.c_int()
+        cap = 512
+        buf = (LpKernelTime * cap)()
+        check(self.lib, self.lib.lp_profile_read(self._h, buf, cap, C.byref(n)))
+        return [dict(name=buf[i].name.decode(), layer=buf[i].layer.decode(), ms=buf[i].ms, flops=buf[i].flops,
+                     bytes=buf[i].bytes) for i in range(min(cap, n.value))]
+
+    # ---- test hooks ----------------------------------------------------------------------------
+    def debug_blob(self, name: str) -> np.ndarray:
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        check(self.lib, self.lib.lp_debug_blob(self._h, name.encode(), None, 0, C.byref(c), C.byref(h), C.byref(w)))
+        out = np.empty((1, c.value, h.value, w.value), np.float32)
+        check(self.lib, self.lib.lp_debug_blob(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size,
+                                               C.byref(c), C.byref(h), C.byref(w)))
+        return out
+
+    def test_conv(self, x, w, bias, stride=1, act=0, res=None, impl=0) -> np.ndarray:
+        fp = C.POINTER(C.c_float)
+        x = np.ascontiguousarray(x, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        N, Cin, H, W = x.shape
+        Cout, _, k, _ = w.shape
+        Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+        y = np.empty((N, Cout, Ho, Wo), np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        r = None if res is None else np.ascontiguousarray(res, np.float32)
+        check(self.lib, self.lib.lp_test_conv(self._h, impl, x.ctypes.data_as(fp), N, Cin, H, W, w.ctypes.data_as(fp),
+                                              None if b is None else b.ctypes.data_as(fp), Cout, k, stride, act,
+                                              None if r is None else r.ctypes.data_as(fp), y.ctypes.data_as(fp)))
+        return y
+
+    def test_postprocess(self, out0, orig_shape, ratio, pad, conf, iou):
+        fp = C.POINTER(C.c_float)
+        o = np.ascontiguousarray(out0, np.float32)
+        nc, A = o.shape[0] - 4, o.shape[1]
+        dets = np.zeros(A, dtype=DET_DTYPE)
+        cnt = C.c_int()
+        check(self.lib, self.lib.lp_test_postprocess(self._h, o.ctypes.data_as(fp), nc, A, int(orig_shape[0]), int(orig_shape[1]),
+                                                     float(ratio), float(pad[0]), float(pad[1]), float(conf), float(iou),
+                                                     dets.ctypes.data, C.byref(cnt)))
+        return dets[:cnt.value]
+
+    def test_roi_resize(self, rois: Sequence[np.ndarray]) -> np.ndarray:
+        imgs, ptrs, hs, ws = self._img_args(rois)
+        S = self.cfg.cls_input
+        out = np.empty((len(imgs), S, S, 3), np.uint8)
+        check(self.lib, self.lib.lp_test_roi_resize(self._h, ptrs, hs, ws, len(imgs), out.ctypes.data))
+        return out
+
+    def test_letterbox(self, img: np.ndarray):
+        a = _as_bgr(img)
+        S = self.cfg.det_input
+        out = np.empty((S, S, 3), np.uint8)
+        r, pw, ph = C.c_float(), C.c_float(), C.c_float()
+        check(self.lib, self.lib.lp_test_letterbox(self._h, a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data,
+                                                   C.byref(r), C.byref(pw), C.byref(ph)))
+        return out, r.value, (pw.value, ph.value)
+
+
+# ==================== reference-compatible surface ====================
+@dataclass
+class PipelineMetrics:
+    """Same fields as the reference dataclass (e2e.py:34-62)."""
+    t_detection: float = 0.0
+    t_roi_extract: float = 0.0
+    t_classification: float = 0.0
+    t_postprocess: float = 0.0
+    t_total: float = 0.0
+    fps: float = 0.0
+    num_detections: int = 0
+    det_confidence_avg: float = 0.0
+    cls_confidence_avg: float = 0.0
+    cpu_percent: float = 0.0
+    memory_mb: float = 0.0
+    temperature: float = 0.0
+    precision: float = 0.0
+    recall: float = 0.0
+    f1: float = 0.0
+    level: str = "HIP(MI355X)"
+
+
+def _empty_detect():
+    # the reference returns float64 empties here (e2e.py:264,292-294)
+    return np.empty((0, 4)), np.empty((0,)), np.empty((0,))
+
+
+class NCNNDetector:
+    """e2e.py:195-316.  ``use_gpu``/``num_threads`` are accepted and ignored (the detector always
+    runs on the HIP device)."""
+
+    def __init__(self, param_path: str, bin_path: str, input_size: int = 640, use_gpu: bool = False, num_threads: int = 4,
+                 input_name: str = "in0", output_name: str = "out0", *, precision: str = "fp16", max_batch: int = 1,
+                 max_det: int = 300, device: int = 0, _engine: Optional[Engine] = None):
+        self.input_size = input_size
+        self.input_name = input_name
+        self.output_name = output_name
+        print("[HIP Detector] Loading model...")
+        print(f"  Param: {param_path}")
+        print(f"  Bin: {bin_path}")
+        self.engine = _engine or Engine(precision=precision, max_batch=max_batch, max_det=max_det, det_input=input_size,
+                                        device=device)
+        try:
+            self.engine.load_detector(param_path, bin_path)
+        except _ffi.LitepiError as e:  # e2e.py:213-216 raises RuntimeError on load failure
+            raise RuntimeError(str(e)) from e
+        print(f"  Device: HIP:{self.engine.cfg.device} ({self.engine.precision})")
+        print(f"  Input size: {input_size}x{input_size}")
+
+    def detect_batch(self, images: Sequence[np.ndarray], conf_threshold: float = 0.5, iou_threshold: float = 0.45):
+        try:
+            dets, counts = self.engine.detect(images, conf_threshold, iou_threshold)
+        except _ffi.LitepiError:
+            return [_empty_detect() for _ in images]  # engine failure -> empty, never raises (e2e.py:309-310)
+        out = []
+        for i, n in enumerate(counts):
+            if n == 0:
+                out.append(_empty_detect())
+                continue
+            d = dets[i, :n]
+            boxes = np.stack([d["x1"], d["y1"], d["x2"], d["y2"]], axis=1).astype(np.float32)
+            out.append((boxes, d["det_conf"].astype(np.float32), d["det_class"].astype(np.int64)))
+        return out
+
+    def detect(self, image: np.ndarray, conf_threshold: float = 0.5, iou_threshold: float = 0.45):
+        return self.detect_batch([image], conf_threshold, iou_threshold)[0]
+
+
+def load_classifier_state(model_path: Optional[str], num_classes: int):
+    """torch is used only to READ the checkpoint (weights_only: nothing from the file is executed).
+    Returns (state_dict, loaded_flag); a missing/unreadable file gives seeded random weights and a
+    warning, like the reference's silent random-init fallback (e2e.py:337-343)."""
+    import torch
+
+    if model_path and os.path.exists(model_path):
+        try:
+            sd = torch.load(model_path, map_location="cpu", weights_only=True)
+            if isinstance(sd, dict) and "state_dict" in sd:
+                sd = sd["state_dict"]
+            print(f"Loaded classifier weights from {model_path}")
+            return sd, True
+        except Exception as e:  # noqa: BLE001 - mirror the reference's catch-all
+            print(f"WARNING: could not load classifier weights ({e}); the classifier stays RANDOM-INIT")
+    else:
+        print(f"WARNING: classifier weights {model_path!r} not found; the classifier stays RANDOM-INIT")
+    return random_shufflenet_state(num_classes), False
+
+
+def random_shufflenet_state(num_classes: int, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded random ShuffleNetV2 x1.0 state_dict with torchvision's key names and shapes."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = (rng.standard_normal((co, ci, k, k)) * (1.7 / (ci * k * k)) ** 0.5).astype(np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = rng.uniform(0.75, 1.25, c).astype(np.float32)
+        sd[name + ".bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_mean"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_var"] = rng.uniform(0.75, 1.25, c).astype(np.float32)
+
+    conv("conv1.0", 24, 3, 3)
+    bn("conv1.1", 24)
+    inp = 24
+    for stage, rep, oup in (("stage2", 4, 116), ("stage3", 8, 232), ("stage4", 4, 464)):
+        bf = oup // 2
+        for r in range(rep):
+            p = f"{stage}.{r}."
+            if r == 0:
+                conv(p + "branch1.0", inp, 1, 3); bn(p + "branch1.1", inp)
+                conv(p + "branch1.2", bf, inp, 1); bn(p + "branch1.3", bf)
+                conv(p + "branch2.0", bf, inp, 1)
+            else:
+                conv(p + "branch2.0", bf, bf, 1)
+            bn(p + "branch2.1", bf)
+            conv(p + "branch2.3", bf, 1, 3); bn(p + "branch2.4", bf)
+            conv(p + "branch2.5", bf, bf, 1); bn(p + "branch2.6", bf)
+        inp = oup
+    conv("conv5.0", 1024, 464, 1)
+    bn("conv5.1", 1024)
+    sd["fc.weight"] = (rng.standard_normal((num_classes, 1024)) * (1.0 / 1024) ** 0.5).astype(np.float32)
+    sd["fc.bias"] = (rng.standard_normal(num_classes) * 0.1).astype(np.float32)
+    return sd
+
+
+class PyTorchClassifier:
+    """e2e.py:350-396 (name kept for drop-in use; the model runs in HIP, not torch)."""
+
+    def __init__(self, model_path: str, arch: str, num_classes: int = 58, input_size: int = 64, device: str = "cpu", *,
+                 precision: str = "fp16", max_rois: int = 1024, _engine: Optional[Engine] = None):
+        if arch != "shufflenetv2":
+            raise ValueError(f"Unknown architecture for the HIP backend: {arch} (only shufflenetv2 is accelerated)")
+        self.input_size = input_size
+        self.num_classes = num_classes
+        self.arch = arch
+        print(f"[HIP Classifier] Loading {arch} model...")
+        print(f"  Model: {model_path}")
+        self.engine = _engine or Engine(precision=precision, max_batch=1, max_det=max_rois, num_classes=num_classes,
+                                        cls_input=input_size, max_rois=max_rois)
+        sd, self.weights_loaded = load_classifier_state(model_path, num_classes)
+        self.engine.load_classifier(sd)
+        print(f"  Architecture: {arch}")
+        print(f"  Input size: {input_size}x{input_size}")
+        print(f"  Num classes: {num_classes}")
+
+    def predict_batch(self, images: List[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+        if len(images) == 0:
+            return np.array([]), np.array([])  # e2e.py:380-381
+        ids, probs = self.engine.classify(images)
+        return ids, probs
+
+
+class HybridPipeline:
+    """e2e.py:399-531 with one extra method, ``run_batch``.  Detector and classifier share one
+    device handle, so detections never leave the GPU between the two stages."""
+
+    def __init__(self, detector_param: str, detector_bin: str, classifier_path: str, classifier_arch: str,
+                 num_classes: int = 58, det_input_size: int = 640, cls_input_size: int = 64, use_gpu_detector: bool = False,
+                 detector_threads: int = 4, classifier_device: str = "cpu", batch_size: int = 8, *, precision: str = "fp16",
+                 max_batch: int = 1, max_det: int = 300, device: int = 0, max_rois: int = 0):
+        print("\n" + "=" * 70)
+        print("HYBRID PIPELINE: HIP Detector + HIP Classifier (MI355X)")
+        print("=" * 70)
+        self.engine = Engine(precision=precision, max_batch=max_batch, max_det=max_det, num_classes=num_classes,
+                             det_input=det_input_size, cls_input=cls_input_size, device=device, max_rois=max_rois)
+        self.detector = NCNNDetector(detector_param, detector_bin, det_input_size, use_gpu_detector, detector_threads,
+                                     _engine=self.engine)
+        self.classifier = PyTorchClassifier(classifier_path, classifier_arch, num_classes, cls_input_size, classifier_device,
+                                            _engine=self.engine)
+        self.batch_size = batch_size  # kept for signature parity: all ROIs of a call are classified in one pass
+        print("\nPipeline ready!")
+        print("=" * 70 + "\n")
+
+    def run_batch(self, images: Sequence[np.ndarray], conf_threshold: float = 0.5, iou_threshold: float = 0.45,
+                  min_area: int = 100) -> List[Tuple[List[Dict], PipelineMetrics]]:
+        t0 = time.perf_counter()
+        try:
+            dets, counts, num_det, timing = self.engine.run_batch(images, conf_threshold, iou_threshold, min_area)
+        except _ffi.LitepiError:
+            return [([], PipelineMetrics()) for _ in images]
+        wall_ms = (time.perf_counter() - t0) * 1000.0
+        B = len(images)
+        out = []
+        for i in range(B):
+            m = PipelineMetrics()
+            # device stage times are per batch call; report the per-image share like a sequential loop would
+            m.t_detection = timing.t_detection / B
+            m.t_roi_extract = timing.t_roi_extract / B
+            m.t_classification = timing.t_classification / B
+            m.t_total = wall_ms / B
+            m.fps = 1000.0 / m.t_total if m.t_total > 0 else 0
+            m.num_detections = int(num_det[i])  # counted BEFORE the min-area filter (e2e.py:454)
+            n = int(counts[i])
+            d = dets[i, :n]
+            if n:
+                m.det_confidence_avg = float(np.mean(d["det_conf"]))
+                cl = d["cls_conf"][d["cls_class"] >= 0]
+                if len(cl):
+                    m.cls_confidence_avg = float(np.mean(cl))
+            results = []
+            for k in range(n):
+                box = np.array([d["x1"][k], d["y1"][k], d["x2"][k], d["y2"][k]], np.float32)
+                results.append({
+                    "bbox": tuple(box.astype(int)),          # truncation of the float box (e2e.py:522)
+                    "det_class": int(d["det_class"][k]),
+                    "det_conf": float(d["det_conf"][k]),
+                    "cls_class": int(d["cls_class"][k]),
+                    "cls_conf": float(d["cls_conf"][k]),
+                    "time_det": m.t_detection / n,
+                    "time_cls": m.t_classification / n,
+                })
+            out.append((results, m))
+        return out
+
+    def run(self, image: np.ndarray, conf_threshold: float = 0.5, iou_threshold: float = 0.45,
+            min_area: int = 100) -> Tuple[List[Dict], PipelineMetrics]:
+        return self.run_batch([image], conf_threshold, iou_threshold, min_area)[0]
