@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=12, help="images in the CPU baseline sample")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent pipeline handles (own stream + activation buffers) the steps rotate over, so "
+                         "consecutive steps overlap on the GPU")
     ap.add_argument("--dump-profile", default="", help="write the per-launch profile of the roofline pass to this JSON file")
     return ap.parse_args()
 
@@ -138,22 +141,30 @@ def main():
     cal_imgs = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (8, 640, 640, 3), dtype=np.uint8)).to(dev)
     param, binf, cls_state, spec = build_models(args, workdir, engine_factory, cal_imgs)
 
-    eng = engine_factory()
-    eng.load_detector(param, binf)
-    eng.load_classifier(cls_state)
-    # a non-default torch stream: the library launches on it, so torch events, the RCCL gather and
-    # torch.cuda.synchronize() are all ordered with the pipeline's kernels
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    eng.set_stream(stream.cuda_stream)
-    dets, counts = alloc_result_buffers(B, args.max_det, dev)
+    # args.inflight pipeline handles, each with its own (non-default torch) stream and buffers:
+    # step i runs on handle i % inflight, so the tail of one step overlaps the head of the next.
+    # torch streams: torch.cuda.synchronize(), events and the RCCL gather see the library's work.
+    engs, streams, outs = [], [], []
+    for _ in range(max(1, args.inflight)):
+        e = engine_factory()
+        e.load_detector(param, binf)
+        e.load_classifier(cls_state)
+        st = torch.cuda.Stream(device=dev)
+        e.set_stream(st.cuda_stream)
+        engs.append(e); streams.append(st); outs.append(alloc_result_buffers(B, args.max_det, dev))
+    eng, (dets, counts) = engs[0], outs[0]
     torch.cuda.synchronize()
+    step_no = [0]
 
     def step():
-        eng.run_batch_device(imgs.data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, dets.data_ptr(), counts.data_ptr())
-        if world > 1:
-            return gather_detections(dets, counts, dst=0)
-        return dets, counts.view(1, -1)
+        i = step_no[0] % len(engs)
+        step_no[0] += 1
+        d, c = outs[i]
+        with torch.cuda.stream(streams[i]):
+            engs[i].run_batch_device(imgs.data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
+            if world > 1:
+                return gather_detections(d, c, dst=0)
+        return d, c.view(1, -1)
 
     for _ in range(args.warmup):
         step()
@@ -180,6 +191,7 @@ def main():
     # ---- roofline of the dominant kernel family: profiled passes of the same step ---------------
     roofline, families = None, {}
     if rank == 0:
+        torch.cuda.set_stream(streams[0])
         launches = []
         for _ in range(args.profile_steps):
             eng.profile_next(True)
@@ -242,7 +254,7 @@ def main():
                 "detector": f"YOLO-LitePi {args.preset} architecture, seeded random weights (LSUV-scaled), "
                             f"{flop_img / 1e9:.3f} GFLOP/image, class bias calibrated to ~{TARGET_CANDIDATES} candidates/image",
                 "classifier": f"ShuffleNetV2 x1.0, {NUM_CLASSES} classes, seeded random weights, 64x64 ROIs",
-                "conf": CONF, "iou": IOU, "min_area": MIN_AREA, "max_det": args.max_det,
+                "conf": CONF, "iou": IOU, "min_area": MIN_AREA, "max_det": args.max_det, "steps_in_flight": len(engs),
                 "global_batch": world * B,
                 "rois_per_step_rank0": int(kept), "boxes_pre_area_filter_rank0": int(prefilter),
                 "detector_fp16_roofline_frac_e2e": (total_images / elapsed) * flop_img / (world * PEAK_FP16_TFLOPS * 1e12),
@@ -251,7 +263,8 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    eng.close()
+    for e in engs:
+        e.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -46,7 +46,7 @@ def resize_linear_u8(img: np.ndarray, dst_w: int, dst_h: int) -> np.ndarray:
     ONE = 1 << 11
 
     def coeffs(dst, src):
-        scale = src / dst
+        scale = 1.0 / (dst / src)  # OpenCV: inv_scale = dsize/ssize; scale = 1./inv_scale
         idx = np.empty(dst, np.int64)
         a = np.empty((dst, 2), np.int64)
         for d in range(dst):

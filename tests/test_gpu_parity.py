@@ -338,9 +338,10 @@ def _calibrated_model(tmp_path, preset="v1", target_per_image=8):
     rng = np.random.default_rng(123)
     imgs = rng.integers(0, 256, (2, 640, 640, 3), dtype=np.uint8)
     ref, _ = _oracle_out0(p, b, imgs)
-    s = np.sort(ref[:, 4].ravel())[::-1]
-    kth = s[target_per_image * 2]
-    logit = np.log(kth / (1 - kth))
+    s = np.sort(ref[:, 4].astype(np.float64).ravel())[::-1]
+    k = target_per_image * 2
+    # put the threshold midway (in logit space) between the k-th and (k+1)-th score: no anchor sits on it
+    logit = 0.5 * (np.log(s[k - 1] / (1 - s[k - 1])) + np.log(s[k] / (1 - s[k])))
     ncnn_export.shift_cls_bias(p, b, float(np.log(0.25 / 0.75) - logit))
     return p, b, imgs
 

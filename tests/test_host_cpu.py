@@ -1,0 +1,211 @@
+"""CPU suite (-m "not gpu"), part 2: the boundary and the host logic.
+
+* liblitepi_hip.so loads and exports every symbol include/litepi.h declares (no compute calls);
+* without a GPU the product fails loudly (no CPU fallback);
+* the multi-GPU path (shard + one gather of padded records) with world_size 2 over gloo;
+* host-side helpers (synthetic classifier state, record layout, CLI surface).
+"""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from litepi import _ffi
+    if not os.path.exists(_ffi.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    return _ffi.load_library()
+
+
+def test_library_exports_every_declared_symbol():
+    from litepi import _ffi
+    lib = _lib()
+    header = open(os.path.join(ROOT, "include", "litepi.h")).read()
+    declared = sorted(set(re.findall(r"\b(lp_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in litepi.h but not exported"
+    assert sorted(_ffi.SYMBOLS) == declared
+    assert lib.lp_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    from litepi import _ffi
+    assert ctypes.sizeof(_ffi.LpDet) == 32 and np.dtype(_ffi.DET_DTYPE).itemsize == 32
+    assert ctypes.sizeof(_ffi.LpConfig) == 16 * 4
+    assert ctypes.sizeof(_ffi.LpTiming) == 16
+    assert ctypes.sizeof(_ffi.LpKernelTime) == 48 + 32 + 4 + 4 + 16  # name, layer, ms, pad, flops+bytes
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_fails_loudly_never_falls_back():
+    from litepi import Engine, _ffi
+    _lib()
+    with pytest.raises(_ffi.LitepiError) as ei:
+        Engine()
+    assert ei.value.code == _ffi.LP_ERR_NODEVICE
+    assert "no CPU path" in str(ei.value)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "yolo-litepi_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f"{f} imports the oracle"
+
+
+def test_shard_range_partitions_exactly():
+    from litepi.distributed import shard_range
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "yolo-litepi_amd"))
+    from litepi.distributed import alloc_result_buffers, gather_detections, records_to_numpy
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, max_det = 3, 5
+    dets, counts = alloc_result_buffers(B, max_det, "cpu")
+    rec = records_to_numpy(dets)            # a copy; fill a structured array and write it back
+    rec = np.zeros((B, max_det), dtype=rec.dtype)
+    for b in range(B):
+        n = (rank + b) % (max_det + 1)
+        counts[b] = n
+        counts[B + b] = n + 1
+        for k in range(n):
+            rec[b, k] = (rank, b, k, 0.5, 0.9 - 0.1 * k, 0, rank * 10 + k, 0.75)
+    dets.copy_(torch.from_numpy(rec.view(np.uint8).reshape(B, max_det, 32)))
+    out = gather_detections(dets, counts, dst=0)
+    if rank == 0:
+        all_dets, all_counts = out
+        r = records_to_numpy(all_dets)
+        ok = all_dets.shape == (world * B, max_det, 32) and all_counts.shape == (world, 2 * B)
+        for src in range(world):
+            for b in range(B):
+                n = (src + b) % (max_det + 1)
+                ok = ok and int(all_counts[src, b]) == n and int(all_counts[src, B + b]) == n + 1
+                for k in range(n):
+                    e = r[src * B + b, k]
+                    ok = ok and e["x1"] == src and e["y1"] == b and e["x2"] == k and e["cls_class"] == src * 10 + k
+        q.put(ok)
+    else:
+        q.put(out is None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_detection_records_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res)
+
+
+def test_single_process_gather_is_identity():
+    from litepi.distributed import alloc_result_buffers, gather_detections
+    dets, counts = alloc_result_buffers(2, 4, "cpu")
+    d, c = gather_detections(dets, counts)
+    assert d is dets and c.shape == (1, 4)
+
+
+def test_random_shufflenet_state_matches_torchvision_layout():
+    """The product's random-init classifier state has the key names/shapes of the oracle's
+    torchvision-compatible module (so real shufflenetv2.pth files are interchangeable)."""
+    from litepi.backend import random_shufflenet_state
+    from oracle import shufflenet_ref as S
+    sd = random_shufflenet_state(49, seed=3)
+    ref = {k: v for k, v in S.ShuffleNetV2(49).state_dict().items() if not k.endswith("num_batches_tracked")}
+    assert set(sd) == set(ref)
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    m = S.ShuffleNetV2(49)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+
+
+def test_shift_cls_bias_touches_only_the_class_projections(tmp_path):
+    from litepi import ncnn_export
+    from oracle import ncnn_ref
+    p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    ncnn_export.export_detector(p, b, "v1", seed=5, cls_bias=-1.0)
+    before = ncnn_ref.load_model(p, b)
+    ncnn_export.shift_cls_bias(p, b, 0.75)
+    after = ncnn_ref.load_model(p, b)
+    changed = 0
+    for l0, l1 in zip(ncnn_ref.conv_layers(before), ncnn_ref.conv_layers(after)):
+        assert np.array_equal(l0.weight, l1.weight)
+        if l0.bias is None:
+            continue
+        if not np.array_equal(l0.bias, l1.bias):
+            changed += 1
+            assert l0.weight.shape[0] == 1 and np.allclose(l1.bias - l0.bias, 0.75)
+    assert changed == 3
+
+
+def test_cli_surface_matches_reference_flags():
+    """litepi.e2e keeps the reference's argument surface (e2e.py:1017-1048)."""
+    from litepi import e2e
+    ap = e2e.build_parser()
+    flags = {a.option_strings[0] for a in ap._actions if a.option_strings}
+    for f in ("--detector_param", "--detector_bin", "--classifier", "--clf_arch", "--input", "--labels", "--classes",
+              "--num_samples", "--seed", "--yolo_conf", "--benchmark_conf", "--min_area", "--iou_threshold",
+              "--det_input_size", "--cls_input_size", "--detector_threads", "--batch_size", "--device", "--output",
+              "--save_viz"):
+        assert f in flags, f
+    d = ap.parse_args(["--detector_param", "a", "--detector_bin", "b", "--input", "i", "--labels", "l", "--classes", "c"])
+    assert (d.seed, d.yolo_conf, d.benchmark_conf, d.min_area, d.iou_threshold) == (42, 0.001, 0.25, 50, 0.45)
+    assert (d.det_input_size, d.cls_input_size, d.detector_threads, d.batch_size) == (640, 64, 4, 8)
+
+
+def test_evaluate_predictions_matches_reference_goldens(golden_dir):
+    """litepi.e2e.evaluate_predictions vs outputs of the REFERENCE's evaluate_predictions
+    (tools/make_goldens.py ran it on these toy sets in the build container)."""
+    from litepi.e2e import evaluate_predictions
+    g = np.load(os.path.join(golden_dir, "ref_evaluate.npz"))
+    for i in range(4):
+        nimg, nclass = g[f"c{i}_nimg_nclass"]
+        preds = [[] for _ in range(nimg)]
+        gts = [[] for _ in range(nimg)]
+        for row in g[f"c{i}_preds"]:
+            preds[int(row[0])].append({"bbox": tuple(int(v) for v in row[1:5]), "conf": float(row[5]), "cls_class": int(row[6])})
+        for row in g[f"c{i}_gts"]:
+            gts[int(row[0])].append(tuple(int(v) for v in row[1:]))
+        m = evaluate_predictions(preds, gts, int(nclass), 0.45)
+        for k in ("precision", "recall", "f1", "tp", "fp", "fn", "ap50_per_class"):
+            assert np.allclose(m[k], g[f"c{i}_{k}"], rtol=0, atol=1e-12), (i, k)
+        assert np.allclose([m["mAP50"], m["mAP50_95"]], g[f"c{i}_map"], atol=1e-12)
+        assert np.array_equal(m["classes_present"], g[f"c{i}_present"])

@@ -10,6 +10,7 @@ called:
   nms_numpy                      e2e.py:89-119
   NCNNDetector.postprocess       e2e.py:240-296  (unbound, dummy self)
   HybridPipeline.run ROI logic   e2e.py:443-531  (fake detector / classifier)
+  evaluate_predictions           e2e.py:656-824
 
 Inputs are seeded and tie-free (distinct scores), so the goldens do not depend
 on how NumPy's unstable argsort orders equal keys.  The committed .npz files
@@ -201,6 +202,45 @@ def gen_pipeline(ref, rng):
     print("pipeline:", [cases[f"c{j}_res_bbox"].shape[0] for j in range(4)])
 
 
+def gen_evaluate(ref, rng):
+    """evaluate_predictions (e2e.py:656-824) on toy prediction / ground-truth sets."""
+    cases = {}
+    nclass = 6
+    for i, (nimg, noise, drop, extra) in enumerate([(12, 2.0, 0.1, 1), (30, 6.0, 0.3, 3), (5, 0.5, 0.0, 0), (8, 12.0, 0.5, 4)]):
+        preds_all, gts_all = [], []
+        for _ in range(nimg):
+            ng = int(rng.integers(0, 5))
+            gts, preds = [], []
+            for _ in range(ng):
+                x1, y1 = rng.integers(0, 500, 2)
+                w, h = rng.integers(20, 120, 2)
+                c = int(rng.integers(0, nclass - 1))  # class nclass-1 never appears in GT
+                gts.append((c, int(x1), int(y1), int(x1 + w), int(y1 + h)))
+                if rng.random() >= drop:
+                    d = rng.normal(0, noise, 4)
+                    pc = c if rng.random() < 0.85 else int(rng.integers(0, nclass))
+                    preds.append({"bbox": (int(x1 + d[0]), int(y1 + d[1]), int(x1 + w + d[2]), int(y1 + h + d[3])),
+                                  "conf": float(rng.uniform(0.05, 0.99)), "cls_class": pc})
+            for _ in range(int(rng.integers(0, extra + 1))):
+                x1, y1 = rng.integers(0, 500, 2)
+                preds.append({"bbox": (int(x1), int(y1), int(x1 + 40), int(y1 + 40)), "conf": float(rng.uniform(0.01, 0.6)),
+                              "cls_class": int(rng.integers(-1, nclass))})
+            preds_all.append(preds)
+            gts_all.append(gts)
+        m = ref.evaluate_predictions(preds_all, gts_all, nclass, 0.45)
+        flat_p = [(j, *p["bbox"], p["conf"], p["cls_class"]) for j, ps in enumerate(preds_all) for p in ps]
+        flat_g = [(j, *g) for j, gs in enumerate(gts_all) for g in gs]
+        cases[f"c{i}_preds"] = np.array(flat_p, np.float64).reshape(-1, 7)
+        cases[f"c{i}_gts"] = np.array(flat_g, np.int64).reshape(-1, 6)
+        cases[f"c{i}_nimg_nclass"] = np.array([nimg, nclass], np.int64)
+        for k in ("precision", "recall", "f1", "tp", "fp", "fn", "ap50_per_class"):
+            cases[f"c{i}_{k}"] = np.asarray(m[k], np.float64)
+        cases[f"c{i}_map"] = np.array([m["mAP50"], m["mAP50_95"]], np.float64)
+        cases[f"c{i}_present"] = np.asarray(m["classes_present"], bool)
+    np.savez_compressed(os.path.join(OUT, "ref_evaluate.npz"), **cases)
+    print("evaluate:", [tuple(np.round(cases[f"c{j}_map"], 3)) for j in range(4)])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -208,6 +248,7 @@ def main():
     gen_nms(ref, rng)
     gen_postprocess(ref, rng)
     gen_pipeline(ref, rng)
+    gen_evaluate(ref, np.random.default_rng(99))
 
 
 if __name__ == "__main__":

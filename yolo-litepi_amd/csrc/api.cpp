@@ -550,7 +550,7 @@ int lp_test_conv(lp_handle* h, int impl, const float* x, int N, int Cin, int H, 
     if (bias) bp[o] = bias[o];
   }
   ConvLayer L;
-  L.build(prec, impl, k, stride, Cin, Cout, act, wp, bp, Ho, Wo);
+  L.build(prec, impl, k, stride, Cin, Cout, act, wp, bp, Ho, Wo, N);
   auto to_dev = [&](const float* src, int C, int HH, int WW, DevBuf& d) {
     const size_t npix = (size_t)N * HH * WW;
     std::vector<uint8_t> buf(npix * C * es);

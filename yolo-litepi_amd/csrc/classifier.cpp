@@ -5,6 +5,7 @@
 // last pointwise conv (conv_kernels.hip, EPI_SHUFFLE), which also copies the pass-through half.
 #include "classifier.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace lp {
@@ -35,7 +36,7 @@ int Classifier::add_pw(const std::string& name, const std::vector<float>& w, con
                        int cout, int act, int hw) {
   pws_.emplace_back(new ConvLayer());
   pws_.back()->name = name;
-  pws_.back()->build(prec_, impl_, 1, 1, cin, cout, act, w, b, hw, hw);
+  pws_.back()->build(prec_, impl_, 1, 1, cin, cout, act, w, b, hw, hw, std::min(maxR_, 512));
   return (int)pws_.size() - 1;
 }
 

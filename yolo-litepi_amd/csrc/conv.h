@@ -25,9 +25,10 @@ struct ConvLayer {
   double macs_per_pixel() const { return (double)k * k * Cin * Cout; }
 
   // w_phys: fp32 [Cout][k*k][Cin] over PHYSICAL channels (zeros at padding channels);
-  // bias_phys: fp32 [Cout] or empty.  hout/wout: output map size (picks the 3x3 tile shape).
+  // bias_phys: fp32 [Cout] or empty.  hout/wout: output map size and batch_hint: images (or ROIs)
+  // per call at capacity -- together they pick the tile shape and the channel split.
   void build(int prec, int impl, int k, int stride, int cin, int cout, int act,
-             const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout);
+             const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout, int batch_hint);
   void launch(const ConvIO& io, hipStream_t st) const;
 };
 

@@ -147,19 +147,44 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
   const T* in = reinterpret_cast<const T*>(a.in);
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     if (chunk) __syncthreads();
-    // weights of this (channel split, chunk): already in fragment order, 16 B per lane
+    // Stage this chunk: weight fragments (already in fragment order, 16 B per lane) and the
+    // halo'd input tile (zero outside the image = the conv's zero padding).  Loads are issued in
+    // groups of 8 per thread before any LDS store, so a block pays one or two memory round trips
+    // instead of one per element (these layers are latency-bound: one tile per block).
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + ((size_t)(ns * a.nchunks + chunk) * Sc * NT) * 64;
-    for (int i = tid; i < Sc * NT * 64; i += nthr) lds_w[i] = wsrc[i];
-    // halo'd input tile, zero outside the image (= the conv's zero padding)
+    const int nW = Sc * NT * 64, nI = IH * IW * CGc;
     const int cbase = chunk * a.CK;
-    for (int i = tid; i < IH * IW * CGc; i += nthr) {
-      const int pix = i / CGc, cg = i - pix * CGc;
-      const int iy = pix / IW, ix = pix - iy * IW;
-      const int gy = iy0 + iy, gx = ix0 + ix;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
-        v = *reinterpret_cast<const u32x4*>(in + ((long)(n * a.Hin + gy) * a.Win + gx) * a.in_pitch + cbase + cg * G);
-      *reinterpret_cast<u32x4*>(lds_in + (iy * LW + ix) * PS + cg * 16) = v;
+    for (int r0 = 0; r0 < nW || r0 < nI; r0 += nthr * 8) {
+      u32x4 wv[8], iv[8];
+      int ioff[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = r0 + u * nthr + tid;
+        wv[u] = u32x4{0u, 0u, 0u, 0u};
+        if (i < nW) wv[u] = wsrc[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = r0 + u * nthr + tid;
+        iv[u] = u32x4{0u, 0u, 0u, 0u};
+        ioff[u] = -1;
+        if (i < nI) {
+          const int pix = i / CGc, cg = i - pix * CGc;
+          const int iy = pix / IW, ix = pix - iy * IW;
+          const int gy = iy0 + iy, gx = ix0 + ix;
+          ioff[u] = (iy * LW + ix) * PS + cg * 16;
+          if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
+            iv[u] = *reinterpret_cast<const u32x4*>(in + ((long)(n * a.Hin + gy) * a.Win + gx) * a.in_pitch + cbase + cg * G);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = r0 + u * nthr + tid;
+        if (i < nW) lds_w[i] = wv[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (ioff[u] >= 0) *reinterpret_cast<u32x4*>(lds_in + ioff[u]) = iv[u];
     }
     __syncthreads();
     for (int s = 0; s < Sc; ++s) {
@@ -213,13 +238,14 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
   const int S = a.steps;
   const int CG = a.Cin / G;
 
+  const long M = a.m_dyn ? (long)(*a.m_dyn) * a.pix_per_item : (long)a.M;
+  const long ntiles = (M + 64 * NP - 1) / (64 * NP);
+  if ((long)blockIdx.x >= ntiles) return;  // grid is sized for the capacity; idle blocks must not stage weights
+
   u32x4* lds_w = reinterpret_cast<u32x4*>(smem);
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)ns * S * NT * 64;
   for (int i = tid; i < S * NT * 64; i += 256) lds_w[i] = wsrc[i];
   __syncthreads();
-
-  const long M = a.m_dyn ? (long)(*a.m_dyn) * a.pix_per_item : (long)a.M;
-  const long ntiles = (M + 64 * NP - 1) / (64 * NP);
   const T* in = reinterpret_cast<const T*>(a.in);
 
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -377,7 +403,7 @@ static void put_elem(std::vector<uint8_t>& buf, size_t idx, int prec, float v) {
 }
 
 void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int cout, int act_,
-                      const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout) {
+                      const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout, int batch_hint) {
   prec = prec_; impl = impl_; k = k_; stride = stride_; Cin = cin; Cout = cout; act = act_;
   LP_CHECK(k == 1 || k == 3, LP_ERR_GRAPH, "conv kernel size %d unsupported", k);
   LP_CHECK(Cin % 8 == 0 && Cout % 8 == 0, LP_ERR_GRAPH, "physical channels must be multiples of 8");
@@ -400,30 +426,52 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     return;
   }
 
-  // channel tiles per block
-  NT = tiles_total >= 4 ? 4 : tiles_total;
-  if (tiles_total % 4 != 0 && tiles_total > 4) NT = (tiles_total % 3 == 0) ? 3 : 4;
-  nsplits = ceil_div(tiles_total, NT);
+  // channel tiles per block: 4 when the layer has plenty of pixel tiles; fewer (more channel
+  // splits -> more workgroups) when the map is small, so that ~2 workgroups per CU exist
+  auto pick_nt = [&](long pixel_blocks) {
+    int nt = tiles_total >= 4 ? 4 : tiles_total;
+    if (tiles_total % 4 != 0 && tiles_total > 4) nt = (tiles_total % 3 == 0) ? 3 : 4;
+    while (nt > 1 && pixel_blocks * ceil_div(tiles_total, nt) < 512) nt = (nt == 4 && tiles_total % 4 == 0) ? 2 : nt - 1;
+    return nt;
+  };
+  const int B = batch_hint > 0 ? batch_hint : 1;
 
   if (k == 3) {
-    // K chunking: largest CK (multiple of 8, divides Cin) whose LDS footprint fits the budget
+    // Tile shape (bwh x bww waves of 4x20 pixels) and K chunk CK (multiple of 8, divides Cin):
+    // the halo'd input tile plus the chunk's weight fragments must fit the LDS budget (two
+    // workgroups per CU).  Priority: no idle lanes on this map, >= 16-channel chunks, then the
+    // largest workgroup (weights are staged once per workgroup), then the largest chunk.
     const bool small_map = (hout <= 20 && wout <= 20);
-    bwh = small_map ? 5 : 2;
-    bww = small_map ? 1 : 2;
-    const int TH = 4 * bwh, TW = 20 * bww;
-    const int IH = (TH - 1) * stride + 3, IW = (TW - 1) * stride + 3;
-    LW = IW;
-    while (!(LW % 16 == 4 || LW % 16 == 12)) ++LW;
-    const size_t budget = 64 * 1024;
-    int best = 8;
-    for (int ck = 8; ck <= Cin && ck <= 64; ck += 8) {
-      if (Cin % ck) continue;
-      const int cgc = ck / G;
-      const int ps = ((cgc % 2 == 0) ? cgc + 1 : cgc + 2) * 16;
-      const size_t lds = (size_t)ceil_div(taps * cgc, 4) * NT * 1024 + (size_t)IH * LW * ps;
-      if (lds <= budget) best = ck;
+    const int cand[6][2] = {{5, 1}, {2, 2}, {2, 1}, {1, 2}, {4, 1}, {1, 1}};
+    const size_t budget = 80 * 1024;
+    long best_score = -1;
+    CK = 8; bwh = 1; bww = 1; LW = 0; NT = 1;
+    for (int ci = 0; ci < 6; ++ci) {
+      const int h = cand[ci][0], w = cand[ci][1];
+      if (!small_map && (h == 5 || h == 4)) continue;
+      const int TH = 4 * h, TW = 20 * w;
+      const int IH = (TH - 1) * stride + 3, IW = (TW - 1) * stride + 3;
+      int lw = IW;
+      while (!(lw % 16 == 4 || lw % 16 == 12)) ++lw;
+      const int tiles = ceil_div(hout, TH) * ceil_div(wout, TW);
+      const int nt = pick_nt((long)tiles * B);
+      int ck_fit = 0;
+      for (int ck = 8; ck <= Cin && ck <= 32; ck += 8) {
+        if (Cin % ck) continue;
+        const int cgc = ck / G;
+        const int ps = ((cgc % 2 == 0) ? cgc + 1 : cgc + 2) * 16;
+        const size_t lds = (size_t)ceil_div(taps * cgc, 4) * nt * 1024 + (size_t)IH * lw * ps;
+        if (lds <= budget) ck_fit = ck;
+      }
+      if (!ck_fit) continue;
+      const int util = (int)(100.0 * hout * wout / ((double)tiles * TH * TW));
+      const long score = (util >= 95 ? 3 : util >= 80 ? 2 : util >= 60 ? 1 : 0) * 100000L +
+                         ((ck_fit >= 16 || ck_fit == Cin) ? 10000L : 0L) + (long)h * w * 1000L + ck_fit;
+      if (score > best_score) { best_score = score; CK = ck_fit; bwh = h; bww = w; LW = lw; NT = nt; }
     }
-    CK = best;
+    LP_CHECK(best_score >= 0, LP_ERR_GRAPH, "conv3x3 %d->%d: no tile fits LDS", Cin, Cout);
+    nsplits = ceil_div(tiles_total, NT);
+    const int IH = (4 * bwh - 1) * stride + 3;
     CGc = CK / G;
     PS = ((CGc % 2 == 0) ? CGc + 1 : CGc + 2) * 16;
     nchunks = Cin / CK;
@@ -431,6 +479,7 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     lds_bytes = (size_t)steps * NT * 1024 + (size_t)IH * LW * PS;
     LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv3x3 tile does not fit LDS (%zu B)", lds_bytes);
   } else {
+    NT = pick_nt(ceil_div((long)B * hout * wout, 256));
     CK = Cin;
     CGc = Cin / G;
     nchunks = 1;

@@ -383,7 +383,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         }
         convs_.emplace_back(new ConvLayer());
         convs_.back()->name = l.name;
-        convs_.back()->build(prec_, impl_, k, s, TI.Cp, TO.Cp, fused_act[i], w, b, TO.H, TO.W);
+        convs_.back()->build(prec_, impl_, k, s, TI.Cp, TO.Cp, fused_act[i], w, b, TO.H, TO.W, maxB_);
         op.kind = DetOp::CONV;
         op.conv = (int)convs_.size() - 1;
       }

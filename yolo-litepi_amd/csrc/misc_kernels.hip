@@ -153,9 +153,69 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const T* __restrict__ in
   *reinterpret_cast<vec*>(o3 + pix * p3 + cg * G) = m13;
 }
 
+// LDS version for maps up to 40x40: one workgroup per (image, 16-byte channel group); each 5x5
+// pool is separable (row max, then column max), cascaded three times in place.
+#define SPPF_MAX_PIX 1600
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(const T* __restrict__ in, T* __restrict__ o1, T* __restrict__ o2,
+                                                            T* __restrict__ o3, int H, int W, int CG, int in_pitch, int p1,
+                                                            int p2, int p3) {
+  typedef typename VecT<T>::type vec;
+  constexpr int G = VecT<T>::G;
+  __shared__ vec A[SPPF_MAX_PIX];
+  __shared__ vec B[SPPF_MAX_PIX];
+  const int cg = blockIdx.x % CG, n = blockIdx.x / CG;
+  const int HW = H * W, tid = threadIdx.x;
+  const long base = (long)n * HW;
+  for (int p = tid; p < HW; p += 256) A[p] = *reinterpret_cast<const vec*>(in + (base + p) * in_pitch + cg * G);
+  __syncthreads();
+  T* outs[3] = {o1, o2, o3};
+  const int pitches[3] = {p1, p2, p3};
+  for (int stage = 0; stage < 3; ++stage) {
+    for (int p = tid; p < HW; p += 256) {
+      const int y = p / W, x = p - y * W;
+      vec m = A[p];
+      for (int d = -2; d <= 2; ++d) {
+        const int xx = x + d;
+        if (d == 0 || xx < 0 || xx >= W) continue;
+        const vec v = A[y * W + xx];
+#pragma unroll
+        for (int i = 0; i < G; ++i) m[i] = v[i] > m[i] ? v[i] : m[i];
+      }
+      B[p] = m;
+    }
+    __syncthreads();
+    for (int p = tid; p < HW; p += 256) {
+      const int y = p / W, x = p - y * W;
+      vec m = B[p];
+      for (int d = -2; d <= 2; ++d) {
+        const int yy = y + d;
+        if (d == 0 || yy < 0 || yy >= H) continue;
+        const vec v = B[yy * W + x];
+#pragma unroll
+        for (int i = 0; i < G; ++i) m[i] = v[i] > m[i] ? v[i] : m[i];
+      }
+      A[p] = m;
+      *reinterpret_cast<vec*>(outs[stage] + (base + p) * pitches[stage] + cg * G) = m;
+    }
+    __syncthreads();
+  }
+}
+
 void launch_sppf_pool(int prec, const View& in, const View& o1, const View& o2, const View& o3, int N, hipStream_t st) {
   const int G = prec == LP_FP16 ? 8 : 4;
   const int CG = in.C / G;
+  if (in.H * in.W <= SPPF_MAX_PIX) {
+    dim3 grid((unsigned)(N * CG));
+    if (prec == LP_FP16)
+      hipLaunchKernelGGL(sppf_pool_lds_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)o1.base,
+                         (half_t*)o2.base, (half_t*)o3.base, in.H, in.W, CG, in.pitch, o1.pitch, o2.pitch, o3.pitch);
+    else
+      hipLaunchKernelGGL(sppf_pool_lds_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)o1.base,
+                         (float*)o2.base, (float*)o3.base, in.H, in.W, CG, in.pitch, o1.pitch, o2.pitch, o3.pitch);
+    LP_HIP(hipGetLastError());
+    return;
+  }
   const long total = (long)N * in.H * in.W * CG;
   dim3 grid((unsigned)((total + 255) / 256));
   if (prec == LP_FP16)

@@ -38,41 +38,65 @@ __device__ __forceinline__ void emit_candidate(float cx, float cy, float w, floa
 // each box side, expectation with the DFL weights, dist2bbox around the anchor point,
 // x stride; class sigmoid.  One thread per (image, anchor).
 // ------------------------------------------------------------------------------------
-template <typename T>
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct DecVec;
+template <> struct DecVec<half_t> { typedef half8_t type; static constexpr int G = 8; };
+template <> struct DecVec<float> { typedef float4_t type; static constexpr int G = 4; };
+template <typename T> __device__ __forceinline__ float dec_exp(float x);
+template <> __device__ __forceinline__ float dec_exp<half_t>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ float dec_exp<float>(float x) { return expf(x); }
+
+// Four adjacent lanes share one anchor, one box side each: a wave reads 16 anchors x 4*reg_max
+// channels = fully coalesced 16-byte loads.  The side-0 lane then gathers the four distances
+// with wave shuffles and finishes the anchor.
+template <typename T, int RM>
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+  typedef typename DecVec<T>::type vec;
+  constexpr int G = DecVec<T>::G;
   const int n = blockIdx.y;
-  const int anchor = blockIdx.x * 256 + threadIdx.x;
-  if (anchor >= a.A) return;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  int anchor = gid >> 2;
+  const int side = gid & 3;
+  const bool live = anchor < a.A;
+  anchor = live ? anchor : a.A - 1;
   int l = 0;
   for (int i = 1; i < a.nlevels; ++i)
     if (anchor >= a.lv[i].anchor_off) l = i;
   const DecodeLevel lv = a.lv[l];
   const long pix = (long)n * lv.H * lv.W + (anchor - lv.anchor_off);
-  const T* box = reinterpret_cast<const T*>(lv.box) + pix * lv.box_pitch;
-  const T* cls = reinterpret_cast<const T*>(lv.cls) + pix * lv.cls_pitch;
-  float d[4];
+  const T* b = reinterpret_cast<const T*>(lv.box) + pix * lv.box_pitch + side * RM;
+  float v[RM];
 #pragma unroll
-  for (int side = 0; side < 4; ++side) {
-    const T* b = box + side * a.reg_max;
-    float mx = -INFINITY;
-    for (int i = 0; i < a.reg_max; ++i) mx = fmaxf(mx, (float)b[i]);
-    float sum = 0.f, ex = 0.f;
-    for (int i = 0; i < a.reg_max; ++i) {
-      const float e = expf((float)b[i] - mx);
-      sum += e;
-      ex += e * a.dfl_w[i];
-    }
-    d[side] = ex / sum;
+  for (int q = 0; q < RM / G; ++q) {
+    const vec x = *reinterpret_cast<const vec*>(b + q * G);
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[q * G + i] = (float)x[i];
   }
+  float mx = v[0];
+#pragma unroll
+  for (int i = 1; i < RM; ++i) mx = fmaxf(mx, v[i]);
+  float sum = 0.f, ex = 0.f;
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    const float e = dec_exp<T>(v[i] - mx);
+    sum += e;
+    ex += e * a.dfl_w[i];
+  }
+  const float dist = ex / sum;
+  const int lane = threadIdx.x & 63, base = lane & ~3;
+  const float d0 = __shfl(dist, base), d1 = __shfl(dist, base + 1), d2 = __shfl(dist, base + 2), d3 = __shfl(dist, base + 3);
+  if (side != 0 || !live) return;
+  const T* cls = reinterpret_cast<const T*>(lv.cls) + pix * lv.cls_pitch;
   const float ax = a.anchors[anchor], ay = a.anchors[a.A + anchor], s = a.strides[anchor];
-  const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+  const float x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3;
   const float cx = (x1 + x2) * 0.5f * s, cy = (y1 + y2) * 0.5f * s;
   const float w = (x2 - x1) * s, h = (y2 - y1) * s;
   float best = -1.f;
   int best_c = 0;
   float* o = a.out0 ? a.out0 + (long)n * (4 + a.nc) * a.A + anchor : nullptr;
   for (int c = 0; c < a.nc; ++c) {
-    const float sc = 1.f / (1.f + expf(-(float)cls[c]));
+    const float sc = 1.f / (1.f + dec_exp<T>(-(float)cls[c]));
     if (o) o[(long)(4 + c) * a.A] = sc;
     if (sc > best) { best = sc; best_c = c; }
   }
@@ -83,11 +107,14 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
 }
 
 void launch_decode(int prec, const DecodeArgs& a, int N, hipStream_t st) {
-  dim3 grid(ceil_div(a.A, 256), N);
-  if (prec == LP_FP16)
-    hipLaunchKernelGGL(decode_kernel<half_t>, grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(decode_kernel<float>, grid, dim3(256), 0, st, a);
+  dim3 grid(ceil_div(a.A * 4, 256), N);
+  LP_CHECK(a.reg_max == 16 || a.reg_max == 8 || a.reg_max == 32, LP_ERR_GRAPH, "reg_max %d unsupported (8, 16, 32)", a.reg_max);
+#define LP_DEC(TT)                                                                           \
+  if (a.reg_max == 16) hipLaunchKernelGGL((decode_kernel<TT, 16>), grid, dim3(256), 0, st, a); \
+  else if (a.reg_max == 8) hipLaunchKernelGGL((decode_kernel<TT, 8>), grid, dim3(256), 0, st, a); \
+  else hipLaunchKernelGGL((decode_kernel<TT, 32>), grid, dim3(256), 0, st, a);
+  if (prec == LP_FP16) { LP_DEC(half_t) } else { LP_DEC(float) }
+#undef LP_DEC
   LP_HIP(hipGetLastError());
 }
 
@@ -306,13 +333,16 @@ void launch_roi_index(const int* counts, const RoiTable& t, int N, int max_det, 
 // Pinned against Pillow itself through oracle/pil_resize_ref.py.
 // ------------------------------------------------------------------------------------
 #define RR_THREADS 256
-#define RR_MAXK 129           /* ceil(support)*2+1 for crops up to 4096 px per side */
 #define RR_PRECISION_BITS 22
+// "small" variant: ROI sides <= 256 px (support <= 4 -> at most 9 taps); the whole
+// horizontally-resampled crop [in_h][S][3] lives in LDS, so a ROI costs two barriers.
+// "large" variant: sides up to 4096 px (129 taps), one output row at a time.
+#define RR_SMALL_SIDE 256
+#define RR_SMALL_K 9
+#define RR_LARGE_K 129
 
-size_t roi_resize_lds_bytes() {
-  // kx, ky: [64][RR_MAXK] int ; bounds: 4*64 int ; tmp rows: RR_MAXK*64*3 bytes
-  return (size_t)2 * 64 * RR_MAXK * 4 + 4 * 64 * 4 + (size_t)RR_MAXK * 64 * 3 + 64;
-}
+size_t roi_resize_lds_bytes() { return (size_t)2 * 64 * RR_LARGE_K * 4 + 4 * 64 * 4 + (size_t)RR_LARGE_K * 64 * 3 + 64; }
+static size_t roi_resize_small_lds() { return (size_t)2 * 64 * RR_SMALL_K * 4 + 4 * 64 * 4 + (size_t)RR_SMALL_SIDE * 64 * 3 + 64; }
 
 __device__ void pil_coeffs(int in_size, int out_size, int xx, int* k, int* xmin_out, int* n_out) {
   const double scale = (double)in_size / (double)out_size;
@@ -347,73 +377,120 @@ __device__ __forceinline__ uint8_t clip8(int v) {
   return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+template <int MAXK, bool SMALL>
 __global__ __launch_bounds__(RR_THREADS) void roi_resize_kernel(const RoiResizeArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = a.S;
   int* kx = reinterpret_cast<int*>(smem);
-  int* ky = kx + 64 * RR_MAXK;
-  int* bx = ky + 64 * RR_MAXK;  // [S][2]
+  int* ky = kx + 64 * MAXK;
+  int* bx = ky + 64 * MAXK;  // [S][2]
   int* by = bx + 2 * 64;
   uint8_t* tmp = reinterpret_cast<uint8_t*>(by + 2 * 64);  // [rows][S][3]
   const int tid = threadIdx.x;
   const int R = a.tab.total[0];
+  const int half = 1 << (RR_PRECISION_BITS - 1);
   for (int r = blockIdx.x; r < R; r += gridDim.x) {
     const int img = a.tab.img[r], slot = a.tab.slot[r];
     const ImgGeom gm = a.geom[img];
     const int* rc = a.rects + ((long)img * a.max_det + slot) * 4;
     const int rx = rc[0], ry = rc[1];
-    int in_w = rc[2] - rx, in_h = rc[3] - ry;
+    const int in_w = rc[2] - rx, in_h = rc[3] - ry;
+    const bool small = in_w <= RR_SMALL_SIDE && in_h <= RR_SMALL_SIDE;
+    if (small != SMALL) continue;  // block-uniform: the other variant owns this ROI
     const uint8_t* src = a.src + gm.src_off;
     uint8_t* out = a.out + (long)r * S * S * 3;
+    if (in_w > 4096 || in_h > 4096) {  // beyond the tap budget: defined (zero) output instead of garbage
+      for (int i = tid; i < S * S * 3; i += RR_THREADS) out[i] = 0;
+      continue;
+    }
     __syncthreads();
     if (tid < S)
-      pil_coeffs(in_w, S, tid, kx + tid * RR_MAXK, bx + 2 * tid, bx + 2 * tid + 1);
+      pil_coeffs(in_w, S, tid, kx + tid * MAXK, bx + 2 * tid, bx + 2 * tid + 1);
     else if (tid >= 64 && tid < 64 + S)
-      pil_coeffs(in_h, S, tid - 64, ky + (tid - 64) * RR_MAXK, by + 2 * (tid - 64), by + 2 * (tid - 64) + 1);
+      pil_coeffs(in_h, S, tid - 64, ky + (tid - 64) * MAXK, by + 2 * (tid - 64), by + 2 * (tid - 64) + 1);
     __syncthreads();
-    const int half = 1 << (RR_PRECISION_BITS - 1);
-    for (int yy = 0; yy < S; ++yy) {
-      const int ymin = by[2 * yy], ny = by[2 * yy + 1];
-      // horizontal pass of the ny source rows this output row needs
-      for (int i = tid; i < ny * S * 3; i += RR_THREADS) {
+    if (SMALL) {
+      // horizontal pass of every source row into LDS (uint8, as Pillow's intermediate image)
+      for (int i = tid; i < in_h * S * 3; i += RR_THREADS) {
         const int c = i % 3, xx = (i / 3) % S, row = i / (3 * S);
         const int xmin = bx[2 * xx], nx = bx[2 * xx + 1];
-        const uint8_t* p = src + ((long)(ry + ymin + row) * gm.w + rx + xmin) * 3 + (2 - c);  // BGR -> RGB
+        const uint8_t* p = src + ((long)(ry + row) * gm.w + rx + xmin) * 3 + (2 - c);  // BGR -> RGB
         uint8_t v;
         if (in_w == S) {
           v = p[0];  // Pillow skips the pass when the width already matches (identity either way)
         } else {
-          const int* k = kx + xx * RR_MAXK;
+          const int* k = kx + xx * MAXK;
           int acc = half;
-          for (int x = 0; x < nx; ++x) acc += (int)p[x * 3] * k[x];
+#pragma unroll
+          for (int x = 0; x < MAXK; ++x) {  // fixed trip count: every tap's byte load is in flight at once
+            const int xi = x < nx ? x : nx - 1;
+            acc += (int)p[xi * 3] * (x < nx ? k[x] : 0);
+          }
           v = clip8(acc);
         }
         tmp[i] = v;
       }
       __syncthreads();
-      for (int i = tid; i < S * 3; i += RR_THREADS) {
+      for (int i = tid; i < S * S * 3; i += RR_THREADS) {
+        const int yy = i / (S * 3), j = i - yy * S * 3;
+        const int ymin = by[2 * yy], ny = by[2 * yy + 1];
         uint8_t v;
         if (in_h == S) {
-          v = tmp[i];
+          v = tmp[(ymin)*S * 3 + j];
         } else {
-          const int* k = ky + yy * RR_MAXK;
+          const int* k = ky + yy * MAXK;
           int acc = half;
-          for (int y = 0; y < ny; ++y) acc += (int)tmp[y * S * 3 + i] * k[y];
+          for (int y = 0; y < ny; ++y) acc += (int)tmp[(ymin + y) * S * 3 + j] * k[y];
           v = clip8(acc);
         }
-        out[yy * S * 3 + i] = v;
+        out[i] = v;
       }
-      __syncthreads();
+    } else {
+      for (int yy = 0; yy < S; ++yy) {
+        const int ymin = by[2 * yy], ny = by[2 * yy + 1];
+        for (int i = tid; i < ny * S * 3; i += RR_THREADS) {
+          const int c = i % 3, xx = (i / 3) % S, row = i / (3 * S);
+          const int xmin = bx[2 * xx], nx = bx[2 * xx + 1];
+          const uint8_t* p = src + ((long)(ry + ymin + row) * gm.w + rx + xmin) * 3 + (2 - c);
+          uint8_t v;
+          if (in_w == S) {
+            v = p[0];
+          } else {
+            const int* k = kx + xx * MAXK;
+            int acc = half;
+            for (int x = 0; x < nx; ++x) acc += (int)p[x * 3] * k[x];
+            v = clip8(acc);
+          }
+          tmp[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < S * 3; i += RR_THREADS) {
+          uint8_t v;
+          if (in_h == S) {
+            v = tmp[i];
+          } else {
+            const int* k = ky + yy * MAXK;
+            int acc = half;
+            for (int y = 0; y < ny; ++y) acc += (int)tmp[y * S * 3 + i] * k[y];
+            v = clip8(acc);
+          }
+          out[yy * S * 3 + i] = v;
+        }
+        __syncthreads();
+      }
     }
   }
 }
 
 void launch_roi_resize(const RoiResizeArgs& a, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel<RR_LARGE_K, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel<RR_SMALL_K, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
   (void)once;
   LP_CHECK(a.S <= 64, LP_ERR_ARG, "classifier input larger than 64 unsupported by the resize kernel");
-  hipLaunchKernelGGL(roi_resize_kernel, dim3(512), dim3(RR_THREADS), roi_resize_lds_bytes(), st, a);
+  hipLaunchKernelGGL((roi_resize_kernel<RR_SMALL_K, true>), dim3(1024), dim3(RR_THREADS), roi_resize_small_lds(), st, a);
+  hipLaunchKernelGGL((roi_resize_kernel<RR_LARGE_K, false>), dim3(256), dim3(RR_THREADS), roi_resize_lds_bytes(), st, a);
   LP_HIP(hipGetLastError());
 }
 

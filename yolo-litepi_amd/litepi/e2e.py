@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""End-to-end evaluation CLI with the argument surface of the reference's
+``src/tt100k/pipeline/e2e.py`` (flags and defaults: e2e.py:1017-1048), running on the HIP
+backend.  Same two passes per image (benchmark pass at ``--benchmark_conf`` whose time feeds the
+FPS figure, evaluation pass at ``--yolo_conf`` that feeds mAP; e2e.py:955-1011), same
+Ultralytics-style metric (e2e.py:656-824) and the same appended ``comparison_summary.csv`` schema
+(e2e.py:1166-1184).  New flags: ``--batch_images``, ``--precision``, ``--hip_device``.
+
+Differences, on purpose: images are decoded with Pillow (cv2 is not a dependency);
+``--detector_threads`` and ``--device`` are accepted and ignored (everything runs on the GPU);
+only ``--clf_arch shufflenetv2`` is accelerated; ``--save_viz`` is accepted and ignored.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="E2E HIP (MI355X) detector + classifier evaluation pipeline")
+    p.add_argument("--detector_param", type=str, default="../convert/model/yolo_plus/yolo_plus_ncnn_model/model.ncnn.param")
+    p.add_argument("--detector_bin", type=str, default="../convert/model/yolo_plus/yolo_plus_ncnn_model/model.ncnn.bin")
+    p.add_argument("--classifier", type=str, default="../weight/shufflenetv2.pth")
+    p.add_argument("--clf_arch", type=str, choices=["resnet18", "efficientnet", "mobilenetv2", "shufflenetv2"], default="shufflenetv2")
+    p.add_argument("--input", type=str, default="../Dataset/E2E/data_e2e_tt100k/images/test")
+    p.add_argument("--labels", type=str, default="../Dataset/E2E/data_e2e_tt100k/labels/test")
+    p.add_argument("--classes", type=str, default="../Dataset/E2E/data_e2e_tt100k/idx2label.json")
+    p.add_argument("--num_samples", type=int, default=None)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--yolo_conf", type=float, default=0.001)
+    p.add_argument("--benchmark_conf", type=float, default=0.25)
+    p.add_argument("--min_area", type=int, default=50)
+    p.add_argument("--iou_threshold", type=float, default=0.45)
+    p.add_argument("--det_input_size", type=int, default=640)
+    p.add_argument("--cls_input_size", type=int, default=64)
+    p.add_argument("--detector_threads", type=int, default=4, help="ignored (NCNN threads in the reference)")
+    p.add_argument("--batch_size", type=int, default=8, help="kept for compatibility: all ROIs of a call are classified together")
+    p.add_argument("--device", type=str, choices=["cpu", "cuda", "hip"], default="hip", help="ignored: always the HIP device")
+    p.add_argument("--output", type=str, default="output_eval")
+    p.add_argument("--save_viz", default=False, help="accepted and ignored")
+    # new
+    p.add_argument("--batch_images", type=int, default=1, help="images per GPU call")
+    p.add_argument("--precision", type=str, choices=["fp16", "fp32"], default="fp16")
+    p.add_argument("--hip_device", type=int, default=0)
+    p.add_argument("--max_det", type=int, default=300, help="detections kept per image (the reference keeps all)")
+    return p
+
+
+def load_class_names(path: str) -> List[str]:
+    """JSON {"idx": "name"} or one name per line (e2e.py:160-176)."""
+    with open(path, "r") as f:
+        text = f.read()
+    try:
+        data = json.loads(text)
+    except json.JSONDecodeError:
+        return [ln.strip() for ln in text.splitlines() if ln.strip()]
+    if not isinstance(data, dict):
+        raise ValueError("JSON must be a dictionary")
+    names = [""] * (max(int(k) for k in data) + 1)
+    for k, v in data.items():
+        names[int(k)] = v
+    return names
+
+
+def parse_yolo_label(label_path, img_w: int, img_h: int) -> List[Tuple[int, int, int, int, int]]:
+    """``cls xc yc w h`` normalised -> (cls, x1, y1, x2, y2) int pixels (e2e.py:137-157)."""
+    if not os.path.exists(label_path):
+        return []
+    out = []
+    with open(label_path) as f:
+        for line in f:
+            t = line.split()
+            if len(t) < 5:
+                continue
+            xc, yc, w, h = (float(v) for v in t[1:5])
+            out.append((int(t[0]), int((xc - w / 2) * img_w), int((yc - h / 2) * img_h), int((xc + w / 2) * img_w),
+                        int((yc + h / 2) * img_h)))
+    return out
+
+
+def sample_images(files: Sequence, num_samples: Optional[int], seed: int = 42):
+    """Deterministic subset (e2e.py:179-186)."""
+    if num_samples is None or num_samples <= 0 or num_samples >= len(files):
+        return list(files)
+    random.seed(seed)
+    return sorted(random.sample(list(files), num_samples))
+
+
+def read_image_bgr(path) -> Optional[np.ndarray]:
+    from PIL import Image
+    try:
+        with Image.open(path) as im:
+            return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
+    except Exception:  # noqa: BLE001 - unreadable image -> skipped, like cv2.imread returning None
+        return None
+
+
+# ------------------------------------------------------------------------------------------------
+def _pairwise_iou(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = np.maximum(a[:, None, :2], b[:, :2])
+    rb = np.minimum(a[:, None, 2:], b[:, 2:])
+    wh = (rb - lt).clip(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (area_a[:, None] + area_b - inter + 1e-7)
+
+
+def _ap101(recall: np.ndarray, precision: np.ndarray) -> float:
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([1.0], precision, [0.0]))
+    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))
+    x = np.linspace(0, 1, 101)
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+    return float(trapz(np.interp(x, mrec, mpre), x))
+
+
+def evaluate_predictions(all_preds, all_gts, num_classes, iou_threshold=0.5, iou_thresholds=np.arange(0.5, 1.0, 0.05)) -> Dict:
+    """Ultralytics-style global evaluation with the semantics of the reference (e2e.py:656-824):
+    per IoU threshold, matches are ranked by IoU, de-duplicated per prediction then per ground
+    truth, and count only when the CLASSIFIER class equals the label; predictions are ranked
+    globally by detector confidence; AP is the 101-point interpolated area; the means run over the
+    classes present in the ground truth.  ``iou_threshold`` is unused, as in the reference."""
+    nt = len(iou_thresholds)
+    stats = []
+    for preds, gts in zip(all_preds, all_gts):
+        if len(preds) == 0:
+            if len(gts) > 0:
+                stats.append((np.zeros((0, nt), bool), np.array([]), np.array([]), np.array(gts)[:, 0]))
+            continue
+        pb = np.array([p["bbox"] for p in preds])
+        pconf = np.array([p["conf"] for p in preds])
+        pcls = np.array([p["cls_class"] for p in preds])
+        correct = np.zeros((len(preds), nt), bool)
+        if len(gts) > 0:
+            g = np.array(gts)
+            tcls, tb = g[:, 0], g[:, 1:]
+            iou = _pairwise_iou(pb, tb)
+            for j, thr in enumerate(iou_thresholds):
+                pi, gi = np.where(iou >= thr)
+                if not len(pi):
+                    continue
+                m = np.concatenate((np.stack((pi, gi), 1), iou[pi, gi][:, None]), 1)
+                if len(pi) > 1:
+                    m = m[m[:, 2].argsort()[::-1]]
+                    m = m[np.unique(m[:, 0], return_index=True)[1]]
+                    m = m[np.unique(m[:, 1], return_index=True)[1]]
+                for p_i, g_i, _ in m:
+                    if pcls[int(p_i)] == tcls[int(g_i)]:
+                        correct[int(p_i), j] = True
+        else:
+            tcls = np.array([])
+        stats.append((correct, pconf, pcls, tcls))
+
+    zeros = lambda: np.zeros(num_classes)  # noqa: E731
+    if not stats:
+        return {"precision": zeros(), "recall": zeros(), "f1": zeros(), "tp": zeros(), "fp": zeros(), "fn": zeros(),
+                "mAP50": 0.0, "mAP50_95": 0.0, "classes_present": np.zeros(num_classes, dtype=bool)}
+    tp = np.concatenate([s[0] for s in stats], 0)
+    conf = np.concatenate([s[1] for s in stats], 0)
+    pcls = np.concatenate([s[2] for s in stats], 0)
+    tcls = np.concatenate([s[3] for s in stats], 0)
+    order = np.argsort(-conf)
+    tp, pcls = tp[order], pcls[order]
+    uniq, counts = np.unique(tcls, return_counts=True)
+    n_gt_of = dict(zip(uniq, counts))
+    ap50, ap5095, pbest, rbest, fbest = zeros(), zeros(), zeros(), zeros(), zeros()
+    tpc_, fpc_, fnc_ = zeros(), zeros(), zeros()
+    for c in range(num_classes):
+        n_gt = n_gt_of.get(c, 0)
+        sel = pcls == c
+        n_p = sel.sum()
+        if n_p == 0 and n_gt == 0:
+            continue
+        if n_p == 0 or n_gt == 0:
+            fnc_[c] = n_gt
+            continue
+        tpc = tp[sel].cumsum(0)
+        fpc = (1 - tp[sel]).cumsum(0)
+        rec = tpc / (n_gt + 1e-16)
+        prec = tpc / (tpc + fpc + 1e-16)
+        aps = [_ap101(rec[:, j], prec[:, j]) for j in range(tp.shape[1])]
+        ap50[c], ap5095[c] = aps[0], np.mean(aps)
+        f1 = 2 * prec[:, 0] * rec[:, 0] / (prec[:, 0] + rec[:, 0] + 1e-16)
+        b = int(np.argmax(f1))
+        pbest[c], rbest[c], fbest[c] = prec[b, 0], rec[b, 0], f1[b]
+        tpc_[c], fpc_[c] = tpc[b, 0], fpc[b, 0]
+        fnc_[c] = n_gt - tpc_[c]
+    present = uniq.astype(int)
+    return {"precision": pbest, "recall": rbest, "f1": fbest, "tp": tpc_, "fp": fpc_, "fn": fnc_,
+            "mAP50": float(np.mean(ap50[present])) if len(present) else 0.0,
+            "mAP50_95": float(np.mean(ap5095[present])) if len(present) else 0.0,
+            "ap50_per_class": ap50, "classes_present": np.isin(np.arange(num_classes), uniq)}
+
+
+# ------------------------------------------------------------------------------------------------
+def main(argv=None) -> int:
+    import pandas as pd
+
+    from .backend import HybridPipeline
+
+    args = build_parser().parse_args(argv)
+    class_names = load_class_names(args.classes)
+    num_classes = len(class_names)
+    detector_name = Path(args.detector_param).stem
+    combo = f"{detector_name}+{args.clf_arch}"
+    print(f"\n{'=' * 60}\nMODEL COMBINATION: {combo}\n{'=' * 60}")
+    nb = max(1, args.batch_images)
+    pipeline = HybridPipeline(args.detector_param, args.detector_bin, args.classifier, args.clf_arch, num_classes,
+                              args.det_input_size, args.cls_input_size, False, args.detector_threads, args.device,
+                              args.batch_size, precision=args.precision, max_batch=nb, max_det=args.max_det,
+                              device=args.hip_device)
+    out_dir = Path(args.output) / combo
+    out_dir.mkdir(parents=True, exist_ok=True)
+
+    inp = Path(args.input)
+    if inp.is_file():
+        files = [inp]
+        label_dir = Path(args.labels) if args.labels else None
+    else:
+        label_dir = Path(args.labels) if args.labels else inp / "labels"
+        files = sorted(list(inp.glob("*.jpg")) + list(inp.glob("*.png")) + list(inp.glob("*.jpeg")))
+        if args.num_samples:
+            files = sample_images(files, args.num_samples, args.seed)
+    print(f"\nFound {len(files)} images for processing")
+
+    all_preds, all_gts, bench_time = [], [], 0.0
+    for i in range(0, len(files), nb):
+        chunk, imgs = [], []
+        for f in files[i:i + nb]:
+            im = read_image_bgr(f)
+            if im is None:
+                print(f"\nSkipping {f.name}")
+                continue
+            chunk.append(f)
+            imgs.append(im)
+        if not imgs:
+            continue
+        bench = pipeline.run_batch(imgs, args.benchmark_conf, args.iou_threshold, args.min_area)
+        bench_time += sum(m.t_total for _, m in bench) / 1000.0
+        ev = bench if args.yolo_conf == args.benchmark_conf else pipeline.run_batch(imgs, args.yolo_conf, args.iou_threshold, args.min_area)
+        for f, im, (res, _) in zip(chunk, imgs, ev):
+            lp = (label_dir / f"{f.stem}.txt") if label_dir else f.parent / "labels" / f"{f.stem}.txt"
+            all_gts.append(parse_yolo_label(lp, im.shape[1], im.shape[0]))
+            all_preds.append([{"bbox": r["bbox"], "conf": r.get("det_conf", 0.0), "cls_class": r.get("cls_class", -1)} for r in res])
+
+    print("\n" + "=" * 80 + f"\nEVALUATION RESULTS - {combo}\n" + "=" * 80)
+    m = evaluate_predictions(all_preds, all_gts, num_classes, args.iou_threshold)
+    avg = bench_time / len(all_preds) if all_preds else 0.0
+    fps = 1.0 / avg if avg > 0 else 0.0
+    print(f"\nPerformance Metrics (at conf={args.benchmark_conf}):\n  Avg Inference Time: {avg * 1000:.2f} ms\n  Real FPS:           {fps:.2f} FPS")
+    print(f"\nAccuracy Metrics (at conf={args.yolo_conf}):")
+    print(f"{'Class':<20} {'Precision':>10} {'Recall':>10} {'F1':>10} {'TP':>6} {'FP':>6} {'FN':>6}\n" + "-" * 80)
+    valid = m["classes_present"]
+    for c, name in enumerate(class_names):
+        if valid[c]:
+            print(f"{name:<20} {m['precision'][c]:>10.3f} {m['recall'][c]:>10.3f} {m['f1'][c]:>10.3f} "
+                  f"{int(m['tp'][c]):>6} {int(m['fp'][c]):>6} {int(m['fn'][c]):>6}")
+    mean = lambda k: float(np.mean(m[k][valid])) if valid.any() else 0.0  # noqa: E731
+    print("-" * 80 + f"\n{'MEAN':<20} {mean('precision'):>10.3f} {mean('recall'):>10.3f} {mean('f1'):>10.3f}")
+    print(f"{'mAP@0.5':<20} {m['mAP50']:>10.3f}\n{'mAP@0.5:0.95':<20} {m['mAP50_95']:>10.3f}")
+    row = pd.DataFrame([{"model_combination": combo, "detector": detector_name, "classifier": args.clf_arch,
+                         "num_test_images": len(all_preds), "mean_precision": mean("precision"), "mean_recall": mean("recall"),
+                         "mean_f1": mean("f1"), "fps": fps, "mAP50": m["mAP50"], "mAP50-95": m["mAP50_95"]}])
+    summary = Path(args.output) / "comparison_summary.csv"
+    if summary.exists():
+        row = pd.concat([pd.read_csv(summary), row], ignore_index=True)
+    row.to_csv(summary, index=False)
+    print(f"Updated comparison summary at {summary}")
+    pipeline.engine.close()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
