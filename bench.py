@@ -96,6 +96,8 @@ def cpu_baseline(param, binf, cls_state, imgs_np, n_images):
     assert not [k for k in missing.missing_keys if "num_batches_tracked" not in k], missing
     model.eval()
     pipe = pipeline_ref.CpuPipeline(layers, model)
+    # the GPU box gives one GPU a 16-core CPU share; oneDNN at batch 1 does not scale past that
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     cores = torch.get_num_threads()
     pipe.run(imgs_np[0], CONF, IOU, MIN_AREA)  # warm-up
     t0 = time.perf_counter()
@@ -190,7 +192,7 @@ def main():
 
     # ---- roofline of the dominant kernel family: profiled passes of the same step ---------------
     roofline, families = None, {}
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         torch.cuda.set_stream(streams[0])
         launches = []
         for _ in range(args.profile_steps):

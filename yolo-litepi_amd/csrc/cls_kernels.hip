@@ -209,7 +209,8 @@ void launch_spatial_mean(int prec, const View& in, const View& out, const int* m
 }
 
 // ------------------------------------------------------------------------------------
-// softmax(dim=1) + argmax (e2e.py:394-396), one thread per ROI
+// softmax(dim=1) + argmax (e2e.py:394-396), one wavefront per ROI (classes strided over lanes,
+// wave-level max / sum / arg-max reductions)
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __restrict__ logits, int pitch, int nc,
                                                              float* __restrict__ probs, int* __restrict__ ids,
@@ -217,32 +218,43 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __rest
                                                              const int* __restrict__ roi_img, const int* __restrict__ roi_slot,
                                                              const int* __restrict__ m_dyn) {
   const int R = *m_dyn;
-  for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+  for (int r = wave; r < R; r += nwaves) {
     const float* l = logits + (long)r * pitch;
     float mx = -INFINITY;
-    for (int c = 0; c < nc; ++c) mx = fmaxf(mx, l[c]);
+    for (int c = lane; c < nc; c += 64) mx = fmaxf(mx, l[c]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float sum = 0.f;
-    for (int c = 0; c < nc; ++c) sum += expf(l[c] - mx);
+    for (int c = lane; c < nc; c += 64) sum += expf(l[c] - mx);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     float best = -1.f;
-    int best_c = 0;
-    for (int c = 0; c < nc; ++c) {
+    int best_c = 0x7fffffff;
+    for (int c = lane; c < nc; c += 64) {
       const float p = expf(l[c] - mx) / sum;
       if (probs) probs[(long)r * nc + c] = p;
-      if (p > best) { best = p; best_c = c; }
+      if (p > best) { best = p; best_c = c; }  // first maximum within the lane (ascending c)
     }
-    if (ids) ids[r] = best_c;
-    if (conf) conf[r] = best;
-    if (dets) {
-      lp_det* d = dets + (long)roi_img[r] * max_det + roi_slot[r];
-      d->cls_class = best_c;
-      d->cls_conf = best;
+    for (int o = 32; o > 0; o >>= 1) {  // first maximum across lanes: larger p, then smaller class index
+      const float ob = __shfl_xor(best, o);
+      const int oc = __shfl_xor(best_c, o);
+      if (ob > best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+    }
+    if (lane == 0) {
+      if (ids) ids[r] = best_c;
+      if (conf) conf[r] = best;
+      if (dets) {
+        lp_det* d = dets + (long)roi_img[r] * max_det + roi_slot[r];
+        d->cls_class = best_c;
+        d->cls_conf = best;
+      }
     }
   }
 }
 
 void launch_softmax_argmax(const float* logits, int pitch, int nc, float* probs, int* ids, float* conf, lp_det* dets,
                            int max_det, const RoiTable* tab, const int* m_dyn, int max_items, hipStream_t st) {
-  dim3 grid(grid_for(max_items));
+  dim3 grid(grid_for((long)max_items * 64));
   hipLaunchKernelGGL(softmax_argmax_kernel, grid, dim3(256), 0, st, logits, pitch, nc, probs, ids, conf, dets, max_det,
                      tab ? tab->img : nullptr, tab ? tab->slot : nullptr, m_dyn);
   LP_HIP(hipGetLastError());

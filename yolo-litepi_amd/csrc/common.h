@@ -56,7 +56,12 @@ struct DevBuf {
     if (n == 0) n = 16;
     LP_HIP(hipMalloc(&p, n));
     bytes = n;
-    if (zero) LP_HIP(hipMemset(p, 0, n));
+    if (zero) {
+      // hipMemset runs on the null stream and may return before it has executed; the handle's
+      // streams are non-blocking, so a later async copy/kernel could otherwise overtake the fill
+      LP_HIP(hipMemset(p, 0, n));
+      LP_HIP(hipStreamSynchronize(nullptr));
+    }
   }
   void release() {
     if (p) (void)hipFree(p);

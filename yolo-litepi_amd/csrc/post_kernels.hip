@@ -332,7 +332,7 @@ void launch_roi_index(const int* counts, const RoiTable& t, int N, int max_det, 
 // quantised to 22-bit fixed point, horizontal pass to uint8 then vertical pass to uint8.
 // Pinned against Pillow itself through oracle/pil_resize_ref.py.
 // ------------------------------------------------------------------------------------
-#define RR_THREADS 256
+#define RR_THREADS 1024  /* 16 waves: the byte gathers are latency-bound, TLP hides them */
 #define RR_PRECISION_BITS 22
 // "small" variant: ROI sides <= 256 px (support <= 4 -> at most 9 taps); the whole
 // horizontally-resampled crop [in_h][S][3] lives in LDS, so a ROI costs two barriers.
@@ -489,8 +489,8 @@ void launch_roi_resize(const RoiResizeArgs& a, hipStream_t st) {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
   (void)once;
   LP_CHECK(a.S <= 64, LP_ERR_ARG, "classifier input larger than 64 unsupported by the resize kernel");
-  hipLaunchKernelGGL((roi_resize_kernel<RR_SMALL_K, true>), dim3(1024), dim3(RR_THREADS), roi_resize_small_lds(), st, a);
-  hipLaunchKernelGGL((roi_resize_kernel<RR_LARGE_K, false>), dim3(256), dim3(RR_THREADS), roi_resize_lds_bytes(), st, a);
+  hipLaunchKernelGGL((roi_resize_kernel<RR_SMALL_K, true>), dim3(512), dim3(RR_THREADS), roi_resize_small_lds(), st, a);
+  hipLaunchKernelGGL((roi_resize_kernel<RR_LARGE_K, false>), dim3(128), dim3(RR_THREADS), roi_resize_lds_bytes(), st, a);
   LP_HIP(hipGetLastError());
 }
 

@@ -239,7 +239,7 @@ def make_anchors(size: int, strides: Sequence[int] = (8, 16, 32)) -> Tuple[np.nd
 
 
 def export_detector(param_path: str, bin_path: str, preset: str = "v1", seed: int = 1234, nc: int = 1,
-                    reg_max: int = 16, size: int = 640, cls_bias: float = -4.0, gain: float = 2.0,
+                    reg_max: int = 16, size: int = 640, cls_bias: float = -4.0, gain: float = 2.0, box_ramp: float = 0.45,
                     spec: Optional[dict] = None) -> dict:
     """Write a seeded random-weight detector; returns the spec used."""
     sp = dict(PRESETS[preset]) if spec is None else dict(spec)
@@ -270,7 +270,10 @@ def export_detector(param_path: str, bin_path: str, preset: str = "v1", seed: in
     for feat, cin in ((f3, sp["f3"]), (d4, sp["d4"]), (d5, sp["d5"])):
         b = g.conv(feat, cin, hb, 3)
         b = g.conv(b, hb, hb, 3)
-        b = g.conv(b, hb, 4 * reg_max, 1, act=False, bias_init=1.0)
+        b = g.conv(b, hb, 4 * reg_max, 1, act=False)
+        # DFL bias ramp: favour the low distance bins so boxes are a few strides wide (traffic
+        # signs: ~54 px in TT100K frames) instead of the ~8-bin mean of flat logits
+        g.ops[-1].bias = (g.ops[-1].bias + np.tile(-box_ramp * np.arange(reg_max, dtype=np.float32), 4)).astype(np.float32)
         c = g.conv(feat, cin, hc, 3)
         c = g.conv(c, hc, hc, 3)
         c = g.conv(c, hc, nc, 1, act=False, bias_init=cls_bias)
