@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--max-det", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=12, help="images in the CPU baseline sample")
+    ap.add_argument("--cpu-images", type=int, default=320, help="images in the CPU baseline sample")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent pipeline handles (own stream + activation buffers) the steps rotate over, so "

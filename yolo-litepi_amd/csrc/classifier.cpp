@@ -112,9 +112,22 @@ void expand_dw(const Folded& f, const Layout& in, int in_first, int cp, int in_v
 }
 }  // namespace
 
+static void upload_f32(DevBuf& d, const std::vector<float>& v) {
+  d.alloc((v.size() + 16) * 4);
+  LP_HIP(hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+}
+static void upload_u16(DevBuf& d, const std::vector<uint16_t>& v) {
+  d.alloc(v.size() * 2);
+  LP_HIP(hipMemcpy(d.p, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+}
+
 void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
   loaded_ = false;
   pws_.clear(); dws_.clear(); blocks_.clear();
+  for (auto& f : fused_) f.clear();
+  // stride-1 blocks of a stage run as one fused launch (cls_fused.hip) in the fp16 MFMA configuration;
+  // fp32 and the naive debug path keep one kernel per layer
+  use_fused_ = prec_ == LP_FP16 && impl_ == IMPL_MFMA && S_ == 64;
   LP_CHECK(S_ % 32 == 0 && S_ >= 32 && S_ <= 64, LP_ERR_ARG, "classifier input size must be 32 or 64");
 
   // conv1 + BN -> fp32 [27][24], RGB order
@@ -176,6 +189,11 @@ void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
         expand_pw(a1, lout, bf, bfp, w, b, bfp, bfp);
         B.b2_pw1 = add_pw(p + "branch2.0", w, b, bfp, bfp, ACT_RELU, Ho);
         t1_elems = std::max(t1_elems, (size_t)Ho * Ho * bfp);
+        if (use_fused_) {
+          fused_[s].emplace_back();
+          upload_u16(fused_[s].back().w1, pack_fused_pw(w, bfp, bfp));
+          upload_f32(fused_[s].back().b1, b);
+        }
       }
       Layout lmid;
       lmid.C = bf;
@@ -183,10 +201,12 @@ void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
       LP_CHECK(d2.co == bf && d2.ci == 1 && d2.k == 3, LP_ERR_ARG, "%sbranch2.3 shape", p.c_str());
       expand_dw(d2, lmid, 0, bfp, 0, w, b);
       B.b2_dw = add_dw(p + "branch2.3", w, b, bfp, B.stride);
+      if (use_fused_ && B.stride == 1) { upload_f32(fused_[s].back().dw, w); upload_f32(fused_[s].back().dwb, b); }
       Folded a2 = fold(sd, p + "branch2.5", p + "branch2.6");
       LP_CHECK(a2.co == bf && a2.ci == bf, LP_ERR_ARG, "%sbranch2.5 shape", p.c_str());
       expand_pw(a2, lmid, 0, bfp, w, b, bfp, 0);
       B.b2_pw2 = add_pw(p + "branch2.5", w, b, bfp, bfp, ACT_RELU, Ho);
+      if (use_fused_ && B.stride == 1) { upload_u16(fused_[s].back().w2, pack_fused_pw(w, bfp, bfp)); upload_f32(fused_[s].back().b2, b); }
       t2_elems = std::max(t2_elems, (size_t)Ho * Ho * bfp);
       blocks_.push_back(B);
       inp = oup;
@@ -269,6 +289,30 @@ void Classifier::forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Pro
     const int bf = half_c_[s], bfp = half_cp_[s];
     for (int r = 0; r < kStageRepeats[s]; ++r, ++bi) {
       const Block& B = blocks_[bi];
+      if (use_fused_ && r == 1) {
+        // blocks 1..n-1 of the stage in one launch, X resident in LDS
+        Act& dstf = a_stage_[s][1];
+        FusedStageArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.in = x.base; fa.out = dstf.mem.p; fa.m_dyn = d_R;
+        fa.nblk = kStageRepeats[s] - 1;
+        for (int q = 0; q < fa.nblk; ++q) {
+          const FusedW& fw = fused_[s][q];
+          fa.blk[q].w1 = fw.w1.as<u32x4_t>(); fa.blk[q].b1 = fw.b1.as<float>();
+          fa.blk[q].dw = fw.dw.as<float>(); fa.blk[q].dwb = fw.dwb.as<float>();
+          fa.blk[q].w2 = fw.w2.as<u32x4_t>(); fa.blk[q].b2 = fw.b2.as<float>();
+        }
+        fa.HW = dstf.H * dstf.W; fa.W = dstf.W; fa.bf = bf; fa.bfp = bfp; fa.group = 64 / fa.HW;
+        fa.in_pitch = x.pitch; fa.out_pitch = dstf.C;
+        P0();
+        launch_fused_stage(fa, maxR_, st);
+        const double px = (double)fa.HW;
+        P1("shuffle_stage_fused", fmt("stage%d.1-%d", s + 2, kStageRepeats[s] - 1),
+           fa.nblk * (2.0 * 2.0 * bfp * bfp + 2.0 * 9 * bfp) * px, 2.0 * px * 2 * bfp * esd);
+        x = act_view(dstf);
+        bi += kStageRepeats[s] - 1;  // the loop's ++bi does not run after break
+        break;
+      }
       Act& dst = a_stage_[s][r & 1];
       const int Ho = dst.H;
       const View out = act_view(dst);

@@ -4,6 +4,7 @@
 #include "common.h"
 #include "conv.h"
 #include "detector.h"
+#include "cls_fused.h"
 #include "kernels.h"
 
 namespace lp {
@@ -51,6 +52,10 @@ class Classifier {
   Act a_stem_, a_pool_, a_t1_, a_t2_, a_b1dw_, a_b1_, a_stage_[3][2], a_conv5_, a_mean_;
   DevBuf d_logits_;
   int half_c_[3], half_cp_[3];
+  // fused stride-1 stage path (fp16 + MFMA only)
+  struct FusedW { DevBuf w1, b1, dw, dwb, w2, b2; };
+  std::vector<FusedW> fused_[3];
+  bool use_fused_ = false;
 };
 
 }  // namespace lp

@@ -1,0 +1,34 @@
+// Fused ShuffleNetV2 stage kernel (cls_fused.hip): host-side declarations.
+#pragma once
+#include "common.h"
+
+namespace lp {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+struct FusedBlockW {
+  const u32x4_t* w1;  // branch2.0 (+BN) A fragments [tile][step][lane][16 B]
+  const float* b1;    // [bfp]
+  const float* dw;    // branch2.3 (+BN) fp32 [9][bfp]
+  const float* dwb;   // [bfp]
+  const u32x4_t* w2;  // branch2.5 (+BN)
+  const float* b2;    // [bfp]
+};
+
+struct FusedStageArgs {
+  const void* in;     // [R, H, W, 2*bfp] fp16 (output of the stage's stride-2 block)
+  void* out;          // same shape
+  const int* m_dyn;   // device ROI count
+  FusedBlockW blk[8];
+  int nblk;
+  int HW, W;          // pixels per ROI at this stage, map width
+  int bf, bfp;        // logical / physical channels of one half
+  int group;          // ROIs per workgroup (group * HW == 64)
+  int in_pitch, out_pitch;
+};
+
+size_t fused_stage_lds_bytes(int bfp);
+void launch_fused_stage(const FusedStageArgs& a, int max_items, hipStream_t st);
+std::vector<uint16_t> pack_fused_pw(const std::vector<float>& w_phys, int cout_p, int cin_p);
+
+}  // namespace lp

@@ -1,0 +1,221 @@
+// Fused ShuffleNetV2 stage (fp16): every stride-1 InvertedResidual of a stage in ONE launch.
+//
+// The un-fused classifier spends ~40 launches per batch on GEMMs of a few MFLOP each, all of
+// them bound by the ~6 us launch/latency floor.  Here one workgroup owns 64 pixels (1 ROI at
+// 8x8, 4 ROIs at 4x4, 16 ROIs at 2x2) and keeps the stage tensor X = [x_lo | x_hi] resident in
+// LDS across all blocks; per block (reference e2e.py:393 -> torchvision InvertedResidual):
+//     t1 = relu(W1 . x_hi + b1)            MFMA, A fragments straight from L2 (weights are read
+//     t2 = dw3x3(t1) + bd                  VALU                      once per workgroup per block)
+//     y  = relu(W2 . t2 + b2)              MFMA
+//     X  = channel_shuffle(cat(x_lo, y))   in place: read x_lo, barrier, write interleaved pairs
+// MFMA orientation as in conv_kernels.hip: D[out-channel][pixel]; a D fragment holds 4
+// consecutive channels of one pixel per lane, which is exactly the 8-byte store the next stage's
+// B fragment (8 consecutive channels of one pixel) wants in LDS.
+#include "cls_fused.h"
+
+namespace lp {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define FS_PIX 64  // pixels per workgroup = 4 MFMA column tiles
+
+template <int TPW>
+__device__ __forceinline__ void pw_gemm(const u32x4* __restrict__ wfrag, const char* bsrc, int brow, int S, int Tt, int K,
+                                        int wave, int lane, floatx4 (&acc)[TPW][4]) {
+  const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[ti][p] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    half8 bf[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};  // K groups past the last physical channel: LDS there is row padding
+      if ((4 * s + g) * 8 < K) v = *reinterpret_cast<const u32x4*>(bsrc + (p * 16 + col) * brow + (4 * s + g) * 16);
+      bf[p] = __builtin_bit_cast(half8, v);
+    }
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int t = wave + 4 * ti;
+      if (t < Tt) {
+        const half8 af = __builtin_bit_cast(half8, wfrag[((size_t)t * S + s) * 64 + lane]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[ti][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[p], acc[ti][p], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int TPW>
+__global__ __launch_bounds__(256) void shuffle_stage_kernel(const FusedStageArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int bfp = a.bfp, bf = a.bf, HW = a.HW, W = a.W;
+  const int xrow = 2 * bfp * 2 + 16;  // LDS row pitches in bytes: odd number of 16-byte slots
+  const int trow = bfp * 2 + 16;
+  char* X = smem;
+  char* T1 = X + FS_PIX * xrow;
+  char* T2 = T1 + FS_PIX * trow;
+  const int CGX = 2 * bfp / 8, CGT = bfp / 8;
+  const int Tt = bfp / 16, S = (bfp + 31) / 32;
+  const int R = *a.m_dyn;
+  const int ngroups = (R + a.group - 1) / a.group;
+  const half_t* in = reinterpret_cast<const half_t*>(a.in);
+  half_t* out = reinterpret_cast<half_t*>(a.out);
+
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int roi0 = grp * a.group;
+    const int nvalid = ((R - roi0) < a.group ? (R - roi0) : a.group) * HW;
+    const long pix0 = (long)roi0 * HW;
+    for (int i = tid; i < FS_PIX * CGX; i += 256) {
+      const int px = i / CGX, cg = i - px * CGX;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (px < nvalid) v = *reinterpret_cast<const u32x4*>(in + (pix0 + px) * a.in_pitch + cg * 8);
+      *reinterpret_cast<u32x4*>(X + px * xrow + cg * 16) = v;
+    }
+    __syncthreads();
+
+    for (int b = 0; b < a.nblk; ++b) {
+      const FusedBlockW bw = a.blk[b];
+      floatx4 acc[TPW][4];
+      // ---- t1 = relu(W1 . x_hi + b1) -------------------------------------------------------
+      pw_gemm<TPW>(bw.w1, X + bfp * 2, xrow, S, Tt, bfp, wave, lane, acc);
+#pragma unroll
+      for (int ti = 0; ti < TPW; ++ti) {
+        const int t = wave + 4 * ti;
+        if (t < Tt) {
+          const int ch0 = t * 16 + 4 * g;
+          const floatx4 bias = *reinterpret_cast<const floatx4*>(bw.b1 + ch0);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            half4 q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = (half_t)fmaxf(acc[ti][p][i] + bias[i], 0.f);
+            *reinterpret_cast<half4*>(T1 + (p * 16 + col) * trow + ch0 * 2) = q;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- t2 = dw3x3(t1) + bd (pad 1, stride 1, inside each ROI's HxW map) -------------------
+      for (int i = tid; i < FS_PIX * CGT; i += 256) {
+        const int px = i / CGT, cg = i - px * CGT;
+        const int rl = px / HW, pp = px - rl * HW;
+        const int y = pp / W, x = pp - y * W;
+        float acc8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc8[j] = bw.dwb[cg * 8 + j];
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = y - 1 + ky;
+          if (yy < 0 || yy >= W) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x - 1 + kx;
+            if (xx < 0 || xx >= W) continue;
+            const half8 v = *reinterpret_cast<const half8*>(T1 + (rl * HW + yy * W + xx) * trow + cg * 16);
+            const float* wr = bw.dw + (ky * 3 + kx) * bfp + cg * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc8[j] = fmaf((float)v[j], wr[j], acc8[j]);
+          }
+        }
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)acc8[j];
+        *reinterpret_cast<half8*>(T2 + px * trow + cg * 16) = o;
+      }
+      __syncthreads();
+      // ---- y = relu(W2 . t2 + b2); X = shuffle(cat(x_lo, y)) in place --------------------------
+      pw_gemm<TPW>(bw.w2, T2, trow, S, Tt, bfp, wave, lane, acc);
+      half4 x1v[TPW][4];
+#pragma unroll
+      for (int ti = 0; ti < TPW; ++ti) {
+        const int t = wave + 4 * ti;
+        if (t < Tt) {
+          const int ch0 = t * 16 + 4 * g;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) x1v[ti][p] = *reinterpret_cast<const half4*>(X + (p * 16 + col) * xrow + ch0 * 2);
+        }
+      }
+      __syncthreads();  // every x_lo value is in registers before any interleaved pair is written
+#pragma unroll
+      for (int ti = 0; ti < TPW; ++ti) {
+        const int t = wave + 4 * ti;
+        if (t < Tt) {
+          const int ch0 = t * 16 + 4 * g;
+          const floatx4 bias = *reinterpret_cast<const floatx4*>(bw.b2 + ch0);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int c = ch0 + i;
+              if (c < bf) {
+                const int l = 2 * c;
+                const int phys = l < bf ? l : bfp + (l - bf);
+                half2v pr;
+                pr[0] = x1v[ti][p][i];
+                pr[1] = (half_t)fmaxf(acc[ti][p][i] + bias[i], 0.f);
+                *reinterpret_cast<half2v*>(X + (p * 16 + col) * xrow + phys * 2) = pr;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    for (int i = tid; i < FS_PIX * CGX; i += 256) {
+      const int px = i / CGX, cg = i - px * CGX;
+      if (px < nvalid)
+        *reinterpret_cast<u32x4*>(out + (pix0 + px) * a.out_pitch + cg * 8) = *reinterpret_cast<const u32x4*>(X + px * xrow + cg * 16);
+    }
+    __syncthreads();
+  }
+}
+
+size_t fused_stage_lds_bytes(int bfp) { return (size_t)FS_PIX * ((2 * bfp * 2 + 16) + 2 * (bfp * 2 + 16)); }
+
+void launch_fused_stage(const FusedStageArgs& a, int max_items, hipStream_t st) {
+  const size_t lds = fused_stage_lds_bytes(a.bfp);
+  LP_CHECK(lds <= 160 * 1024 && a.bfp % 16 == 0 && FS_PIX % a.HW == 0 && a.group * a.HW == FS_PIX, LP_ERR_STATE,
+           "fused ShuffleNet stage: unsupported geometry (bfp %d, HW %d)", a.bfp, a.HW);
+  const int tpw = (a.bfp / 16 + 3) / 4;
+  int groups = (max_items + a.group - 1) / a.group;
+  if (groups > 1024) groups = 1024;
+  if (groups < 1) groups = 1;
+#define LP_FS(N)                                                                                          \
+  {                                                                                                       \
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_stage_kernel<N>), \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); \
+    (void)once;                                                                                           \
+    hipLaunchKernelGGL((shuffle_stage_kernel<N>), dim3(groups), dim3(256), lds, st, a);                    \
+  }
+  if (tpw <= 1) LP_FS(1) else if (tpw == 2) LP_FS(2) else if (tpw <= 4) LP_FS(4) else
+    throw Error(LP_ERR_STATE, "fused ShuffleNet stage: too many channel tiles");
+#undef LP_FS
+  LP_HIP(hipGetLastError());
+}
+
+// A fragments of a pointwise conv over PHYSICAL channels: [tile][step][lane][8 halfs];
+// tile t row m = output channel 16t+m, K group q = 4s+g = input channels [8q, 8q+8).
+std::vector<uint16_t> pack_fused_pw(const std::vector<float>& w_phys, int cout_p, int cin_p) {
+  const int Tt = cout_p / 16, S = (cin_p + 31) / 32;
+  std::vector<uint16_t> buf((size_t)Tt * S * 64 * 8, 0);
+  for (int t = 0; t < Tt; ++t)
+    for (int s = 0; s < S; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, m = lane & 15;
+        const int oc = t * 16 + m;
+        for (int j = 0; j < 8; ++j) {
+          const int ci = (4 * s + g) * 8 + j;
+          if (ci < cin_p) buf[(((size_t)t * S + s) * 64 + lane) * 8 + j] = f32_to_f16(w_phys[(size_t)oc * cin_p + ci]);
+        }
+      }
+  return buf;
+}
+
+}  // namespace lp
