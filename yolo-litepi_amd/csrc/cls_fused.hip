@@ -1,7 +1,8 @@
 // Fused ShuffleNetV2 stage (fp16): every stride-1 InvertedResidual of a stage in ONE launch.
 //
 // The un-fused classifier spends ~40 launches per batch on GEMMs of a few MFLOP each, all of
-// them bound by the ~6 us launch/latency floor.  Here one workgroup owns 64 pixels (1 ROI at
+// them bound by the ~6 us launch/latency floor.  Here one workgroup (one wave per 16-channel
+// tile: 4/8/16 waves) owns 64 pixels (1 ROI at
 // 8x8, 4 ROIs at 4x4, 16 ROIs at 2x2) and keeps the stage tensor X = [x_lo | x_hi] resident in
 // LDS across all blocks; per block (reference e2e.py:393 -> torchvision InvertedResidual):
 //     t1 = relu(W1 . x_hi + b1)            MFMA, A fragments straight from L2 (weights are read
@@ -24,37 +25,43 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define FS_PIX 64  // pixels per workgroup = 4 MFMA column tiles
 
-template <int TPW>
-__device__ __forceinline__ void pw_gemm(const u32x4* __restrict__ wfrag, const char* bsrc, int brow, int S, int Tt, int K,
-                                        int wave, int lane, floatx4 (&acc)[TPW][4]) {
+// One wave = one 16-channel output tile x 4 pixel tiles.  The S weight fragments of a GEMM are
+// requested together (prefetch_w) well before they are used, so a GEMM costs one L2 round trip
+// that overlaps the preceding phase instead of one per K step.
+template <int SMAX>
+__device__ __forceinline__ void prefetch_w(const u32x4* __restrict__ wfrag, int S, int t, int lane, bool active,
+                                           u32x4 (&af)[SMAX]) {
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s) {
+    af[s] = u32x4{0u, 0u, 0u, 0u};
+    if (active && s < S) af[s] = wfrag[((size_t)t * S + s) * 64 + lane];
+  }
+}
+
+template <int SMAX>
+__device__ __forceinline__ void pw_gemm(const u32x4 (&af)[SMAX], const char* bsrc, int brow, int S, int K, int lane,
+                                        floatx4 (&acc)[4]) {
   const int g = lane >> 4, col = lane & 15;
 #pragma unroll
-  for (int ti = 0; ti < TPW; ++ti)
+  for (int p = 0; p < 4; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[ti][p] = floatx4{0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < S; ++s) {
-    half8 bf[4];
+  for (int s = 0; s < SMAX; ++s) {
+    if (s < S) {
+      const half8 a = __builtin_bit_cast(half8, af[s]);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};  // K groups past the last physical channel: LDS there is row padding
-      if ((4 * s + g) * 8 < K) v = *reinterpret_cast<const u32x4*>(bsrc + (p * 16 + col) * brow + (4 * s + g) * 16);
-      bf[p] = __builtin_bit_cast(half8, v);
-    }
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-      const int t = wave + 4 * ti;
-      if (t < Tt) {
-        const half8 af = __builtin_bit_cast(half8, wfrag[((size_t)t * S + s) * 64 + lane]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[ti][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[p], acc[ti][p], 0, 0, 0);
+      for (int p = 0; p < 4; ++p) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};  // K groups past the last physical channel: LDS there is row padding
+        if ((4 * s + g) * 8 < K) v = *reinterpret_cast<const u32x4*>(bsrc + (p * 16 + col) * brow + (4 * s + g) * 16);
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(half8, v), acc[p], 0, 0, 0);
       }
     }
   }
 }
 
-template <int TPW>
-__global__ __launch_bounds__(256) void shuffle_stage_kernel(const FusedStageArgs a) {
+template <int NW, int SMAX>
+__global__ __launch_bounds__(NW * 64) void shuffle_stage_kernel(const FusedStageArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTHR = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, col = lane & 15;
   const int bfp = a.bfp, bf = a.bf, HW = a.HW, W = a.W;
@@ -65,6 +72,8 @@ __global__ __launch_bounds__(256) void shuffle_stage_kernel(const FusedStageArgs
   char* T2 = T1 + FS_PIX * trow;
   const int CGX = 2 * bfp / 8, CGT = bfp / 8;
   const int Tt = bfp / 16, S = (bfp + 31) / 32;
+  const bool active = wave < Tt;  // this wave's output tile (waves beyond the tile count only move data)
+  const int ch0 = wave * 16 + 4 * g;
   const int R = *a.m_dyn;
   const int ngroups = (R + a.group - 1) / a.group;
   const half_t* in = reinterpret_cast<const half_t*>(a.in);
@@ -74,7 +83,9 @@ __global__ __launch_bounds__(256) void shuffle_stage_kernel(const FusedStageArgs
     const int roi0 = grp * a.group;
     const int nvalid = ((R - roi0) < a.group ? (R - roi0) : a.group) * HW;
     const long pix0 = (long)roi0 * HW;
-    for (int i = tid; i < FS_PIX * CGX; i += 256) {
+    u32x4 w1f[SMAX], w2f[SMAX];
+    prefetch_w<SMAX>(a.blk[0].w1, S, wave, lane, active, w1f);
+    for (int i = tid; i < FS_PIX * CGX; i += NTHR) {
       const int px = i / CGX, cg = i - px * CGX;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
       if (px < nvalid) v = *reinterpret_cast<const u32x4*>(in + (pix0 + px) * a.in_pitch + cg * 8);
@@ -84,27 +95,24 @@ __global__ __launch_bounds__(256) void shuffle_stage_kernel(const FusedStageArgs
 
     for (int b = 0; b < a.nblk; ++b) {
       const FusedBlockW bw = a.blk[b];
-      floatx4 acc[TPW][4];
+      floatx4 acc[4];
       // ---- t1 = relu(W1 . x_hi + b1) -------------------------------------------------------
-      pw_gemm<TPW>(bw.w1, X + bfp * 2, xrow, S, Tt, bfp, wave, lane, acc);
+      prefetch_w<SMAX>(bw.w2, S, wave, lane, active, w2f);  // lands while pw1 + dw run
+      if (active) {
+        pw_gemm<SMAX>(w1f, X + bfp * 2, xrow, S, bfp, lane, acc);
+        const floatx4 bias = *reinterpret_cast<const floatx4*>(bw.b1 + ch0);
 #pragma unroll
-      for (int ti = 0; ti < TPW; ++ti) {
-        const int t = wave + 4 * ti;
-        if (t < Tt) {
-          const int ch0 = t * 16 + 4 * g;
-          const floatx4 bias = *reinterpret_cast<const floatx4*>(bw.b1 + ch0);
+        for (int p = 0; p < 4; ++p) {
+          half4 q;
 #pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            half4 q;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = (half_t)fmaxf(acc[ti][p][i] + bias[i], 0.f);
-            *reinterpret_cast<half4*>(T1 + (p * 16 + col) * trow + ch0 * 2) = q;
-          }
+          for (int i = 0; i < 4; ++i) q[i] = (half_t)fmaxf(acc[p][i] + bias[i], 0.f);
+          *reinterpret_cast<half4*>(T1 + (p * 16 + col) * trow + ch0 * 2) = q;
         }
       }
+      if (b + 1 < a.nblk) prefetch_w<SMAX>(a.blk[b + 1].w1, S, wave, lane, active, w1f);  // for the next block
       __syncthreads();
-      // ---- t2 = dw3x3(t1) + bd (pad 1, stride 1, inside each ROI's HxW map) -------------------
-      for (int i = tid; i < FS_PIX * CGT; i += 256) {
+      // ---- t2 = dw3x3(t1) + bd (pad 1, stride 1, inside each ROI's WxW map) -------------------
+      for (int i = tid; i < FS_PIX * CGT; i += NTHR) {
         const int px = i / CGT, cg = i - px * CGT;
         const int rl = px / HW, pp = px - rl * HW;
         const int y = pp / W, x = pp - y * W;
@@ -130,37 +138,27 @@ __global__ __launch_bounds__(256) void shuffle_stage_kernel(const FusedStageArgs
       }
       __syncthreads();
       // ---- y = relu(W2 . t2 + b2); X = shuffle(cat(x_lo, y)) in place --------------------------
-      pw_gemm<TPW>(bw.w2, T2, trow, S, Tt, bfp, wave, lane, acc);
-      half4 x1v[TPW][4];
+      half4 x1v[4];
+      if (active) {
+        pw_gemm<SMAX>(w2f, T2, trow, S, bfp, lane, acc);
 #pragma unroll
-      for (int ti = 0; ti < TPW; ++ti) {
-        const int t = wave + 4 * ti;
-        if (t < Tt) {
-          const int ch0 = t * 16 + 4 * g;
-#pragma unroll
-          for (int p = 0; p < 4; ++p) x1v[ti][p] = *reinterpret_cast<const half4*>(X + (p * 16 + col) * xrow + ch0 * 2);
-        }
+        for (int p = 0; p < 4; ++p) x1v[p] = *reinterpret_cast<const half4*>(X + (p * 16 + col) * xrow + ch0 * 2);
       }
       __syncthreads();  // every x_lo value is in registers before any interleaved pair is written
+      if (active) {
+        const floatx4 bias = *reinterpret_cast<const floatx4*>(bw.b2 + ch0);
 #pragma unroll
-      for (int ti = 0; ti < TPW; ++ti) {
-        const int t = wave + 4 * ti;
-        if (t < Tt) {
-          const int ch0 = t * 16 + 4 * g;
-          const floatx4 bias = *reinterpret_cast<const floatx4*>(bw.b2 + ch0);
+        for (int p = 0; p < 4; ++p) {
 #pragma unroll
-          for (int p = 0; p < 4; ++p) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int c = ch0 + i;
-              if (c < bf) {
-                const int l = 2 * c;
-                const int phys = l < bf ? l : bfp + (l - bf);
-                half2v pr;
-                pr[0] = x1v[ti][p][i];
-                pr[1] = (half_t)fmaxf(acc[ti][p][i] + bias[i], 0.f);
-                *reinterpret_cast<half2v*>(X + (p * 16 + col) * xrow + phys * 2) = pr;
-              }
+          for (int i = 0; i < 4; ++i) {
+            const int c = ch0 + i;
+            if (c < bf) {
+              const int l = 2 * c;
+              const int phys = l < bf ? l : bfp + (l - bf);
+              half2v pr;
+              pr[0] = x1v[p][i];
+              pr[1] = (half_t)fmaxf(acc[p][i] + bias[i], 0.f);
+              *reinterpret_cast<half2v*>(X + (p * 16 + col) * xrow + phys * 2) = pr;
             }
           }
         }
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(256) void shuffle_stage_kernel(const FusedStageArgs
       __syncthreads();
     }
 
-    for (int i = tid; i < FS_PIX * CGX; i += 256) {
+    for (int i = tid; i < FS_PIX * CGX; i += NTHR) {
       const int px = i / CGX, cg = i - px * CGX;
       if (px < nvalid)
         *reinterpret_cast<u32x4*>(out + (pix0 + px) * a.out_pitch + cg * 8) = *reinterpret_cast<const u32x4*>(X + px * xrow + cg * 16);
@@ -183,18 +181,18 @@ void launch_fused_stage(const FusedStageArgs& a, int max_items, hipStream_t st) 
   const size_t lds = fused_stage_lds_bytes(a.bfp);
   LP_CHECK(lds <= 160 * 1024 && a.bfp % 16 == 0 && FS_PIX % a.HW == 0 && a.group * a.HW == FS_PIX, LP_ERR_STATE,
            "fused ShuffleNet stage: unsupported geometry (bfp %d, HW %d)", a.bfp, a.HW);
-  const int tpw = (a.bfp / 16 + 3) / 4;
+  const int Tt = a.bfp / 16, S = (a.bfp + 31) / 32;
   int groups = (max_items + a.group - 1) / a.group;
   if (groups > 1024) groups = 1024;
   if (groups < 1) groups = 1;
-#define LP_FS(N)                                                                                          \
-  {                                                                                                       \
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_stage_kernel<N>), \
+#define LP_FS(NW, SM)                                                                                          \
+  {                                                                                                            \
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_stage_kernel<NW, SM>), \
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); \
-    (void)once;                                                                                           \
-    hipLaunchKernelGGL((shuffle_stage_kernel<N>), dim3(groups), dim3(256), lds, st, a);                    \
+    (void)once;                                                                                                \
+    hipLaunchKernelGGL((shuffle_stage_kernel<NW, SM>), dim3(groups), dim3(NW * 64), lds, st, a);                 \
   }
-  if (tpw <= 1) LP_FS(1) else if (tpw == 2) LP_FS(2) else if (tpw <= 4) LP_FS(4) else
+  if (Tt <= 4 && S <= 2) LP_FS(4, 2) else if (Tt <= 8 && S <= 4) LP_FS(8, 4) else if (Tt <= 16 && S <= 8) LP_FS(16, 8) else
     throw Error(LP_ERR_STATE, "fused ShuffleNet stage: too many channel tiles");
 #undef LP_FS
   LP_HIP(hipGetLastError());

@@ -20,6 +20,7 @@ struct ConvLayer {
   // MFMA tiling
   int NT = 1, nsplits = 1, CK = 0, CGc = 0, nchunks = 1, steps = 0, LW = 0, PS = 0, bwh = 2, bww = 2;
   size_t lds_bytes = 0;
+  bool direct = false;  // 3x3 stride-2: gather B fragments from global memory (no LDS input tile)
   DevBuf d_w, d_bias;
   std::string name;
   double macs_per_pixel() const { return (double)k * k * Cin * Cout; }

@@ -295,6 +295,104 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// 3x3 stride-2 (pad 1) implicit GEMM without input staging.  A stride-2 halo tile is 4x the
+// output tile, so LDS staging re-reads more than it saves: each input element feeds only
+// 9/4 taps on average.  Same structure as the 1x1 kernel: this block's weight fragments (all
+// of K = 9 x Cin) in LDS, B fragments gathered straight from global memory with per-tap bounds
+// checks (zero padding), flattened output pixels.
+// ------------------------------------------------------------------------------------
+template <typename T, int NT, int NP>
+__global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = Tr<T>::G;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int ns = blockIdx.y;
+  const int S = a.steps;
+  const int CG = a.Cin / G;
+  const long M = (long)a.M;
+  const long ntiles = (M + 64 * NP - 1) / (64 * NP);
+  if ((long)blockIdx.x >= ntiles) return;
+
+  u32x4* lds_w = reinterpret_cast<u32x4*>(smem);
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + (size_t)ns * S * NT * 64;
+  const int nW = S * NT * 64;
+  for (int r0 = 0; r0 < nW; r0 += 256 * 8) {
+    u32x4 wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = r0 + u * 256 + tid;
+      wv[u] = u32x4{0u, 0u, 0u, 0u};
+      if (i < nW) wv[u] = wsrc[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = r0 + u * 256 + tid;
+      if (i < nW) lds_w[i] = wv[u];
+    }
+  }
+  __syncthreads();
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const int HWo = a.Hout * a.Wout;
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long pix0 = (tile * 4 + wave) * 16 * NP;
+    if (pix0 >= M) continue;
+    const T* src[NP];
+    int iy0[NP], ix0[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      long pix = pix0 + p * 16 + col;
+      pix = pix < M ? pix : M - 1;
+      const int n = (int)(pix / HWo);
+      const int rem = (int)(pix - (long)n * HWo);
+      const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+      iy0[p] = oy * 2 - 1;
+      ix0[p] = ox * 2 - 1;
+      src[p] = in + ((long)(n * a.Hin + iy0[p]) * a.Win + ix0[p]) * a.in_pitch;  // dereferenced only when in bounds
+    }
+    floatx4 acc[NT][NP];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) acc[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < S; ++s) {
+      const int q = 4 * s + g;
+      const int tap = q / CG, cg = q - tap * CG;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const long toff = ((long)ky * a.Win + kx) * a.in_pitch + cg * G;
+      typename Tr<T>::frag af[NT], bf[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        const int iy = iy0[p] + ky, ix = ix0[p] + kx;
+        if (tap < 9 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) v = *reinterpret_cast<const u32x4*>(src[p] + toff);
+        bf[p] = as_frag<T>(v);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w[(s * NT + t) * 64 + lane]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const long pix = pix0 + p * 16 + col;
+      if (pix < M) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
+          if (ch0 < a.Cout) store_quad<T, EPI_PLAIN>(a, pix, ch0, acc[t][p]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Naive direct convolution (one thread per output element, fp32 accumulate).  GPU-side
 // debugging aid selected with lp_config.conv_impl = 1; never the product path.
 // Weights: [Cout][k*k][Cin] as T.
@@ -436,7 +534,19 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
   };
   const int B = batch_hint > 0 ? batch_hint : 1;
 
-  if (k == 3) {
+  direct = (k == 3 && stride == 2);
+  if (direct) {
+    // stride-2: no input staging (see conv3x3s2_direct_kernel); all of K for this block's channel split in LDS
+    NT = pick_nt(ceil_div((long)B * hout * wout, 256));
+    CK = Cin;
+    CGc = Cin / G;
+    nchunks = 1;
+    steps = ceil_div(taps * CGc, 4);
+    while (NT > 1 && (size_t)steps * NT * 1024 > 64 * 1024) --NT;
+    nsplits = ceil_div(tiles_total, NT);
+    lds_bytes = (size_t)steps * NT * 1024;
+    LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv3x3/s2 weights do not fit LDS (%zu B)", lds_bytes);
+  } else if (k == 3) {
     // Tile shape (bwh x bww waves of 4x20 pixels) and K chunk CK (multiple of 8, divides Cin):
     // the halo'd input tile plus the chunk's weight fragments must fit the LDS budget (two
     // workgroups per CU).  Priority: no idle lanes on this map, >= 16-channel chunks, then the
@@ -530,6 +640,14 @@ static void launch3x3(const ConvArgs& a, int stride, dim3 grid, int threads, siz
   }
 }
 
+template <typename T, int NT>
+static void launch_s2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<T, NT, 4>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  hipLaunchKernelGGL((conv3x3s2_direct_kernel<T, NT, 4>), grid, dim3(256), lds, st, a);
+}
+
 template <typename T, int NT, int NP, int EPI>
 static void launch1x1_(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_mfma_kernel<T, NT, NP, EPI>),
@@ -574,7 +692,20 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
     return;
   }
 
-  if (k == 3) {
+  if (direct) {
+    LP_CHECK(!io.m_dyn && !io.x1.base && !io.out_f32, LP_ERR_STATE, "conv3x3/s2: unsupported epilogue");
+    const long ntiles = ((long)a.M + 255) / 256;
+    dim3 grid((unsigned)(ntiles < 4096 ? (ntiles > 0 ? ntiles : 1) : 4096), nsplits);
+#define LP_LD(TT)                                                                                      \
+  switch (NT) {                                                                                        \
+    case 1: launch_s2<TT, 1>(a, grid, lds_bytes, st); break;                                           \
+    case 2: launch_s2<TT, 2>(a, grid, lds_bytes, st); break;                                           \
+    case 3: launch_s2<TT, 3>(a, grid, lds_bytes, st); break;                                           \
+    default: launch_s2<TT, 4>(a, grid, lds_bytes, st); break;                                          \
+  }
+    if (f16) { LP_LD(half_t) } else { LP_LD(float) }
+#undef LP_LD
+  } else if (k == 3) {
     LP_CHECK(!io.m_dyn && !io.x1.base && !io.out_f32, LP_ERR_STATE, "conv3x3: unsupported epilogue");
     const int TH = 4 * bwh, TW = 20 * bww;
     a.tiles_x = ceil_div(a.Wout, TW);

@@ -505,7 +505,7 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         io.in = view(op.in); io.out = view(op.out); io.N = B;
         if (op.res >= 0) io.res = view(op.res);
         c.launch(io, st);
-        kname = std::string(c.impl == IMPL_NAIVE ? "conv_naive" : (c.k == 3 ? "conv3x3_mfma" : "conv1x1_mfma")) + sfx;
+        kname = std::string(c.impl == IMPL_NAIVE ? "conv_naive" : (c.direct ? "conv3x3s2_direct" : (c.k == 3 ? "conv3x3_mfma" : "conv1x1_mfma"))) + sfx;
         break;
       }
       case DetOp::UPSAMPLE:
