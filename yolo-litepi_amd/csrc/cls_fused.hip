@@ -83,8 +83,10 @@ __global__ __launch_bounds__(NW * 64) void shuffle_stage_kernel(const FusedStage
     const int roi0 = grp * a.group;
     const int nvalid = ((R - roi0) < a.group ? (R - roi0) : a.group) * HW;
     const long pix0 = (long)roi0 * HW;
+    // 16-wave workgroups are capped at 128 VGPRs: they keep one fragment set in flight, not two
+    constexpr bool PREF_NEXT = NW < 16;
     u32x4 w1f[SMAX], w2f[SMAX];
-    prefetch_w<SMAX>(a.blk[0].w1, S, wave, lane, active, w1f);
+    if (PREF_NEXT) prefetch_w<SMAX>(a.blk[0].w1, S, wave, lane, active, w1f);
     for (int i = tid; i < FS_PIX * CGX; i += NTHR) {
       const int px = i / CGX, cg = i - px * CGX;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(NW * 64) void shuffle_stage_kernel(const FusedStage
       const FusedBlockW bw = a.blk[b];
       floatx4 acc[4];
       // ---- t1 = relu(W1 . x_hi + b1) -------------------------------------------------------
-      prefetch_w<SMAX>(bw.w2, S, wave, lane, active, w2f);  // lands while pw1 + dw run
+      if (!PREF_NEXT) prefetch_w<SMAX>(bw.w1, S, wave, lane, active, w1f);
+      if (PREF_NEXT) prefetch_w<SMAX>(bw.w2, S, wave, lane, active, w2f);  // lands while pw1 + dw run
       if (active) {
         pw_gemm<SMAX>(w1f, X + bfp * 2, xrow, S, bfp, lane, acc);
         const floatx4 bias = *reinterpret_cast<const floatx4*>(bw.b1 + ch0);
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(NW * 64) void shuffle_stage_kernel(const FusedStage
           *reinterpret_cast<half4*>(T1 + (p * 16 + col) * trow + ch0 * 2) = q;
         }
       }
-      if (b + 1 < a.nblk) prefetch_w<SMAX>(a.blk[b + 1].w1, S, wave, lane, active, w1f);  // for the next block
+      if (PREF_NEXT && b + 1 < a.nblk) prefetch_w<SMAX>(a.blk[b + 1].w1, S, wave, lane, active, w1f);  // for the next block
+      if (!PREF_NEXT) prefetch_w<SMAX>(bw.w2, S, wave, lane, active, w1f);  // re-use the one set: lands during dw
       __syncthreads();
       // ---- t2 = dw3x3(t1) + bd (pad 1, stride 1, inside each ROI's WxW map) -------------------
       for (int i = tid; i < FS_PIX * CGT; i += NTHR) {
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(NW * 64) void shuffle_stage_kernel(const FusedStage
       // ---- y = relu(W2 . t2 + b2); X = shuffle(cat(x_lo, y)) in place --------------------------
       half4 x1v[4];
       if (active) {
-        pw_gemm<SMAX>(w2f, T2, trow, S, bfp, lane, acc);
+        if (PREF_NEXT) pw_gemm<SMAX>(w2f, T2, trow, S, bfp, lane, acc); else pw_gemm<SMAX>(w1f, T2, trow, S, bfp, lane, acc);
 #pragma unroll
         for (int p = 0; p < 4; ++p) x1v[p] = *reinterpret_cast<const half4*>(X + (p * 16 + col) * xrow + ch0 * 2);
       }

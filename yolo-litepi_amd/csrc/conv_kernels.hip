@@ -34,7 +34,8 @@ template <> struct Tr<half_t> {
   static __device__ __forceinline__ floatx4 mma(frag a, frag b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
   }
-  static __device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
+  // x * sigmoid(x) with the hardware reciprocal (1 ulp): an IEEE divide costs ~10 VALU ops per element
+  static __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 };
 template <> struct Tr<float> {
   static constexpr int G = 4;
@@ -48,7 +49,7 @@ template <> struct Tr<float> {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
     return c;
   }
-  static __device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
+  static __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 };
 
 template <typename T> __device__ __forceinline__ float activate(float v, int act) {
@@ -63,11 +64,19 @@ template <typename T> __device__ __forceinline__ typename Tr<T>::frag as_frag(u3
 
 // One lane's 4 consecutive output channels of one pixel: bias, activation, residual,
 // store.  ch0 is the first physical channel of the quad.
-template <typename T, int EPI>
+template <typename T, int ACT> __device__ __forceinline__ float activate_ct(float v) {
+  if (ACT == ACT_SILU) return Tr<T>::silu(v);
+  if (ACT == ACT_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+
+// The activation is a template parameter: a run-time switch here costs three scalar branches
+// per output element (hundreds per wave), more than the MFMAs of a small-K layer.
+template <typename T, int EPI, int ACT>
 __device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0, floatx4 v) {
   const floatx4 b = *reinterpret_cast<const floatx4*>(a.bias + ch0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = activate<T>(v[i] + b[i], a.act);
+  for (int i = 0; i < 4; ++i) v[i] = activate_ct<T, ACT>(v[i] + b[i]);
   if (EPI == EPI_SHUFFLE) {
     // ShuffleNetV2 channel_shuffle(cat(x1, y), 2) fused into the store: logical output
     // channel 2c = x1[c], 2c+1 = y[c]; each half of the output is padded to half_cp.
@@ -101,15 +110,47 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0,
   }
 }
 
+template <typename T, int NT, int ACT>
+__device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const floatx4 (&acc)[NT][5], int n, int ns, int g, int oy,
+                                              int oxb) {
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const int ox = oxb + p * 4;
+    if (oy < a.Hout && ox < a.Wout) {
+      const long pix = (long)(n * a.Hout + oy) * a.Wout + ox;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
+        if (ch0 < a.Cout) store_quad<T, EPI_PLAIN, ACT>(a, pix, ch0, acc[t][p]);
+      }
+    }
+  }
+}
+
+template <typename T, int NT, int NP, int EPI, int ACT>
+__device__ __forceinline__ void epilogue_flat(const ConvArgs& a, const floatx4 (&acc)[NT][NP], long pix0, long M, int ns, int g,
+                                              int col) {
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const long pix = pix0 + p * 16 + col;
+    if (pix < M) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
+        if (ch0 < a.Cout) store_quad<T, EPI, ACT>(a, pix, ch0, acc[t][p]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // 3x3 (pad 1, stride 1|2) implicit GEMM.  One workgroup = bwh x bww waves; each wave owns
 // a 4-row x 20-column strip of output pixels = five 4x4 patches (one MFMA column tile
 // each) x NT 16-channel tiles.  20 divides every level of a 640 input (160/80/40/20), so
 // no lane is wasted there; other sizes are masked.  Per K chunk (CK input channels) the
 // block stages the halo'd input tile and the chunk's weight fragments in LDS.
-// LDS image of the input: [IH][LW] pixels x PS bytes; PS/16 is odd and LW = 4 or 12 (mod
-// 16) so that the 16 pixels of a patch fall on distinct 16-byte slots of the 256-byte bank
-// row for ds_read_b128.
+// LDS image of the input: [IH][LW] pixels x PS bytes, PS and LW chosen by lds_pixel_slots /
+// lds_row_width so that a B-fragment ds_read_b128 (4x4 pixels x 4 K groups) is conflict-free.
 // ------------------------------------------------------------------------------------
 template <typename T, int NT, int STRIDE>
 __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
@@ -127,8 +168,17 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
   const int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
   const int Sc = a.steps_per_chunk, CGc = a.CGc, LW = a.LW, PS = a.PS;
 
-  u32x4* lds_w = reinterpret_cast<u32x4*>(smem);
-  char* lds_in = smem + (size_t)Sc * NT * 1024;
+  // LDS: [tap-offset table 512 B][weight fragments Sc*NT KB][input tile IH x LW x PS]
+  int* lds_toff = reinterpret_cast<int*>(smem);
+  u32x4* lds_w = reinterpret_cast<u32x4*>(smem + 512);
+  char* lds_in = smem + 512 + (size_t)Sc * NT * 1024;
+  if (tid < Sc * 4) {  // byte offset of K group q = tid inside the input tile: (tap, channel group)
+    int tap = tid / CGc;
+    const int cg = tid - tap * CGc;
+    tap = tap > 8 ? 8 : tap;  // K padding slots: weights are zero, read any finite data
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    lds_toff[tid] = (ky * LW + kx) * PS + cg * 16;
+  }
 
   const int ly = wy * 4 + (col >> 2);
   int pbase[5];
@@ -137,6 +187,13 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
     const int lx = wx * 20 + p * 4 + (col & 3);
     pbase[p] = ((ly * STRIDE) * LW + lx * STRIDE) * PS;
   }
+  // input staging map, divisions hoisted: a row of the tile has RI = IW*CGc 16-byte items; the
+  // workgroup covers rpp rows per pass, each thread keeps its (column, channel group)
+  const int RI = IW * CGc;
+  const int rpp = nthr / RI;
+  const int srow = tid / RI, scol = tid - srow * RI;
+  const int six = scol / CGc, scg = scol - six * CGc;
+  const bool stager = rpp > 0 && srow < rpp;
 
   floatx4 acc[NT][5];
 #pragma unroll
@@ -152,48 +209,56 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
     // groups of 8 per thread before any LDS store, so a block pays one or two memory round trips
     // instead of one per element (these layers are latency-bound: one tile per block).
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + ((size_t)(ns * a.nchunks + chunk) * Sc * NT) * 64;
-    const int nW = Sc * NT * 64, nI = IH * IW * CGc;
+    const int nW = Sc * NT * 64;
     const int cbase = chunk * a.CK;
-    for (int r0 = 0; r0 < nW || r0 < nI; r0 += nthr * 8) {
-      u32x4 wv[8], iv[8];
-      int ioff[8];
+    const int gx = ix0 + six;
+    const bool xok = gx >= 0 && gx < a.Win;
+    const int passes = rpp > 0 ? (IH + rpp - 1) / rpp : 0;
+    for (int r0 = 0; r0 * nthr < nW; r0 += 8) {
+      u32x4 wv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = r0 + u * nthr + tid;
+        const int i = (r0 + u) * nthr + tid;
         wv[u] = u32x4{0u, 0u, 0u, 0u};
         if (i < nW) wv[u] = wsrc[i];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = r0 + u * nthr + tid;
+        const int i = (r0 + u) * nthr + tid;
+        if (i < nW) lds_w[i] = wv[u];
+      }
+    }
+    for (int r0 = 0; r0 < passes; r0 += 8) {
+      u32x4 iv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int iy = (r0 + u) * rpp + srow;
         iv[u] = u32x4{0u, 0u, 0u, 0u};
-        ioff[u] = -1;
-        if (i < nI) {
-          const int pix = i / CGc, cg = i - pix * CGc;
-          const int iy = pix / IW, ix = pix - iy * IW;
-          const int gy = iy0 + iy, gx = ix0 + ix;
-          ioff[u] = (iy * LW + ix) * PS + cg * 16;
-          if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
-            iv[u] = *reinterpret_cast<const u32x4*>(in + ((long)(n * a.Hin + gy) * a.Win + gx) * a.in_pitch + cbase + cg * G);
-        }
+        const int gy = iy0 + iy;
+        if (stager && iy < IH && xok && gy >= 0 && gy < a.Hin)
+          iv[u] = *reinterpret_cast<const u32x4*>(in + ((long)(n * a.Hin + gy) * a.Win + gx) * a.in_pitch + cbase + scg * G);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = r0 + u * nthr + tid;
-        if (i < nW) lds_w[i] = wv[u];
+        const int iy = (r0 + u) * rpp + srow;
+        if (stager && iy < IH) *reinterpret_cast<u32x4*>(lds_in + (iy * LW + six) * PS + scg * 16) = iv[u];
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (ioff[u] >= 0) *reinterpret_cast<u32x4*>(lds_in + ioff[u]) = iv[u];
+    }
+    if (rpp == 0) {  // a tile row has more items than threads (fp32, wide chunks): generic path
+      const int nI = IH * IW * CGc;
+      for (int i = tid; i < nI; i += nthr) {
+        const int pix = i / CGc, cg = i - pix * CGc;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = iy0 + iy, gxx = ix0 + ix;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (gy >= 0 && gy < a.Hin && gxx >= 0 && gxx < a.Win)
+          v = *reinterpret_cast<const u32x4*>(in + ((long)(n * a.Hin + gy) * a.Win + gxx) * a.in_pitch + cbase + cg * G);
+        *reinterpret_cast<u32x4*>(lds_in + (iy * LW + ix) * PS + cg * 16) = v;
+      }
     }
     __syncthreads();
     for (int s = 0; s < Sc; ++s) {
-      const int q = 4 * s + g;
-      int tap = q / CGc;
-      const int cg = q - tap * CGc;
-      tap = tap > 8 ? 8 : tap;  // K padding slots: weights are zero, read any finite data
-      const int ky = tap / 3, kx = tap - 3 * ky;
-      const int toff = (ky * LW + kx) * PS + cg * 16;
+      const int toff = lds_toff[4 * s + g];
       typename Tr<T>::frag af[NT], bf[5];
 #pragma unroll
       for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w[(s * NT + t) * 64 + lane]);
@@ -207,18 +272,10 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
   }
 
   const int oy = oy0 + ly;
-#pragma unroll
-  for (int p = 0; p < 5; ++p) {
-    const int ox = ox0 + wx * 20 + p * 4 + (col & 3);
-    if (oy < a.Hout && ox < a.Wout) {
-      const long pix = (long)(n * a.Hout + oy) * a.Wout + ox;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
-        if (ch0 < a.Cout) store_quad<T, EPI_PLAIN>(a, pix, ch0, acc[t][p]);
-      }
-    }
-  }
+  const int oxb = ox0 + wx * 20 + (col & 3);
+  if (a.act == ACT_SILU) epilogue_tile<T, NT, ACT_SILU>(a, acc, n, ns, g, oy, oxb);
+  else if (a.act == ACT_RELU) epilogue_tile<T, NT, ACT_RELU>(a, acc, n, ns, g, oy, oxb);
+  else epilogue_tile<T, NT, ACT_NONE>(a, acc, n, ns, g, oy, oxb);
 }
 
 // ------------------------------------------------------------------------------------
@@ -280,17 +337,9 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
     }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const long pix = pix0 + p * 16 + col;
-      if (pix < M) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
-          if (ch0 < a.Cout) store_quad<T, EPI>(a, pix, ch0, acc[t][p]);
-        }
-      }
-    }
+    if (a.act == ACT_SILU) epilogue_flat<T, NT, NP, EPI, ACT_SILU>(a, acc, pix0, M, ns, g, col);
+    else if (a.act == ACT_RELU) epilogue_flat<T, NT, NP, EPI, ACT_RELU>(a, acc, pix0, M, ns, g, col);
+    else epilogue_flat<T, NT, NP, EPI, ACT_NONE>(a, acc, pix0, M, ns, g, col);
   }
 }
 
@@ -378,17 +427,9 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a)
 #pragma unroll
         for (int p = 0; p < NP; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
     }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const long pix = pix0 + p * 16 + col;
-      if (pix < M) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
-          if (ch0 < a.Cout) store_quad<T, EPI_PLAIN>(a, pix, ch0, acc[t][p]);
-        }
-      }
-    }
+    if (a.act == ACT_SILU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_SILU>(a, acc, pix0, M, ns, g, col);
+    else if (a.act == ACT_RELU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_RELU>(a, acc, pix0, M, ns, g, col);
+    else epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_NONE>(a, acc, pix0, M, ns, g, col);
   }
 }
 
@@ -491,6 +532,24 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restric
 // ====================================================================================
 static size_t elem_size(int prec) { return prec == LP_FP16 ? 2 : 4; }
 
+// LDS geometry of the 3x3 input tile, found by enumerating the ds_read_b128 lane groups
+// ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md, LDS) over every K step: with cg channel groups
+// per pixel, a pixel pitch of p = (smallest value >= cg with p % 4 == 2) 16-byte slots and a row
+// width = 12 (mod 16) pixels make the 4x4-pixel x 4-K-group fragment read conflict-free (4 LDS
+// cycles); the former odd-pitch rule cost 8.  One group per pixel (cg = 1): pitch 1, row = 4 (mod 16).
+static int lds_pixel_slots(int cg) {
+  if (cg <= 1) return 1;
+  int p = cg;
+  while (p % 4 != 2) ++p;
+  return p;
+}
+static int lds_row_width(int iw, int cg) {
+  const int want = cg <= 1 ? 4 : 12;
+  int lw = iw;
+  while (lw % 16 != want) ++lw;
+  return lw;
+}
+
 static void put_elem(std::vector<uint8_t>& buf, size_t idx, int prec, float v) {
   if (prec == LP_FP16) {
     uint16_t h = f32_to_f16(v);
@@ -561,17 +620,15 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
       if (!small_map && (h == 5 || h == 4)) continue;
       const int TH = 4 * h, TW = 20 * w;
       const int IH = (TH - 1) * stride + 3, IW = (TW - 1) * stride + 3;
-      int lw = IW;
-      while (!(lw % 16 == 4 || lw % 16 == 12)) ++lw;
       const int tiles = ceil_div(hout, TH) * ceil_div(wout, TW);
       const int nt = pick_nt((long)tiles * B);
-      int ck_fit = 0;
+      int ck_fit = 0, lw = 0;
       for (int ck = 8; ck <= Cin && ck <= 32; ck += 8) {
         if (Cin % ck) continue;
         const int cgc = ck / G;
-        const int ps = ((cgc % 2 == 0) ? cgc + 1 : cgc + 2) * 16;
-        const size_t lds = (size_t)ceil_div(taps * cgc, 4) * nt * 1024 + (size_t)IH * lw * ps;
-        if (lds <= budget) ck_fit = ck;
+        const int l = lds_row_width(IW, cgc);
+        const size_t lds = 512 + (size_t)ceil_div(taps * cgc, 4) * nt * 1024 + (size_t)IH * l * lds_pixel_slots(cgc) * 16;
+        if (lds <= budget) { ck_fit = ck; lw = l; }
       }
       if (!ck_fit) continue;
       const int util = (int)(100.0 * hout * wout / ((double)tiles * TH * TW));
@@ -583,10 +640,11 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     nsplits = ceil_div(tiles_total, NT);
     const int IH = (4 * bwh - 1) * stride + 3;
     CGc = CK / G;
-    PS = ((CGc % 2 == 0) ? CGc + 1 : CGc + 2) * 16;
+    PS = lds_pixel_slots(CGc) * 16;
     nchunks = Cin / CK;
     steps = ceil_div(taps * CGc, 4);
-    lds_bytes = (size_t)steps * NT * 1024 + (size_t)IH * LW * PS;
+    LP_CHECK(steps * 4 <= 128, LP_ERR_GRAPH, "conv3x3: too many K steps per chunk");
+    lds_bytes = 512 + (size_t)steps * NT * 1024 + (size_t)IH * LW * PS;
     LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv3x3 tile does not fit LDS (%zu B)", lds_bytes);
   } else {
     NT = pick_nt(ceil_div((long)B * hout * wout, 256));
