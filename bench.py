@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=320, help="images in the CPU baseline sample")
     ap.add_argument("--profile-steps", type=int, default=3)
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="independent pipeline handles (own stream + activation buffers) the steps rotate over, so "
                          "consecutive steps overlap on the GPU")
     ap.add_argument("--dump-profile", default="", help="write the per-launch profile of the roofline pass to this JSON file")

@@ -3,6 +3,7 @@
 // model plans; every pipeline stage runs on the GPU -- there is no CPU fallback anywhere.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "classifier.h"
 #include "common.h"
@@ -573,8 +574,25 @@ int lp_test_conv(lp_handle* h, int impl, const float* x, int N, int Cin, int H, 
   io.in = View{dx.p, Cin, Cin, H, W};
   io.out = View{dy.p, Cout, Cout, Ho, Wo};
   if (res) { to_dev(res, Cout, Ho, Wo, dr); io.res = View{dr.p, Cout, Cout, Ho, Wo}; }
+  // diagnostic: LITEPI_STAMPS=<file> dumps 16 clock stamps per workgroup of a (warm) second launch
+  const char* stamp_path = getenv("LITEPI_STAMPS");
   L.launch(io, h->stream);
   LP_HIP(hipStreamSynchronize(h->stream));
+  if (stamp_path && *stamp_path) {
+    const size_t nst = (size_t)1 << 22;
+    DevBuf ds;
+    ds.alloc(nst * 8);
+    io.stamps = ds.as<unsigned long long>();
+    L.launch(io, h->stream);
+    LP_HIP(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> hs(nst);
+    LP_HIP(hipMemcpy(hs.data(), ds.p, nst * 8, hipMemcpyDeviceToHost));
+    size_t used = nst;
+    while (used > 16 && hs[used - 16] == 0 && hs[used - 4] == 0) used -= 16;
+    FILE* f = fopen(stamp_path, "wb");
+    if (f) { fwrite(hs.data(), 8, used, f); fclose(f); }
+    io.stamps = nullptr;
+  }
   std::vector<uint8_t> raw((size_t)N * Ho * Wo * Cout * es);
   LP_HIP(hipMemcpy(raw.data(), dy.p, raw.size(), hipMemcpyDeviceToHost));
   const size_t npix = (size_t)N * Ho * Wo;

@@ -109,6 +109,7 @@ struct ConvArgs {
   // shuffle epilogue
   int half_c, half_cp;  // logical / physical channels of one half of the output
   int out_f32;          // store fp32 regardless of T (classifier logits)
+  unsigned long long* stamps;  // diagnostic only (lp_test_conv + LITEPI_STAMPS): 16 clock stamps per workgroup
 };
 
 enum ConvImpl { IMPL_MFMA = 0, IMPL_NAIVE = 1 };

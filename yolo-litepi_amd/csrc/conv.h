@@ -10,6 +10,7 @@ struct ConvIO {
   const int* m_dyn = nullptr;  // device scalar item count (classifier); M = *m_dyn * out.H * out.W
   int half_c = 0, half_cp = 0; // shuffle epilogue geometry (x1.base != nullptr)
   int out_f32 = 0;
+  unsigned long long* stamps = nullptr;  // diagnostic (see ConvArgs::stamps)
 };
 
 // One Convolution(+bias)(+activation)(+residual) layer with its device weights, packed for

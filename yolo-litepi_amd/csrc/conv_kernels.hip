@@ -26,6 +26,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum { EPI_PLAIN = 0, EPI_SHUFFLE = 1 };
 
+// diagnostic phase stamps (never enabled on the product path: a.stamps is null)
+#define LP_STAMP(k)                                                                                   \
+  if (a.stamps && threadIdx.x == 0)                                                                   \
+    a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (k)] = \
+        (k) == 0 ? wall_clock64() : clock64();
+
 template <typename T> struct Tr;
 template <> struct Tr<half_t> {
   static constexpr int G = 8;  // channels per 16-byte K group
@@ -110,34 +116,100 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0,
   }
 }
 
+// One lane's 4*NT consecutive output channels of one pixel (EPI_PLAIN, T output): bias comes from
+// registers (hoisted out of the epilogue: 20 dependent global loads per lane otherwise), fp16
+// results leave as 16-byte stores (two channel quads at a time).
 template <typename T, int NT, int ACT>
-__device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const floatx4 (&acc)[NT][5], int n, int ns, int g, int oy,
-                                              int oxb) {
+__device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chbase, const floatx4 (&v)[NT],
+                                           const floatx4 (&bias)[NT]) {
+  T* o = reinterpret_cast<T*>(a.out) + pix * a.out_pitch + chbase;
+  const T* r = a.res ? reinterpret_cast<const T*>(a.res) + pix * a.res_pitch + chbase : nullptr;
+  if constexpr (sizeof(T) == 2) {
 #pragma unroll
-  for (int p = 0; p < 5; ++p) {
-    const int ox = oxb + p * 4;
-    if (oy < a.Hout && ox < a.Wout) {
-      const long pix = (long)(n * a.Hout + oy) * a.Wout + ox;
+    for (int t = 0; t + 1 < NT; t += 2) {
+      if (chbase + t * 4 < a.Cout) {
+        half8 q;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
-        if (ch0 < a.Cout) store_quad<T, EPI_PLAIN, ACT>(a, pix, ch0, acc[t][p]);
+        for (int i = 0; i < 4; ++i) {
+          q[i] = (half_t)activate_ct<T, ACT>(v[t][i] + bias[t][i]);
+          q[4 + i] = (half_t)activate_ct<T, ACT>(v[t + 1][i] + bias[t + 1][i]);
+        }
+        if (r) {
+          const half8 rr = *reinterpret_cast<const half8*>(r + t * 4);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) q[i] = (half_t)((float)q[i] + (float)rr[i]);
+        }
+        *reinterpret_cast<half8*>(o + t * 4) = q;
+      }
+    }
+    if (NT & 1) {
+      constexpr int t = NT - 1;
+      if (chbase + t * 4 < a.Cout) {
+        half4 q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = (half_t)activate_ct<T, ACT>(v[t][i] + bias[t][i]);
+        if (r) {
+          const half4 rr = *reinterpret_cast<const half4*>(r + t * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) q[i] = (half_t)((float)q[i] + (float)rr[i]);
+        }
+        *reinterpret_cast<half4*>(o + t * 4) = q;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (chbase + t * 4 < a.Cout) {
+        floatx4 q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = activate_ct<T, ACT>(v[t][i] + bias[t][i]);
+        if (r) {
+          const floatx4 rr = *reinterpret_cast<const floatx4*>(r + t * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) q[i] += rr[i];
+        }
+        *reinterpret_cast<floatx4*>(o + t * 4) = q;
       }
     }
   }
 }
 
+// the residual is added AFTER the activation (C2f bottleneck: x + silu(conv(..))); the fp16 variant
+// above rounds the activated value to fp16 before the add, as a separate add kernel would
+template <typename T, int NT, int ACT>
+__device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const floatx4 (&acc)[NT][5], const floatx4 (&bias)[NT], int n,
+                                              int ns, int g, int oy, int oxb) {
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const int ox = oxb + p * 4;
+    if (oy < a.Hout && ox < a.Wout) {
+      const long pix = (long)(n * a.Hout + oy) * a.Wout + ox;
+      floatx4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = acc[t][p];
+      store_lane<T, NT, ACT>(a, pix, ns * 16 * NT + g * 4 * NT, v, bias);
+    }
+  }
+}
+
 template <typename T, int NT, int NP, int EPI, int ACT>
-__device__ __forceinline__ void epilogue_flat(const ConvArgs& a, const floatx4 (&acc)[NT][NP], long pix0, long M, int ns, int g,
-                                              int col) {
+__device__ __forceinline__ void epilogue_flat(const ConvArgs& a, const floatx4 (&acc)[NT][NP], const floatx4 (&bias)[NT],
+                                              long pix0, long M, int ns, int g, int col) {
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const long pix = pix0 + p * 16 + col;
     if (pix < M) {
+      if (EPI == EPI_PLAIN && !a.out_f32) {
+        floatx4 v[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
-        if (ch0 < a.Cout) store_quad<T, EPI, ACT>(a, pix, ch0, acc[t][p]);
+        for (int t = 0; t < NT; ++t) v[t] = acc[t][p];
+        store_lane<T, NT, ACT>(a, pix, ns * 16 * NT + g * 4 * NT, v, bias);
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int ch0 = ns * 16 * NT + g * 4 * NT + t * 4;
+          if (ch0 < a.Cout) store_quad<T, EPI, ACT>(a, pix, ch0, acc[t][p]);
+        }
       }
     }
   }
@@ -195,6 +267,9 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
   const int six = scol / CGc, scg = scol - six * CGc;
   const bool stager = rpp > 0 && srow < rpp;
 
+  floatx4 bias_r[NT];  // this lane's 4*NT output channels: bias hoisted out of the epilogue
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bias_r[t] = *reinterpret_cast<const floatx4*>(a.bias + ns * 16 * NT + g * 4 * NT + t * 4);
   floatx4 acc[NT][5];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -202,8 +277,11 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
     for (int p = 0; p < 5; ++p) acc[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   const T* in = reinterpret_cast<const T*>(a.in);
+  LP_STAMP(0)
+  LP_STAMP(1)
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     if (chunk) __syncthreads();
+    if (chunk < 2) { LP_STAMP(2 + chunk * 4) }
     // Stage this chunk: weight fragments (already in fragment order, 16 B per lane) and the
     // halo'd input tile (zero outside the image = the conv's zero padding).  Loads are issued in
     // groups of 8 per thread before any LDS store, so a block pays one or two memory round trips
@@ -256,7 +334,9 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
         *reinterpret_cast<u32x4*>(lds_in + (iy * LW + ix) * PS + cg * 16) = v;
       }
     }
+    if (chunk < 2) { LP_STAMP(3 + chunk * 4) }
     __syncthreads();
+    if (chunk < 2) { LP_STAMP(4 + chunk * 4) }
     for (int s = 0; s < Sc; ++s) {
       const int toff = lds_toff[4 * s + g];
       typename Tr<T>::frag af[NT], bf[5];
@@ -269,13 +349,17 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < 5; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
     }
+    if (chunk < 2) { LP_STAMP(5 + chunk * 4) }
   }
+  LP_STAMP(10)
 
   const int oy = oy0 + ly;
   const int oxb = ox0 + wx * 20 + (col & 3);
-  if (a.act == ACT_SILU) epilogue_tile<T, NT, ACT_SILU>(a, acc, n, ns, g, oy, oxb);
-  else if (a.act == ACT_RELU) epilogue_tile<T, NT, ACT_RELU>(a, acc, n, ns, g, oy, oxb);
-  else epilogue_tile<T, NT, ACT_NONE>(a, acc, n, ns, g, oy, oxb);
+  if (a.act == ACT_SILU) epilogue_tile<T, NT, ACT_SILU>(a, acc, bias_r, n, ns, g, oy, oxb);
+  else if (a.act == ACT_RELU) epilogue_tile<T, NT, ACT_RELU>(a, acc, bias_r, n, ns, g, oy, oxb);
+  else epilogue_tile<T, NT, ACT_NONE>(a, acc, bias_r, n, ns, g, oy, oxb);
+  LP_STAMP(11)
+  if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 12] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------
@@ -304,6 +388,9 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
   for (int i = tid; i < S * NT * 64; i += 256) lds_w[i] = wsrc[i];
   __syncthreads();
   const T* in = reinterpret_cast<const T*>(a.in);
+  floatx4 bias_r[NT];  // this lane's 4*NT output channels: bias hoisted out of the epilogue
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bias_r[t] = *reinterpret_cast<const floatx4*>(a.bias + ns * 16 * NT + g * 4 * NT + t * 4);
 
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long pix0 = (tile * 4 + wave) * 16 * NP;
@@ -337,9 +424,9 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
     }
-    if (a.act == ACT_SILU) epilogue_flat<T, NT, NP, EPI, ACT_SILU>(a, acc, pix0, M, ns, g, col);
-    else if (a.act == ACT_RELU) epilogue_flat<T, NT, NP, EPI, ACT_RELU>(a, acc, pix0, M, ns, g, col);
-    else epilogue_flat<T, NT, NP, EPI, ACT_NONE>(a, acc, pix0, M, ns, g, col);
+    if (a.act == ACT_SILU) epilogue_flat<T, NT, NP, EPI, ACT_SILU>(a, acc, bias_r, pix0, M, ns, g, col);
+    else if (a.act == ACT_RELU) epilogue_flat<T, NT, NP, EPI, ACT_RELU>(a, acc, bias_r, pix0, M, ns, g, col);
+    else epilogue_flat<T, NT, NP, EPI, ACT_NONE>(a, acc, bias_r, pix0, M, ns, g, col);
   }
 }
 
@@ -384,6 +471,9 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a)
   __syncthreads();
   const T* in = reinterpret_cast<const T*>(a.in);
   const int HWo = a.Hout * a.Wout;
+  floatx4 bias_r[NT];  // this lane's 4*NT output channels: bias hoisted out of the epilogue
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bias_r[t] = *reinterpret_cast<const floatx4*>(a.bias + ns * 16 * NT + g * 4 * NT + t * 4);
 
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long pix0 = (tile * 4 + wave) * 16 * NP;
@@ -427,9 +517,9 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a)
 #pragma unroll
         for (int p = 0; p < NP; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
     }
-    if (a.act == ACT_SILU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_SILU>(a, acc, pix0, M, ns, g, col);
-    else if (a.act == ACT_RELU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_RELU>(a, acc, pix0, M, ns, g, col);
-    else epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_NONE>(a, acc, pix0, M, ns, g, col);
+    if (a.act == ACT_SILU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_SILU>(a, acc, bias_r, pix0, M, ns, g, col);
+    else if (a.act == ACT_RELU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_RELU>(a, acc, bias_r, pix0, M, ns, g, col);
+    else epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_NONE>(a, acc, bias_r, pix0, M, ns, g, col);
   }
 }
 
@@ -733,7 +823,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
   a.M = io.N * io.out.H * io.out.W; a.pix_per_item = io.out.H * io.out.W;
   a.CK = CK; a.nchunks = nchunks; a.steps_per_chunk = steps; a.CGc = CGc; a.LW = LW; a.PS = PS;
   a.bwh = bwh; a.bww = bww; a.steps = steps; a.nsplit_tiles = NT;
-  a.half_c = io.half_c; a.half_cp = io.half_cp; a.out_f32 = io.out_f32;
+  a.half_c = io.half_c; a.half_cp = io.half_cp; a.out_f32 = io.out_f32; a.stamps = io.stamps;
   LP_CHECK(io.in.C == Cin, LP_ERR_STATE, "conv input view has %d channels, layer expects %d", io.in.C, Cin);
   LP_CHECK(io.x1.base || io.out.C >= Cout || io.out_f32, LP_ERR_STATE, "conv output view too narrow (%d < %d)", io.out.C, Cout);
   LP_CHECK((io.in.pitch % 8) == 0 && (io.out.pitch % 4) == 0, LP_ERR_STATE, "unaligned channel pitch");
