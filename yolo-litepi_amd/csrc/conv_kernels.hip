@@ -224,10 +224,13 @@ __device__ __forceinline__ void epilogue_flat(const ConvArgs& a, const floatx4 (
 // LDS image of the input: [IH][LW] pixels x PS bytes, PS and LW chosen by lds_pixel_slots /
 // lds_row_width so that a B-fragment ds_read_b128 (4x4 pixels x 4 K groups) is conflict-free.
 // ------------------------------------------------------------------------------------
+// second launch-bound = waves per SIMD the register allocation must allow: the narrow variants run many
+// short-lived workgroups and live off occupancy (4 waves/SIMD = 128 VGPRs), the wide ones off MFMA tiles
 template <typename T, int NT, int STRIDE>
-__global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(320, (NT == 1 ? 4 : (NT == 2 ? 3 : 2))) void conv3x3_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
+  constexpr int SB = 4;  // staging loads in flight per thread per round (registers vs. round trips)
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, col = lane & 15;
@@ -292,24 +295,24 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
     const int gx = ix0 + six;
     const bool xok = gx >= 0 && gx < a.Win;
     const int passes = rpp > 0 ? (IH + rpp - 1) / rpp : 0;
-    for (int r0 = 0; r0 * nthr < nW; r0 += 8) {
-      u32x4 wv[8];
+    for (int r0 = 0; r0 * nthr < nW; r0 += SB) {
+      u32x4 wv[SB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < SB; ++u) {
         const int i = (r0 + u) * nthr + tid;
         wv[u] = u32x4{0u, 0u, 0u, 0u};
         if (i < nW) wv[u] = wsrc[i];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < SB; ++u) {
         const int i = (r0 + u) * nthr + tid;
         if (i < nW) lds_w[i] = wv[u];
       }
     }
-    for (int r0 = 0; r0 < passes; r0 += 8) {
-      u32x4 iv[8];
+    for (int r0 = 0; r0 < passes; r0 += SB) {
+      u32x4 iv[SB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < SB; ++u) {
         const int iy = (r0 + u) * rpp + srow;
         iv[u] = u32x4{0u, 0u, 0u, 0u};
         const int gy = iy0 + iy;
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(320) void conv3x3_mfma_kernel(const ConvArgs a) {
           iv[u] = *reinterpret_cast<const u32x4*>(in + ((long)(n * a.Hin + gy) * a.Win + gx) * a.in_pitch + cbase + scg * G);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < SB; ++u) {
         const int iy = (r0 + u) * rpp + srow;
         if (stager && iy < IH) *reinterpret_cast<u32x4*>(lds_in + (iy * LW + six) * PS + scg * 16) = iv[u];
       }
