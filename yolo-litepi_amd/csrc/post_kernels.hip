@@ -334,11 +334,11 @@ void launch_roi_index(const int* counts, const RoiTable& t, int N, int max_det, 
 // ------------------------------------------------------------------------------------
 #define RR_THREADS 1024  /* 16 waves: the byte gathers are latency-bound, TLP hides them */
 #define RR_PRECISION_BITS 22
-// "small" variant: ROI sides <= 256 px (support <= 4 -> at most 9 taps); the whole
+// "small" variant: ROI sides <= 384 px (support <= 6 -> at most 13 taps); the whole
 // horizontally-resampled crop [in_h][S][3] lives in LDS, so a ROI costs two barriers.
 // "large" variant: sides up to 4096 px (129 taps), one output row at a time.
-#define RR_SMALL_SIDE 256
-#define RR_SMALL_K 9
+#define RR_SMALL_SIDE 384
+#define RR_SMALL_K 13
 #define RR_LARGE_K 129
 
 size_t roi_resize_lds_bytes() { return (size_t)2 * 64 * RR_LARGE_K * 4 + 4 * 64 * 4 + (size_t)RR_LARGE_K * 64 * 3 + 64; }
