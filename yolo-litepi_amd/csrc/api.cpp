@@ -335,11 +335,15 @@ void enqueue_classify(lp_handle* h, const uint8_t* src, int B, const int* counts
   if (prof) prof->begin(h->stream);
   launch_roi_resize(r, h->stream);
   if (prof) prof->end(h->stream, "roi_resize_pil", "roi_resize", 0.0, (double)r.S * r.S * 3 * 2, true);
-  h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof);
-  if (prof) prof->begin(h->stream);
-  launch_softmax_argmax(h->cls->logits(), h->cls->logits_pitch(), h->cls->num_classes(), probs, ids, conf, dets, h->cfg.max_det,
-                        &tab, tab.total, h->max_rois, h->stream);
-  if (prof) prof->end(h->stream, "softmax_argmax", "softmax", 0.0, (double)h->cls->num_classes() * 8, true);
+  Classifier::Post post;
+  post.probs = probs; post.ids = ids; post.dets = dets; post.max_det = h->cfg.max_det; post.roi_img = tab.img; post.roi_slot = tab.slot;
+  h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof, &post);
+  if (!h->cls->fused_head()) {
+    if (prof) prof->begin(h->stream);
+    launch_softmax_argmax(h->cls->logits(), h->cls->logits_pitch(), h->cls->num_classes(), probs, ids, conf, dets, h->cfg.max_det,
+                          &tab, tab.total, h->max_rois, h->stream);
+    if (prof) prof->end(h->stream, "softmax_argmax", "softmax", 0.0, (double)h->cls->num_classes() * 8, true);
+  }
 }
 
 // upload B host images of individual sizes into d_src; returns their geometry
@@ -509,9 +513,12 @@ int lp_classify(lp_handle* h, const uint8_t* const* rois, const int* hs, const i
   r.src = h->d_src.as<uint8_t>(); r.geom = h->d_geom.as<ImgGeom>(); r.rects = d_rects_tmp.as<int>(); r.tab = tab;
   r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = 1; r.S = h->cfg.cls_input;
   launch_roi_resize(r, h->stream);
-  h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof);
-  launch_softmax_argmax(h->cls->logits(), h->cls->logits_pitch(), h->cls->num_classes(), h->d_probs.as<float>(), h->d_ids.as<int>(),
-                        nullptr, nullptr, h->cfg.max_det, nullptr, tab.total, h->max_rois, h->stream);
+  Classifier::Post post;
+  post.probs = h->d_probs.as<float>(); post.ids = h->d_ids.as<int>();
+  h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof, &post);
+  if (!h->cls->fused_head())
+    launch_softmax_argmax(h->cls->logits(), h->cls->logits_pitch(), h->cls->num_classes(), h->d_probs.as<float>(), h->d_ids.as<int>(),
+                          nullptr, nullptr, h->cfg.max_det, nullptr, tab.total, h->max_rois, h->stream);
   LP_HIP(hipMemcpyAsync(ids, h->d_ids.p, (size_t)R * 4, hipMemcpyDeviceToHost, h->stream));
   LP_HIP(hipMemcpyAsync(probs, h->d_probs.p, (size_t)R * h->cls->num_classes() * 4, hipMemcpyDeviceToHost, h->stream));
   LP_HIP(hipStreamSynchronize(h->stream));

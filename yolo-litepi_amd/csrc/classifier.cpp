@@ -229,6 +229,12 @@ void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
     std::vector<float> w, b;
     expand_pw(f, lin, 0, 1024, w, b, lin.Cp(), 0);
     conv5_ = add_pw("conv5.0", w, b, lin.Cp(), 1024, ACT_RELU, H);
+    if (use_fused_) {
+      LP_CHECK(H == 2, LP_ERR_STATE, "fused head expects a 2x2 stage-4 map");
+      head_cin_p_ = lin.Cp();
+      upload_u16(head_w5_, pack_fused_pw(w, 1024, lin.Cp()));
+      upload_f32(head_b5_, b);
+    }
     alloc_act(a_conv5_, 1024, H, H);
     alloc_act(a_mean_, 1024, 1, 1);
     const NamedTensor& fw = need(sd, "fc.weight");
@@ -244,12 +250,22 @@ void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
       b2[o] = fb.data[o];
     }
     fc_ = add_pw("fc", w2, b2, 1024, cp, ACT_NONE, 1);
+    if (use_fused_) {
+      head_nc_p_ = round_up(ncls_, 16);
+      std::vector<float> wf((size_t)head_nc_p_ * 1024, 0.f), bf2(head_nc_p_, 0.f);
+      for (int o = 0; o < ncls_; ++o) {
+        memcpy(&wf[(size_t)o * 1024], fw.data + (size_t)o * 1024, 1024 * 4);
+        bf2[o] = fb.data[o];
+      }
+      upload_u16(head_wfc_, pack_fused_pw(wf, head_nc_p_, 1024));
+      upload_f32(head_bfc_, bf2);
+    }
     d_logits_.alloc((size_t)maxR_ * lpitch_ * 4);
   }
   loaded_ = true;
 }
 
-void Classifier::forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Profiler* prof) {
+void Classifier::forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Profiler* prof, const Post* post) {
   LP_CHECK(loaded_, LP_ERR_STATE, "classifier not loaded");
   const size_t es = prec_ == LP_FP16 ? 2 : 4;
   const char* sfx = prec_ == LP_FP16 ? "_f16" : "_f32";
@@ -336,6 +352,24 @@ void Classifier::forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Pro
       }
       x = out;
     }
+  }
+  if (use_fused_) {
+    FusedHeadArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.in = x.base; ha.m_dyn = d_R; ha.in_pitch = x.pitch; ha.cin_p = head_cin_p_;
+    ha.w5 = head_w5_.as<u32x4_t>(); ha.b5 = head_b5_.as<float>();
+    ha.wfc = head_wfc_.as<u32x4_t>(); ha.bfc = head_bfc_.as<float>();
+    ha.nc = ncls_; ha.nc_p = head_nc_p_;
+    ha.logits = d_logits_.as<float>(); ha.logits_pitch = lpitch_;
+    if (post) {
+      ha.probs = post->probs; ha.ids = post->ids; ha.dets = post->dets; ha.max_det = post->max_det;
+      ha.roi_img = post->roi_img; ha.roi_slot = post->roi_slot;
+    }
+    P0();
+    launch_fused_head(ha, maxR_, st);
+    P1("cls_head_fused", "conv5+mean+fc+softmax", 4.0 * 2.0 * head_cin_p_ * 1024 + 2.0 * 1024 * head_nc_p_,
+       4.0 * head_cin_p_ * esd + ncls_ * 4.0);
+    return;
   }
   run_pw(conv5_, x, act_view(a_conv5_), nullptr, 0, 0, 0);
   P0();

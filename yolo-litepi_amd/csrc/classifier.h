@@ -25,7 +25,11 @@ class Classifier {
   int logits_pitch() const { return lpitch_; }
   const float* logits() const { return d_logits_.as<float>(); }
   // rgb: device uint8 [R,S,S,3]; d_R: device ROI count.  Leaves fp32 logits [R, logits_pitch()].
-  void forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Profiler* prof);
+  // With the fused head (fp16) softmax/arg-max/scatter happen inside forward(); post describes where
+  // the results go.  fused_head() tells the caller whether it still has to run softmax itself.
+  struct Post { float* probs = nullptr; int* ids = nullptr; lp_det* dets = nullptr; int max_det = 0; const int* roi_img = nullptr; const int* roi_slot = nullptr; };
+  bool fused_head() const { return use_fused_; }
+  void forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Profiler* prof, const Post* post = nullptr);
 
  private:
   struct DwLayer { DevBuf w, b; int C = 0, stride = 1; std::string name; };
@@ -56,6 +60,8 @@ class Classifier {
   struct FusedW { DevBuf w1, b1, dw, dwb, w2, b2; };
   std::vector<FusedW> fused_[3];
   bool use_fused_ = false;
+  DevBuf head_w5_, head_b5_, head_wfc_, head_bfc_;
+  int head_cin_p_ = 0, head_nc_p_ = 0;
 };
 
 }  // namespace lp

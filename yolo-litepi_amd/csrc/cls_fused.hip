@@ -202,6 +202,155 @@ void launch_fused_stage(const FusedStageArgs& a, int max_items, hipStream_t st) 
   LP_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------
+// Fused classifier head (fp16): conv5 1x1 (Cin -> 1024) + ReLU, x.mean([2,3]), fc, softmax,
+// arg-max and the scatter of (class, confidence) into the detection records -- reference
+// e2e.py:393-396 (torchvision conv5 / mean / fc) + e2e.py:525-526.  One 16-wave workgroup owns
+// 16 ROIs (64 pixels of the 2x2 stage-4 map); activations stay in LDS, the 1024-channel conv5
+// output never exists in memory: each wave reduces its accumulator tiles over the 4 pixels of a ROI
+// with two lane shuffles and writes the fp16 mean straight into the fc operand image.
+// ------------------------------------------------------------------------------------
+#define FH_ROIS 16
+__global__ __launch_bounds__(1024) void cls_head_kernel(const FusedHeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int cin = a.cin_p;                 // physical input channels (two padded halves)
+  const int xrow = cin * 2 + 16;
+  const int mrow = 1024 * 2 + 16;
+  char* X = smem;                          // [64 px][cin] fp16
+  char* Mn = X + 64 * xrow;                // [16 rois][1024] fp16 (mean of relu(conv5))
+  float* LG = reinterpret_cast<float*>(Mn + FH_ROIS * mrow);  // [16 rois][nc_p] fp32 logits
+  const int S5 = (cin + 31) / 32, CGX = cin / 8;
+  const int R = *a.m_dyn;
+  const int ngroups = (R + FH_ROIS - 1) / FH_ROIS;
+  const half_t* in = reinterpret_cast<const half_t*>(a.in);
+
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int roi0 = grp * FH_ROIS;
+    const int nroi = (R - roi0) < FH_ROIS ? (R - roi0) : FH_ROIS;
+    for (int i = tid; i < 64 * CGX; i += 1024) {
+      const int px = i / CGX, cg = i - px * CGX;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (px < nroi * 4) v = *reinterpret_cast<const u32x4*>(in + ((long)roi0 * 4 + px) * a.in_pitch + cg * 8);
+      *reinterpret_cast<u32x4*>(X + px * xrow + cg * 16) = v;
+    }
+    __syncthreads();
+    // ---- conv5: 64 output tiles of 16 channels, 4 per wave; mean over the 4 pixels of each ROI -----
+#pragma unroll 1
+    for (int tq = 0; tq < 4; ++tq) {
+      const int t = wave * 4 + tq;
+      floatx4 acc[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < S5; s0 += 8) {
+        u32x4 af[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          af[u] = u32x4{0u, 0u, 0u, 0u};
+          if (s0 + u < S5) af[u] = a.w5[((size_t)t * S5 + s0 + u) * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s = s0 + u;
+          if (s < S5) {
+            const half8 av = __builtin_bit_cast(half8, af[u]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              u32x4 v = u32x4{0u, 0u, 0u, 0u};
+              if ((4 * s + g) * 8 < cin) v = *reinterpret_cast<const u32x4*>(X + (p * 16 + col) * xrow + (4 * s + g) * 16);
+              acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(half8, v), acc[p], 0, 0, 0);
+            }
+          }
+        }
+      }
+      const int ch0 = t * 16 + 4 * g;
+      const floatx4 bias = *reinterpret_cast<const floatx4*>(a.b5 + ch0);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        half4 q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = fmaxf(acc[p][i] + bias[i], 0.f);
+          v += __shfl_xor(v, 1);   // pixels 4r..4r+3 of ROI r sit on 4 adjacent lanes
+          v += __shfl_xor(v, 2);
+          q[i] = (half_t)(v * 0.25f);
+        }
+        if ((col & 3) == 0) *reinterpret_cast<half4*>(Mn + (p * 4 + (col >> 2)) * mrow + ch0 * 2) = q;
+      }
+    }
+    __syncthreads();
+    // ---- fc: logits[roi][class] = Wfc . mean + b, one 16-class tile per wave ------------------------
+    const int Tfc = a.nc_p / 16;
+    if (wave < Tfc) {
+      floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < 32; s0 += 8) {
+        u32x4 af[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) af[u] = a.wfc[((size_t)wave * 32 + s0 + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(Mn + col * mrow + (4 * (s0 + u) + g) * 16);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, af[u]), __builtin_bit_cast(half8, v), acc, 0, 0, 0);
+        }
+      }
+      const int c0 = wave * 16 + 4 * g;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) LG[col * a.nc_p + c0 + i] = acc[i] + a.bfc[c0 + i];
+    }
+    __syncthreads();
+    // ---- softmax + arg-max, one wave per ROI ------------------------------------------------------------
+    if (wave < nroi) {
+      const int r = roi0 + wave;
+      const float* l = LG + wave * a.nc_p;
+      float mx = -INFINITY;
+      for (int c = lane; c < a.nc; c += 64) mx = fmaxf(mx, l[c]);
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float sum = 0.f;
+      for (int c = lane; c < a.nc; c += 64) sum += expf(l[c] - mx);
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      float best = -1.f;
+      int best_c = 0x7fffffff;
+      for (int c = lane; c < a.nc; c += 64) {
+        const float pr = expf(l[c] - mx) / sum;
+        if (a.probs) a.probs[(long)r * a.nc + c] = pr;
+        if (pr > best) { best = pr; best_c = c; }
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oc = __shfl_xor(best_c, o);
+        if (ob > best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+      }
+      if (lane == 0) {
+        if (a.ids) a.ids[r] = best_c;
+        if (a.dets) {
+          lp_det* d = a.dets + (long)a.roi_img[r] * a.max_det + a.roi_slot[r];
+          d->cls_class = best_c;
+          d->cls_conf = best;
+        }
+      }
+      if (a.logits)
+        for (int c = lane; c < a.nc; c += 64) a.logits[(long)r * a.logits_pitch + c] = l[c];
+    }
+    __syncthreads();
+  }
+}
+
+size_t fused_head_lds_bytes(int cin_p, int nc_p) { return (size_t)64 * (cin_p * 2 + 16) + (size_t)FH_ROIS * (1024 * 2 + 16) + (size_t)FH_ROIS * nc_p * 4; }
+
+void launch_fused_head(const FusedHeadArgs& a, int max_items, hipStream_t st) {
+  const size_t lds = fused_head_lds_bytes(a.cin_p, a.nc_p);
+  LP_CHECK(lds <= 160 * 1024 && a.nc_p % 16 == 0 && a.nc_p <= 256 && a.cin_p % 8 == 0, LP_ERR_STATE,
+           "fused classifier head: unsupported geometry (cin %d, classes %d)", a.cin_p, a.nc);
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_head_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  int groups = (max_items + FH_ROIS - 1) / FH_ROIS;
+  if (groups > 512) groups = 512;
+  hipLaunchKernelGGL(cls_head_kernel, dim3(groups), dim3(1024), lds, st, a);
+  LP_HIP(hipGetLastError());
+}
+
 // A fragments of a pointwise conv over PHYSICAL channels: [tile][step][lane][8 halfs];
 // tile t row m = output channel 16t+m, K group q = 4s+g = input channels [8q, 8q+8).
 std::vector<uint16_t> pack_fused_pw(const std::vector<float>& w_phys, int cout_p, int cin_p) {
