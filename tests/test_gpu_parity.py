@@ -438,3 +438,63 @@ def test_empty_and_error_behaviour(synth_models, tmp_path):
         clf.engine.close()
     with pytest.raises(ValueError):
         PyTorchClassifier("x", "resnet18")
+
+
+# ---------------------------------------------------------------------------- real weights (optional)
+_REF_STAGE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+_REAL = (os.path.join(_REF_STAGE, "yolo_plus_v1.param"), os.path.join(_REF_STAGE, "yolo_plus_v1.bin"))
+
+
+@pytest.mark.skipif(not all(os.path.exists(p) for p in _REAL), reason="reference v1 model not staged (oracle/_ref)")
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_detector_real_v1_weights(prec):
+    """The reference's exported YOLO-LitePi v1 (real weights, staged by __graft_entry__.build() when the
+    reference checkout exists; never committed): fp32 out0 within 1e-3 of the CPU oracle."""
+    from litepi import Engine
+    rng = np.random.default_rng(7)
+    imgs = rng.integers(0, 256, (2, 640, 640, 3), dtype=np.uint8)
+    imgs[1, 200:280, 300:380] = (20, 30, 220)  # a red patch, just to vary statistics
+    ref, _ = _oracle_out0(_REAL[0], _REAL[1], imgs)
+    e = Engine(precision=prec, max_batch=2)
+    try:
+        e.load_detector(*_REAL)
+        assert abs(e.det_macs - 1418713600) < 1
+        got = e.detect_raw(imgs)
+    finally:
+        e.close()
+    err_b = np.abs(got[:, :4] - ref[:, :4])
+    err_s = np.abs(got[:, 4] - ref[:, 4])
+    print(f"real v1 {prec}: score err {err_s.max():.5f}, box err {err_b.max():.4f}")
+    if prec == "fp32":
+        assert err_s.max() <= 1e-3 and (err_b <= 1e-3 + 1e-3 * np.abs(ref[:, :4])).all()
+    else:
+        stride = np.concatenate([np.full(6400, 8.0), np.full(1600, 16.0), np.full(400, 32.0)]).astype(np.float32)
+        assert err_s.max() <= 0.02 and (err_b <= 0.35 * stride + 0.02 * np.abs(ref[:, :4])).all()
+
+
+# ---------------------------------------------------------------------------- letterboxed detection
+@pytest.mark.parametrize("hw", [(480, 640), (640, 360), (720, 1280)])
+def test_detect_non_square_images_fp32(tmp_path, hw):
+    """NCNNDetector.detect on images that need the letterbox (pad-only and resized): boxes come back in
+    ORIGINAL-image pixels, identical post-NMS sets to the oracle (which uses the same restated cv2 resize)."""
+    from litepi import NCNNDetector
+    from oracle import ncnn_ref, pipeline_ref
+    p, b, _ = _calibrated_model(tmp_path, target_per_image=12)
+    rng = np.random.default_rng(hw[0] + hw[1])
+    img = rng.integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+    cpu = pipeline_ref.CpuPipeline(ncnn_ref.load_model(p, b), None)
+    eb, es, ec = cpu.detect(img, 0.25, 0.45)
+    det = NCNNDetector(p, b, precision="fp32", max_det=300)
+    try:
+        gb, gs, gc = det.detect(img, 0.25, 0.45)
+    finally:
+        det.engine.close()
+    # candidates within 1e-3 of the threshold may legitimately differ between fp32 implementations
+    strong = es > 0.252
+    assert len(gb) >= strong.sum() and len(gb) <= len(eb) + 2
+    for box, sc in zip(eb[strong], es[strong]):
+        d = np.abs(gb - box).max(axis=1)
+        j = int(np.argmin(d))
+        assert d[j] <= 0.05 and abs(gs[j] - sc) <= 1e-3, (box, gb[j])
+    if len(gb):
+        assert gb[:, [0, 2]].max() <= hw[1] and gb[:, [1, 3]].max() <= hw[0] and gb.min() >= 0
