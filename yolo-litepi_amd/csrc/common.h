@@ -109,6 +109,10 @@ struct ConvArgs {
   // shuffle epilogue
   int half_c, half_cp;  // logical / physical channels of one half of the output
   int out_f32;          // store fp32 regardless of T (classifier logits)
+  // fused 1x1 tail (second GEMM on the accumulator tile): A fragments [T2][S2][lane][16 B], bias, activation, channels
+  const void* w2;
+  const float* bias2;
+  int act2, Cout2;
   unsigned long long* stamps;  // diagnostic only (lp_test_conv + LITEPI_STAMPS): 16 clock stamps per workgroup
 };
 

@@ -23,6 +23,9 @@ struct ConvLayer {
   size_t lds_bytes = 0;
   bool direct = false;  // 3x3 stride-2: gather B fragments from global memory (no LDS input tile)
   DevBuf d_w, d_bias;
+  // fused 1x1 tail conv (second GEMM in the epilogue): 0 = none, else its 16-channel output tiles
+  int T2 = 0, Cout2 = 0, act2 = ACT_NONE;
+  DevBuf d_w2, d_bias2;
   std::string name;
   double macs_per_pixel() const { return (double)k * k * Cin * Cout; }
 
@@ -30,7 +33,13 @@ struct ConvLayer {
   // bias_phys: fp32 [Cout] or empty.  hout/wout: output map size and batch_hint: images (or ROIs)
   // per call at capacity -- together they pick the tile shape and the channel split.
   void build(int prec, int impl, int k, int stride, int cin, int cout, int act,
-             const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout, int batch_hint);
+             const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout, int batch_hint,
+             bool full_n = false);
+  // Fuse a following 1x1 conv (weights w2_phys [cout2][Cout] over physical channels) into this 3x3 layer.
+  // Requires build(..., full_n = true) (one workgroup holds every intermediate channel).  The fused layer's
+  // output view then has cout2 channels.
+  static bool tail_supported(int k, int stride, int cmid_phys, int cout2_phys);
+  void attach_tail(int cout2_phys, int act2, const std::vector<float>& w2_phys, const std::vector<float>& bias2_phys);
   void launch(const ConvIO& io, hipStream_t st) const;
 };
 

@@ -174,6 +174,61 @@ __device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chba
   }
 }
 
+// Fused 1x1 "tail": out2 = act2(W2 . act1(acc + bias1) + bias2) for one pixel tile, straight from the
+// accumulators.  A lane holds 4*NT consecutive intermediate channels of its pixel -- exactly the B
+// operand of the next MFMA (K slice (s2, g, j) <-> channel g*4NT + G*s2 + j), so no LDS round trip; the
+// intermediate is rounded to T first, as if it had been stored and re-loaded.
+template <typename T> struct TailSteps;
+template <> struct TailSteps<half_t> { static constexpr int per_nt(int nt) { return nt / 2; } };
+template <> struct TailSteps<float> { static constexpr int per_nt(int nt) { return nt; } };
+
+template <typename T, int NT, int T2, int ACT1>
+__device__ __forceinline__ void tail_store(const ConvArgs& a2, long pix, int g, const floatx4 (&v)[NT], const floatx4 (&bias1)[NT],
+                                           const typename Tr<T>::frag (&w2f)[T2][TailSteps<T>::per_nt(NT)],
+                                           const floatx4 (&bias2)[T2]) {
+  constexpr int S2 = TailSteps<T>::per_nt(NT);
+  typename Tr<T>::frag bq[S2];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bq[s][i] = (half_t)activate_ct<T, ACT1>(v[2 * s][i] + bias1[2 * s][i]);
+        bq[s][4 + i] = (half_t)activate_ct<T, ACT1>(v[2 * s + 1][i] + bias1[2 * s + 1][i]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < S2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bq[s][i] = activate_ct<T, ACT1>(v[s][i] + bias1[s][i]);
+  }
+  floatx4 o[T2];
+#pragma unroll
+  for (int t = 0; t < T2; ++t) {
+    o[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S2; ++s) o[t] = Tr<T>::mma(w2f[t][s], bq[s], o[t]);
+  }
+  if (a2.act == ACT_SILU) store_lane<T, T2, ACT_SILU>(a2, pix, g * 4 * T2, o, bias2);
+  else if (a2.act == ACT_RELU) store_lane<T, T2, ACT_RELU>(a2, pix, g * 4 * T2, o, bias2);
+  else store_lane<T, T2, ACT_NONE>(a2, pix, g * 4 * T2, o, bias2);
+}
+
+// loads of the tail's operands, once per wave
+template <typename T, int NT, int T2>
+__device__ __forceinline__ void tail_load(const ConvArgs& a, int lane, int g, typename Tr<T>::frag (&w2f)[T2][TailSteps<T>::per_nt(NT)],
+                                          floatx4 (&bias2)[T2]) {
+  constexpr int S2 = TailSteps<T>::per_nt(NT);
+  const u32x4* w = reinterpret_cast<const u32x4*>(a.w2);
+#pragma unroll
+  for (int t = 0; t < T2; ++t) {
+#pragma unroll
+    for (int s = 0; s < S2; ++s) w2f[t][s] = as_frag<T>(w[(t * S2 + s) * 64 + lane]);
+    bias2[t] = *reinterpret_cast<const floatx4*>(a.bias2 + g * 4 * T2 + t * 4);
+  }
+}
+
 // the residual is added AFTER the activation (C2f bottleneck: x + silu(conv(..))); the fp16 variant
 // above rounds the activated value to fp16 before the add, as a separate add kernel would
 template <typename T, int NT, int ACT>
@@ -226,7 +281,7 @@ __device__ __forceinline__ void epilogue_flat(const ConvArgs& a, const floatx4 (
 // ------------------------------------------------------------------------------------
 // second launch-bound = waves per SIMD the register allocation must allow: the narrow variants run many
 // short-lived workgroups and live off occupancy (4 waves/SIMD = 128 VGPRs), the wide ones off MFMA tiles
-template <typename T, int NT, int STRIDE>
+template <typename T, int NT, int STRIDE, int T2 = 0>
 __global__ __launch_bounds__(320, (NT == 1 ? 4 : (NT == 2 ? 3 : 2))) void conv3x3_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
@@ -358,9 +413,30 @@ __global__ __launch_bounds__(320, (NT == 1 ? 4 : (NT == 2 ? 3 : 2))) void conv3x
 
   const int oy = oy0 + ly;
   const int oxb = ox0 + wx * 20 + (col & 3);
-  if (a.act == ACT_SILU) epilogue_tile<T, NT, ACT_SILU>(a, acc, bias_r, n, ns, g, oy, oxb);
-  else if (a.act == ACT_RELU) epilogue_tile<T, NT, ACT_RELU>(a, acc, bias_r, n, ns, g, oy, oxb);
-  else epilogue_tile<T, NT, ACT_NONE>(a, acc, bias_r, n, ns, g, oy, oxb);
+  if constexpr (T2 > 0) {
+    // fused 1x1 conv on the accumulator tile (needs every intermediate channel in this workgroup: ns == 0)
+    typename Tr<T>::frag w2f[T2][TailSteps<T>::per_nt(NT)];
+    floatx4 bias2[T2];
+    tail_load<T, NT, T2>(a, lane, g, w2f, bias2);
+    ConvArgs a2 = a;
+    a2.Cout = a.Cout2; a2.act = a.act2; a2.res = nullptr;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      const int ox = oxb + p * 4;
+      if (oy < a.Hout && ox < a.Wout) {
+        const long pix = (long)(n * a.Hout + oy) * a.Wout + ox;
+        floatx4 v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = acc[t][p];
+        if (a.act == ACT_SILU) tail_store<T, NT, T2, ACT_SILU>(a2, pix, g, v, bias_r, w2f, bias2);
+        else tail_store<T, NT, T2, ACT_NONE>(a2, pix, g, v, bias_r, w2f, bias2);
+      }
+    }
+  } else {
+    if (a.act == ACT_SILU) epilogue_tile<T, NT, ACT_SILU>(a, acc, bias_r, n, ns, g, oy, oxb);
+    else if (a.act == ACT_RELU) epilogue_tile<T, NT, ACT_RELU>(a, acc, bias_r, n, ns, g, oy, oxb);
+    else epilogue_tile<T, NT, ACT_NONE>(a, acc, bias_r, n, ns, g, oy, oxb);
+  }
   LP_STAMP(11)
   if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 12] = wall_clock64();
 }
@@ -440,7 +516,7 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
 // of K = 9 x Cin) in LDS, B fragments gathered straight from global memory with per-tap bounds
 // checks (zero padding), flattened output pixels.
 // ------------------------------------------------------------------------------------
-template <typename T, int NT, int NP>
+template <typename T, int NT, int NP, int T2 = 0>
 __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
@@ -520,9 +596,28 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a)
 #pragma unroll
         for (int p = 0; p < NP; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
     }
-    if (a.act == ACT_SILU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_SILU>(a, acc, bias_r, pix0, M, ns, g, col);
-    else if (a.act == ACT_RELU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_RELU>(a, acc, bias_r, pix0, M, ns, g, col);
-    else epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_NONE>(a, acc, bias_r, pix0, M, ns, g, col);
+    if constexpr (T2 > 0) {
+      typename Tr<T>::frag w2f[T2][TailSteps<T>::per_nt(NT)];
+      floatx4 bias2[T2];
+      tail_load<T, NT, T2>(a, lane, g, w2f, bias2);
+      ConvArgs a2 = a;
+      a2.Cout = a.Cout2; a2.act = a.act2; a2.res = nullptr;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const long pix = pix0 + p * 16 + col;
+        if (pix < M) {
+          floatx4 v[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) v[t] = acc[t][p];
+          if (a.act == ACT_SILU) tail_store<T, NT, T2, ACT_SILU>(a2, pix, g, v, bias_r, w2f, bias2);
+          else tail_store<T, NT, T2, ACT_NONE>(a2, pix, g, v, bias_r, w2f, bias2);
+        }
+      }
+    } else {
+      if (a.act == ACT_SILU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_SILU>(a, acc, bias_r, pix0, M, ns, g, col);
+      else if (a.act == ACT_RELU) epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_RELU>(a, acc, bias_r, pix0, M, ns, g, col);
+      else epilogue_flat<T, NT, NP, EPI_PLAIN, ACT_NONE>(a, acc, bias_r, pix0, M, ns, g, col);
+    }
   }
 }
 
@@ -653,7 +748,8 @@ static void put_elem(std::vector<uint8_t>& buf, size_t idx, int prec, float v) {
 }
 
 void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int cout, int act_,
-                      const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout, int batch_hint) {
+                      const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout, int batch_hint,
+                      bool full_n) {
   prec = prec_; impl = impl_; k = k_; stride = stride_; Cin = cin; Cout = cout; act = act_;
   LP_CHECK(k == 1 || k == 3, LP_ERR_GRAPH, "conv kernel size %d unsupported", k);
   LP_CHECK(Cin % 8 == 0 && Cout % 8 == 0, LP_ERR_GRAPH, "physical channels must be multiples of 8");
@@ -679,6 +775,7 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
   // channel tiles per block: 4 when the layer has plenty of pixel tiles; fewer (more channel
   // splits -> more workgroups) when the map is small, so that ~2 workgroups per CU exist
   auto pick_nt = [&](long pixel_blocks) {
+    if (full_n) return tiles_total;  // a fused tail needs every intermediate channel in one workgroup
     int nt = tiles_total >= 4 ? 4 : tiles_total;
     if (tiles_total % 4 != 0 && tiles_total > 4) nt = (tiles_total % 3 == 0) ? 3 : 4;
     while (nt > 1 && pixel_blocks * ceil_div(tiles_total, nt) < 512) nt = (nt == 4 && tiles_total % 4 == 0) ? 2 : nt - 1;
@@ -694,7 +791,7 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     CGc = Cin / G;
     nchunks = 1;
     steps = ceil_div(taps * CGc, 4);
-    while (NT > 1 && (size_t)steps * NT * 1024 > 64 * 1024) --NT;
+    while (!full_n && NT > 1 && (size_t)steps * NT * 1024 > 64 * 1024) --NT;
     nsplits = ceil_div(tiles_total, NT);
     lds_bytes = (size_t)steps * NT * 1024;
     LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv3x3/s2 weights do not fit LDS (%zu B)", lds_bytes);
@@ -776,6 +873,42 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
   LP_HIP(hipMemcpy(d_w.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
 }
 
+bool ConvLayer::tail_supported(int k, int stride, int cmid_phys, int cout2_phys) {
+  if (k != 3 || cmid_phys % 32 != 0) return false;
+  const int nt = cmid_phys / 16, t2 = ceil_div(cout2_phys, 16);
+  if (stride == 1) return (nt == 4 && t2 == 4) || (nt == 2 && t2 == 1);
+  if (stride == 2) return (nt == 2 && t2 == 2) || (nt == 4 && t2 == 4);
+  return false;
+}
+
+void ConvLayer::attach_tail(int cout2_phys, int act2_, const std::vector<float>& w2_phys, const std::vector<float>& bias2_phys) {
+  LP_CHECK(impl == IMPL_MFMA && nsplits == 1 && NT * 16 == Cout && tail_supported(k, stride, Cout, cout2_phys), LP_ERR_STATE,
+           "conv %s: fused 1x1 tail not supported for this shape", name.c_str());
+  T2 = ceil_div(cout2_phys, 16);
+  Cout2 = cout2_phys;
+  act2 = act2_;
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const int S2 = prec == LP_FP16 ? NT / 2 : NT;
+  std::vector<uint8_t> buf((size_t)T2 * S2 * 64 * 16, 0);
+  for (int t = 0; t < T2; ++t)
+    for (int s2 = 0; s2 < S2; ++s2)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, m = lane & 15, gm = m >> 2, r = m & 3;
+        const int oc = gm * 4 * T2 + t * 4 + r;  // same row permutation as the main GEMM, for vector stores
+        if (oc >= cout2_phys) continue;
+        for (int j = 0; j < G; ++j) {
+          const int mid = g * 4 * NT + G * s2 + j;  // the intermediate channel this lane's accumulators hold at (s2, j)
+          put_elem(buf, ((size_t)(t * S2 + s2) * 64 + lane) * G + j, prec, w2_phys[(size_t)oc * Cout + mid]);
+        }
+      }
+  d_w2.alloc(buf.size());
+  LP_HIP(hipMemcpy(d_w2.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+  std::vector<float> b(round_up(cout2_phys, 64) + 64, 0.f);
+  for (int c = 0; c < cout2_phys && c < (int)bias2_phys.size(); ++c) b[c] = bias2_phys[c];
+  d_bias2.alloc(b.size() * 4);
+  LP_HIP(hipMemcpy(d_bias2.p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+}
+
 template <typename T, int NT>
 static void launch3x3(const ConvArgs& a, int stride, dim3 grid, int threads, size_t lds, hipStream_t st) {
   if (stride == 1) {
@@ -827,8 +960,9 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
   a.CK = CK; a.nchunks = nchunks; a.steps_per_chunk = steps; a.CGc = CGc; a.LW = LW; a.PS = PS;
   a.bwh = bwh; a.bww = bww; a.steps = steps; a.nsplit_tiles = NT;
   a.half_c = io.half_c; a.half_cp = io.half_cp; a.out_f32 = io.out_f32; a.stamps = io.stamps;
+  a.w2 = d_w2.p; a.bias2 = d_bias2.as<float>(); a.act2 = act2; a.Cout2 = Cout2;
   LP_CHECK(io.in.C == Cin, LP_ERR_STATE, "conv input view has %d channels, layer expects %d", io.in.C, Cin);
-  LP_CHECK(io.x1.base || io.out.C >= Cout || io.out_f32, LP_ERR_STATE, "conv output view too narrow (%d < %d)", io.out.C, Cout);
+  LP_CHECK(io.x1.base || io.out.C >= (T2 ? Cout2 : Cout) || io.out_f32, LP_ERR_STATE, "conv output view too narrow (%d < %d)", io.out.C, T2 ? Cout2 : Cout);
   LP_CHECK((io.in.pitch % 8) == 0 && (io.out.pitch % 4) == 0, LP_ERR_STATE, "unaligned channel pitch");
   const bool f16 = prec == LP_FP16;
 
@@ -854,7 +988,20 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
     case 3: launch_s2<TT, 3>(a, grid, lds_bytes, st); break;                                           \
     default: launch_s2<TT, 4>(a, grid, lds_bytes, st); break;                                          \
   }
-    if (f16) { LP_LD(half_t) } else { LP_LD(float) }
+    if (T2) {
+      LP_CHECK(!io.res.base, LP_ERR_STATE, "fused tail with residual unsupported");
+#define LP_LDT(TT, N_, T_)                                                                                              \
+  {                                                                                                                     \
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<TT, N_, 4, T_>),  \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);       \
+    (void)once;                                                                                                         \
+    hipLaunchKernelGGL((conv3x3s2_direct_kernel<TT, N_, 4, T_>), grid, dim3(256), lds_bytes, st, a);                     \
+  }
+      if (NT == 2 && T2 == 2) { if (f16) LP_LDT(half_t, 2, 2) else LP_LDT(float, 2, 2) }
+      else if (NT == 4 && T2 == 4) { if (f16) LP_LDT(half_t, 4, 4) else LP_LDT(float, 4, 4) }
+      else throw Error(LP_ERR_STATE, "conv3x3/s2: unsupported fused tail shape");
+#undef LP_LDT
+    } else if (f16) { LP_LD(half_t) } else { LP_LD(float) }
 #undef LP_LD
   } else if (k == 3) {
     LP_CHECK(!io.m_dyn && !io.x1.base && !io.out_f32, LP_ERR_STATE, "conv3x3: unsupported epilogue");
@@ -870,7 +1017,20 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
     case 3: launch3x3<TT, 3>(a, stride, grid, threads, lds_bytes, st); break;      \
     default: launch3x3<TT, 4>(a, stride, grid, threads, lds_bytes, st); break;     \
   }
-    if (f16) { LP_L3(half_t) } else { LP_L3(float) }
+    if (T2) {
+      LP_CHECK(!io.res.base && stride == 1, LP_ERR_STATE, "fused tail with residual unsupported");
+#define LP_L3T(TT, N_, T_)                                                                                              \
+  {                                                                                                                     \
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<TT, N_, 1, T_>),     \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);       \
+    (void)once;                                                                                                         \
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<TT, N_, 1, T_>), grid, dim3(threads), lds_bytes, st, a);                      \
+  }
+      if (NT == 4 && T2 == 4) { if (f16) LP_L3T(half_t, 4, 4) else LP_L3T(float, 4, 4) }
+      else if (NT == 2 && T2 == 1) { if (f16) LP_L3T(half_t, 2, 1) else LP_L3T(float, 2, 1) }
+      else throw Error(LP_ERR_STATE, "conv3x3: unsupported fused tail shape");
+#undef LP_L3T
+    } else if (f16) { LP_L3(half_t) } else { LP_L3(float) }
 #undef LP_L3
   } else {
     LP_CHECK(stride == 1, LP_ERR_GRAPH, "strided 1x1 conv unsupported");

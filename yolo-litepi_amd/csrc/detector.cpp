@@ -343,10 +343,31 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
           done[cs[0]] = 1;
         }
       }
+      // 1x1 tail fusion: this 3x3 conv's activation output feeds exactly one 1x1 conv (Detect-head
+      // projections, C2f cv1 after a stride-2 conv): the second GEMM runs on the accumulator tile
+      int tail = -1, tmid = -1;
+      if (res < 0 && k == 3 && tin != input_tensor && impl_ == IMPL_MFMA) {
+        auto& cs2 = canon_consumers[tensors_[tout].name];
+        if (cs2.size() == 1 && L[cs2[0]].type == "Convolution" && !is_tail(cs2[0]) && !done[cs2[0]]) {
+          const NcnnLayer& lb = L[cs2[0]];
+          const int tb = cinfo[cs2[0]].tout;
+          const bool plain1x1 = lb.ipar(1, 1) == 1 && lb.ipar(3, 1) == 1 && tensors_[tout].segs.size() == 1;
+          // B must not itself be the producer of a fused residual add
+          bool b_feeds_add = false;
+          for (int c : canon_consumers[tensors_[tb].name]) b_feeds_add = b_feeds_add || L[c].type == "BinaryOp";
+          if (plain1x1 && !b_feeds_add && ConvLayer::tail_supported(k, s, tensors_[tout].Cp, tensors_[tb].Cp)) {
+            tail = cs2[0];
+            tmid = tout;
+            tout = tb;
+            done[tail] = 1;
+          }
+        }
+      }
       ensure_buffer(tout);
       const Tensor& TI = tensors_[tin];
-      const Tensor& TO = tensors_[tout];
-      const double macs = (double)k * k * Cin * Cout * TO.H * TO.W;
+      const Tensor& TO = tensors_[tail >= 0 ? tmid : tout];
+      double macs = (double)k * k * Cin * Cout * TO.H * TO.W;
+      if (tail >= 0) macs += (double)L[tail].in_ch * L[tail].ipar(0) * TO.H * TO.W;
       macs_ += macs;
       DetOp op;
       op.layer = l.name;
@@ -383,7 +404,22 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         }
         convs_.emplace_back(new ConvLayer());
         convs_.back()->name = l.name;
-        convs_.back()->build(prec_, impl_, k, s, TI.Cp, TO.Cp, fused_act[i], w, b, TO.H, TO.W, maxB_);
+        convs_.back()->build(prec_, impl_, k, s, TI.Cp, TO.Cp, fused_act[i], w, b, TO.H, TO.W, maxB_, tail >= 0);
+        if (tail >= 0) {
+          const NcnnLayer& lb = L[tail];
+          const Tensor& TB = tensors_[tout];
+          const int cin2 = lb.in_ch, cout2 = lb.ipar(0);
+          std::vector<float> w2((size_t)TB.Cp * TO.Cp, 0.f), b2(TB.Cp, 0.f);
+          for (int co = 0; co < cout2; ++co) {
+            const int pc = TB.phys(co);
+            for (int ci = 0; ci < cin2; ++ci) w2[(size_t)pc * TO.Cp + TO.phys(ci)] = lb.weight[(size_t)co * cin2 + ci];
+            if (!lb.bias.empty()) b2[pc] = lb.bias[co];
+          }
+          convs_.back()->attach_tail(TB.Cp, fused_act[tail], w2, b2);
+          convs_.back()->name = l.name + "+" + lb.name;
+          op.layer = convs_.back()->name;
+          op.bytes = ((double)TI.C * TI.H * TI.W + (double)TB.C * TB.H * TB.W) * esd + (double)(l.weight.size() + lb.weight.size()) * esd;
+        }
         op.kind = DetOp::CONV;
         op.conv = (int)convs_.size() - 1;
       }
@@ -505,7 +541,7 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         io.in = view(op.in); io.out = view(op.out); io.N = B;
         if (op.res >= 0) io.res = view(op.res);
         c.launch(io, st);
-        kname = std::string(c.impl == IMPL_NAIVE ? "conv_naive" : (c.direct ? "conv3x3s2_direct" : (c.k == 3 ? "conv3x3_mfma" : "conv1x1_mfma"))) + sfx;
+        kname = std::string(c.impl == IMPL_NAIVE ? "conv_naive" : (c.direct ? "conv3x3s2_direct" : (c.k == 3 ? "conv3x3_mfma" : "conv1x1_mfma"))) + (c.T2 ? "+1x1" : "") + sfx;
         break;
       }
       case DetOp::UPSAMPLE:
