@@ -179,7 +179,7 @@ __device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chba
 // operand of the next MFMA (K slice (s2, g, j) <-> channel g*4NT + G*s2 + j), so no LDS round trip; the
 // intermediate is rounded to T first, as if it had been stored and re-loaded.
 template <typename T> struct TailSteps;
-template <> struct TailSteps<half_t> { static constexpr int per_nt(int nt) { return nt / 2; } };
+template <> struct TailSteps<half_t> { static constexpr int per_nt(int nt) { return (nt + 1) / 2; } };  // odd NT: last K step half filled
 template <> struct TailSteps<float> { static constexpr int per_nt(int nt) { return nt; } };
 
 template <typename T, int NT, int T2, int ACT1>
@@ -194,7 +194,8 @@ __device__ __forceinline__ void tail_store(const ConvArgs& a2, long pix, int g, 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         bq[s][i] = (half_t)activate_ct<T, ACT1>(v[2 * s][i] + bias1[2 * s][i]);
-        bq[s][4 + i] = (half_t)activate_ct<T, ACT1>(v[2 * s + 1][i] + bias1[2 * s + 1][i]);
+        const int t1 = (2 * s + 1 < NT) ? 2 * s + 1 : 0;  // clamped: the odd-NT last step has no second quad
+        bq[s][4 + i] = (2 * s + 1 < NT) ? (half_t)activate_ct<T, ACT1>(v[t1][i] + bias1[t1][i]) : (half_t)0.f;
       }
     }
   } else {
@@ -874,10 +875,10 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
 }
 
 bool ConvLayer::tail_supported(int k, int stride, int cmid_phys, int cout2_phys) {
-  if (k != 3 || cmid_phys % 32 != 0) return false;
+  if (k != 3 || cmid_phys % 16 != 0) return false;
   const int nt = cmid_phys / 16, t2 = ceil_div(cout2_phys, 16);
   if (stride == 1) return (nt == 4 && t2 == 4) || (nt == 2 && t2 == 1);
-  if (stride == 2) return (nt == 2 && t2 == 2) || (nt == 4 && t2 == 4);
+  if (stride == 2) return (nt == 1 && t2 == 1) || (nt == 2 && t2 == 2) || (nt == 4 && t2 == 4);
   return false;
 }
 
@@ -888,7 +889,7 @@ void ConvLayer::attach_tail(int cout2_phys, int act2_, const std::vector<float>&
   Cout2 = cout2_phys;
   act2 = act2_;
   const int G = prec == LP_FP16 ? 8 : 4;
-  const int S2 = prec == LP_FP16 ? NT / 2 : NT;
+  const int S2 = prec == LP_FP16 ? (NT + 1) / 2 : NT;
   std::vector<uint8_t> buf((size_t)T2 * S2 * 64 * 16, 0);
   for (int t = 0; t < T2; ++t)
     for (int s2 = 0; s2 < S2; ++s2)
@@ -897,6 +898,7 @@ void ConvLayer::attach_tail(int cout2_phys, int act2_, const std::vector<float>&
         const int oc = gm * 4 * T2 + t * 4 + r;  // same row permutation as the main GEMM, for vector stores
         if (oc >= cout2_phys) continue;
         for (int j = 0; j < G; ++j) {
+          if (G * s2 + j >= 4 * NT) continue;       // half-filled last K step (odd NT, fp16)
           const int mid = g * 4 * NT + G * s2 + j;  // the intermediate channel this lane's accumulators hold at (s2, j)
           put_elem(buf, ((size_t)(t * S2 + s2) * 64 + lane) * G + j, prec, w2_phys[(size_t)oc * Cout + mid]);
         }
@@ -997,7 +999,8 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
     (void)once;                                                                                                         \
     hipLaunchKernelGGL((conv3x3s2_direct_kernel<TT, N_, 4, T_>), grid, dim3(256), lds_bytes, st, a);                     \
   }
-      if (NT == 2 && T2 == 2) { if (f16) LP_LDT(half_t, 2, 2) else LP_LDT(float, 2, 2) }
+      if (NT == 1 && T2 == 1) { if (f16) LP_LDT(half_t, 1, 1) else LP_LDT(float, 1, 1) }
+      else if (NT == 2 && T2 == 2) { if (f16) LP_LDT(half_t, 2, 2) else LP_LDT(float, 2, 2) }
       else if (NT == 4 && T2 == 4) { if (f16) LP_LDT(half_t, 4, 4) else LP_LDT(float, 4, 4) }
       else throw Error(LP_ERR_STATE, "conv3x3/s2: unsupported fused tail shape");
 #undef LP_LDT
