@@ -716,6 +716,74 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restric
   }
 }
 
+// Stem, fast path: one workgroup = 8 x 32 output pixels.  The 17 x 65-pixel uint8 input tile is
+// staged in LDS with coalesced dword loads (27 scattered byte loads per output pixel made the
+// first version texture-address bound); each thread then reads 3 dwords per input row and pulls
+// its 9 bytes out with v_alignbyte.  Needs 4-byte aligned image rows (Win % 4 == 0).
+#define STEM_TH 8
+#define STEM_TW 32
+#define STEM_ROWW 52  /* dwords per staged row: 1 + 65*3 bytes rounded up, + 2 so that every thread's 3rd dword exists */
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void stem_conv_lds_kernel(const uint8_t* __restrict__ img, T* __restrict__ out,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            int N, int Hin, int Win, int Hout, int Wout, int out_pitch,
+                                                            int act) {
+  __shared__ uint32_t tile[(2 * STEM_TH + 1) * STEM_ROWW];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.z, oy0 = blockIdx.y * STEM_TH, ox0 = blockIdx.x * STEM_TW;
+  const int row_words = Win * 3 / 4;
+  const int w0 = (6 * ox0 - 3) >> 2;  // first staged dword of a row (arithmetic shift: -1 for the left border tile)
+  const uint32_t* im = reinterpret_cast<const uint32_t*>(img + (long)n * Hin * Win * 3);
+  for (int i = tid; i < (2 * STEM_TH + 1) * STEM_ROWW; i += 256) {
+    const int r = i / STEM_ROWW, c = i - r * STEM_ROWW;
+    const int iy = 2 * oy0 - 1 + r, wi = w0 + c;
+    uint32_t v = 0u;
+    if (iy >= 0 && iy < Hin && wi >= 0 && wi < row_words) v = im[(long)iy * row_words + wi];
+    tile[i] = v;
+  }
+  __syncthreads();
+  const int ty = tid >> 5, tx = tid & 31;
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  if (oy >= Hout || ox >= Wout) return;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  const float inv255 = 1.f / 255.f;
+  const int boff = 1 + 6 * tx;        // first needed byte inside the staged row (the tile starts at byte 6*ox0-3 = 4*w0 + 1)
+  const int wi = boff >> 2, sh = boff & 3;
+  // bytes right of the image (ix >= Win) are zeros already; the pixel left of the image (ix = -1) lives in dword -1 -> zero
+  // (ky is NOT unrolled: the weights are wave-uniform scalars, and all 27*CO of them live at once spill the SGPR file)
+#pragma unroll 1
+  for (int ky = 0; ky < 3; ++ky) {
+    const uint32_t* rw = tile + (2 * ty + ky) * STEM_ROWW + wi;
+    const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
+    const uint32_t wa = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t wb = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const uint32_t wc = d2 >> (8 * sh);
+    float px[9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      px[j] = (float)((wa >> (8 * j)) & 0xffu) * inv255;
+      px[4 + j] = (float)((wb >> (8 * j)) & 0xffu) * inv255;
+    }
+    px[8] = (float)(wc & 0xffu) * inv255;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float* wr = w + (ky * 9 + k) * CO;  // (ky*3+kx)*3 + c with k = kx*3 + c
+#pragma unroll
+      for (int co = 0; co < CO; ++co) acc[co] = fmaf(px[k], wr[co], acc[co]);
+    }
+  }
+  T* o = out + ((long)(n * Hout + oy) * Wout + ox) * out_pitch;
+#pragma unroll
+  for (int c0 = 0; c0 < CO; c0 += 4) {
+    typename Tr<T>::quad q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = (T)activate<T>(acc[c0 + i] + bias[c0 + i], act);
+    *reinterpret_cast<typename Tr<T>::quad*>(o + c0) = q;
+  }
+}
+
 // ====================================================================================
 // Host side: weight packing and launch
 // ====================================================================================
@@ -1066,6 +1134,20 @@ void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<floa
 }
 
 void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& out, hipStream_t st) const {
+  if (Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 && out.H == (Hin + 1) / 2 && out.W == (Win + 1) / 2) {
+    dim3 g2(ceil_div(out.W, STEM_TW), ceil_div(out.H, STEM_TH), N);
+#define LP_STL(TT, C)                                                                                            \
+  hipLaunchKernelGGL((stem_conv_lds_kernel<TT, C>), g2, dim3(256), 0, st, img, reinterpret_cast<TT*>(out.base), \
+                     d_w.as<float>(), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch, act)
+    if (prec == LP_FP16) {
+      if (CO == 8) LP_STL(half_t, 8); else if (CO == 16) LP_STL(half_t, 16); else LP_STL(half_t, 32);
+    } else {
+      if (CO == 8) LP_STL(float, 8); else if (CO == 16) LP_STL(float, 16); else LP_STL(float, 32);
+    }
+#undef LP_STL
+    LP_HIP(hipGetLastError());
+    return;
+  }
   const long total = (long)N * out.H * out.W;
   dim3 grid((unsigned)((total + 255) / 256));
 #define LP_ST(TT, C)                                                                                     \
