@@ -282,13 +282,18 @@ __device__ __forceinline__ void epilogue_flat(const ConvArgs& a, const floatx4 (
 // ------------------------------------------------------------------------------------
 // second launch-bound = waves per SIMD the register allocation must allow: the narrow variants run many
 // short-lived workgroups and live off occupancy (4 waves/SIMD = 128 VGPRs), the wide ones off MFMA tiles
+// 16-byte LDS-DMA: lane l's 16 bytes land at lds + 16*l (wave-uniform lds), no VGPR in between
+#define LP_GLDS16(gptr, lptr)                                                                        \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),          \
+                                   (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
+
 template <typename T, int NT, int STRIDE, int T2 = 0>
-__global__ __launch_bounds__(320, (NT == 1 ? 4 : (NT == 2 ? 3 : 2))) void conv3x3_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(T) == 4)) ? 2 : 3))) void conv3x3_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
-  constexpr int SB = 4;  // staging loads in flight per thread per round (registers vs. round trips)
+  constexpr int MAXP = 8;  // 1 KiB pieces per LDS tile row (host checks)
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int g = lane >> 4, col = lane & 15;
   const int wy = wave / a.bww, wx = wave - wy * a.bww;
   const int TH = 4 * a.bwh, TW = 20 * a.bww;
@@ -299,16 +304,18 @@ __global__ __launch_bounds__(320, (NT == 1 ? 4 : (NT == 2 ? 3 : 2))) void conv3x
   const int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
   const int Sc = a.steps_per_chunk, CGc = a.CGc, LW = a.LW, PS = a.PS;
 
-  // LDS: [tap-offset table 512 B][weight fragments Sc*NT KB][input tile IH x LW x PS]
+  // LDS: [tap-offset table 512 B] then per buffer (two when the layer has several K chunks):
+  //      [weight fragments Sc*NT KB][input tile IH x LW x PS]
   int* lds_toff = reinterpret_cast<int*>(smem);
-  u32x4* lds_w = reinterpret_cast<u32x4*>(smem + 512);
-  char* lds_in = smem + 512 + (size_t)Sc * NT * 1024;
-  if (tid < Sc * 4) {  // byte offset of K group q = tid inside the input tile: (tap, channel group)
-    int tap = tid / CGc;
-    const int cg = tid - tap * CGc;
+  const int wbytes = Sc * NT * 1024;
+  const int RS = LW * (PS >> 4);           // 16-byte slots per tile row (pads included)
+  const int bufbytes = wbytes + IH * RS * 16;
+  for (int q = tid; q < Sc * 4; q += nthr) {  // byte offset of K group q inside the input tile: (tap, channel group)
+    int tap = q / CGc;
+    const int cg = q - tap * CGc;
     tap = tap > 8 ? 8 : tap;  // K padding slots: weights are zero, read any finite data
     const int ky = tap / 3, kx = tap - 3 * ky;
-    lds_toff[tid] = (ky * LW + kx) * PS + cg * 16;
+    lds_toff[q] = (ky * LW + kx) * PS + cg * 16;
   }
 
   const int ly = wy * 4 + (col >> 2);
@@ -318,13 +325,44 @@ __global__ __launch_bounds__(320, (NT == 1 ? 4 : (NT == 2 ? 3 : 2))) void conv3x
     const int lx = wx * 20 + p * 4 + (col & 3);
     pbase[p] = ((ly * STRIDE) * LW + lx * STRIDE) * PS;
   }
-  // input staging map, divisions hoisted: a row of the tile has RI = IW*CGc 16-byte items; the
-  // workgroup covers rpp rows per pass, each thread keeps its (column, channel group)
-  const int RI = IW * CGc;
-  const int rpp = nthr / RI;
-  const int srow = tid / RI, scol = tid - srow * RI;
-  const int six = scol / CGc, scg = scol - six * CGc;
-  const bool stager = rpp > 0 && srow < rpp;
+  // Staging map.  The LDS image of a tile row is RS consecutive 16-byte slots = pixel pitch x LW, filled by
+  // 1 KiB LDS-DMA pieces (64 lanes x 16 B, destination lane-linear).  Per piece this lane's slot is a fixed
+  // (column, channel group): its source byte offset inside the image row is computed once; slots that are
+  // pitch padding, beyond the tile, or outside the image read a 16-byte zero line instead (= zero padding).
+  const int pcs = (RS + 63) >> 6;
+  const int PSs = PS >> 4;
+  int soff[MAXP];
+#pragma unroll
+  for (int pc = 0; pc < MAXP; ++pc) {
+    const int sl = pc * 64 + lane;
+    const int ix = sl / PSs, cgs = sl - ix * PSs;
+    const int gx = ix0 + ix;
+    soff[pc] = (ix < IW && cgs < CGc && gx >= 0 && gx < a.Win) ? (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : -1;
+    if (sl >= RS) soff[pc] = -2;  // no slot: lane stays idle for this piece
+  }
+  const char* zeros = reinterpret_cast<const char*>(a.zeros);
+  const char* in_b = reinterpret_cast<const char*>(a.in);
+
+  // issue every load of K chunk c into buffer b (nothing waits here)
+  auto issue = [&](int c, int b) {
+    char* buf = smem + 512 + b * bufbytes;
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + ((size_t)(ns * a.nchunks + c) * Sc * NT) * 64;
+    for (int p = wave; p < Sc * NT; p += nw) LP_GLDS16(wsrc + p * 64 + lane, buf + p * 1024);
+    char* lin = buf + wbytes;
+    const int cbase = c * a.CK;
+    for (int iy = wave; iy < IH; iy += nw) {
+      const int gy = iy0 + iy;
+      const bool rowok = gy >= 0 && gy < a.Hin;
+      const char* rowp = in_b + (((long)(n * a.Hin + gy) * a.Win + ix0) * a.in_pitch + cbase) * (long)sizeof(T);
+#pragma unroll
+      for (int pc = 0; pc < MAXP; ++pc) {
+        if (pc < pcs && soff[pc] != -2) {
+          const char* src = (rowok && soff[pc] >= 0) ? rowp + soff[pc] : zeros;
+          LP_GLDS16(src, lin + (iy * RS + pc * 64) * 16);
+        }
+      }
+    }
+  };
 
   floatx4 bias_r[NT];  // this lane's 4*NT output channels: bias hoisted out of the epilogue
 #pragma unroll
@@ -335,67 +373,20 @@ __global__ __launch_bounds__(320, (NT == 1 ? 4 : (NT == 2 ? 3 : 2))) void conv3x
 #pragma unroll
     for (int p = 0; p < 5; ++p) acc[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  const T* in = reinterpret_cast<const T*>(a.in);
   LP_STAMP(0)
   LP_STAMP(1)
+  issue(0, 0);
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-    if (chunk) __syncthreads();
     if (chunk < 2) { LP_STAMP(2 + chunk * 4) }
-    // Stage this chunk: weight fragments (already in fragment order, 16 B per lane) and the
-    // halo'd input tile (zero outside the image = the conv's zero padding).  Loads are issued in
-    // groups of 8 per thread before any LDS store, so a block pays one or two memory round trips
-    // instead of one per element (these layers are latency-bound: one tile per block).
-    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + ((size_t)(ns * a.nchunks + chunk) * Sc * NT) * 64;
-    const int nW = Sc * NT * 64;
-    const int cbase = chunk * a.CK;
-    const int gx = ix0 + six;
-    const bool xok = gx >= 0 && gx < a.Win;
-    const int passes = rpp > 0 ? (IH + rpp - 1) / rpp : 0;
-    for (int r0 = 0; r0 * nthr < nW; r0 += SB) {
-      u32x4 wv[SB];
-#pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        const int i = (r0 + u) * nthr + tid;
-        wv[u] = u32x4{0u, 0u, 0u, 0u};
-        if (i < nW) wv[u] = wsrc[i];
-      }
-#pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        const int i = (r0 + u) * nthr + tid;
-        if (i < nW) lds_w[i] = wv[u];
-      }
-    }
-    for (int r0 = 0; r0 < passes; r0 += SB) {
-      u32x4 iv[SB];
-#pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        const int iy = (r0 + u) * rpp + srow;
-        iv[u] = u32x4{0u, 0u, 0u, 0u};
-        const int gy = iy0 + iy;
-        if (stager && iy < IH && xok && gy >= 0 && gy < a.Hin)
-          iv[u] = *reinterpret_cast<const u32x4*>(in + ((long)(n * a.Hin + gy) * a.Win + gx) * a.in_pitch + cbase + scg * G);
-      }
-#pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        const int iy = (r0 + u) * rpp + srow;
-        if (stager && iy < IH) *reinterpret_cast<u32x4*>(lds_in + (iy * LW + six) * PS + scg * 16) = iv[u];
-      }
-    }
-    if (rpp == 0) {  // a tile row has more items than threads (fp32, wide chunks): generic path
-      const int nI = IH * IW * CGc;
-      for (int i = tid; i < nI; i += nthr) {
-        const int pix = i / CGc, cg = i - pix * CGc;
-        const int iy = pix / IW, ix = pix - iy * IW;
-        const int gy = iy0 + iy, gxx = ix0 + ix;
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (gy >= 0 && gy < a.Hin && gxx >= 0 && gxx < a.Win)
-          v = *reinterpret_cast<const u32x4*>(in + ((long)(n * a.Hin + gy) * a.Win + gxx) * a.in_pitch + cbase + cg * G);
-        *reinterpret_cast<u32x4*>(lds_in + (iy * LW + ix) * PS + cg * 16) = v;
-      }
-    }
+    // chunk's loads have landed (own: vmcnt, everyone's: barrier); the barrier also says every wave is done
+    // reading the other buffer, so the next chunk's loads go out now and fly during this chunk's MFMAs
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (chunk < 2) { LP_STAMP(3 + chunk * 4) }
-    __syncthreads();
+    if (chunk + 1 < a.nchunks) issue(chunk + 1, (chunk + 1) & 1);
     if (chunk < 2) { LP_STAMP(4 + chunk * 4) }
+    const u32x4* lds_w = reinterpret_cast<const u32x4*>(smem + 512 + (chunk & 1) * bufbytes);
+    const char* lds_in = smem + 512 + (chunk & 1) * bufbytes + wbytes;
     for (int s = 0; s < Sc; ++s) {
       const int toff = lds_toff[4 * s + g];
       typename Tr<T>::frag af[NT], bf[5];
@@ -881,13 +872,16 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
       const int IH = (TH - 1) * stride + 3, IW = (TW - 1) * stride + 3;
       const int tiles = ceil_div(hout, TH) * ceil_div(wout, TW);
       const int nt = pick_nt((long)tiles * B);
+      // K chunk: everything at once when it fits (one round trip, no K padding between chunks), else the
+      // largest chunk whose two buffers fit (the next chunk's LDS-DMA flies during this chunk's MFMAs)
       int ck_fit = 0, lw = 0;
-      for (int ck = 8; ck <= Cin && ck <= 32; ck += 8) {
+      for (int ck = 8; ck <= Cin && ck <= 64; ck += 8) {
         if (Cin % ck) continue;
         const int cgc = ck / G;
         const int l = lds_row_width(IW, cgc);
-        const size_t lds = 512 + (size_t)ceil_div(taps * cgc, 4) * nt * 1024 + (size_t)IH * l * lds_pixel_slots(cgc) * 16;
-        if (lds <= budget) { ck_fit = ck; lw = l; }
+        const size_t one = (size_t)ceil_div(taps * cgc, 4) * nt * 1024 + (size_t)IH * l * lds_pixel_slots(cgc) * 16;
+        const size_t lds = 512 + (ck == Cin ? one : 2 * one);
+        if (lds <= budget && ceil_div(taps * cgc, 4) * 4 <= 128 && ceil_div(l * lds_pixel_slots(cgc), 64) <= 8) { ck_fit = ck; lw = l; }
       }
       if (!ck_fit) continue;
       const int util = (int)(100.0 * hout * wout / ((double)tiles * TH * TW));
@@ -903,7 +897,8 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     nchunks = Cin / CK;
     steps = ceil_div(taps * CGc, 4);
     LP_CHECK(steps * 4 <= 128, LP_ERR_GRAPH, "conv3x3: too many K steps per chunk");
-    lds_bytes = 512 + (size_t)steps * NT * 1024 + (size_t)IH * LW * PS;
+    lds_bytes = 512 + (nchunks > 1 ? 2 : 1) * ((size_t)steps * NT * 1024 + (size_t)IH * LW * PS);
+    LP_CHECK(ceil_div(LW * (PS / 16), 64) <= 8, LP_ERR_GRAPH, "conv3x3: LDS tile row too wide");
     LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv3x3 tile does not fit LDS (%zu B)", lds_bytes);
   } else {
     NT = pick_nt(ceil_div((long)B * hout * wout, 256));
@@ -1031,6 +1026,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
   a.bwh = bwh; a.bww = bww; a.steps = steps; a.nsplit_tiles = NT;
   a.half_c = io.half_c; a.half_cp = io.half_cp; a.out_f32 = io.out_f32; a.stamps = io.stamps;
   a.w2 = d_w2.p; a.bias2 = d_bias2.as<float>(); a.act2 = act2; a.Cout2 = Cout2;
+  a.zeros = d_bias.as<float>() + round_up(Cout, 64);  // the bias buffer ends in 64 zero floats
   LP_CHECK(io.in.C == Cin, LP_ERR_STATE, "conv input view has %d channels, layer expects %d", io.in.C, Cin);
   LP_CHECK(io.x1.base || io.out.C >= (T2 ? Cout2 : Cout) || io.out_f32, LP_ERR_STATE, "conv output view too narrow (%d < %d)", io.out.C, T2 ? Cout2 : Cout);
   LP_CHECK((io.in.pitch % 8) == 0 && (io.out.pitch % 4) == 0, LP_ERR_STATE, "unaligned channel pitch");
