@@ -181,7 +181,8 @@ def test_roi_resize_bit_exact_vs_pillow(eng16):
     from oracle import pil_resize_ref as R
     rng = np.random.default_rng(3)
     sizes = [(10, 10), (28, 27), (24, 24), (65, 73), (72, 84), (22, 23), (18, 21), (64, 64), (64, 30), (30, 64), (1, 1),
-             (7, 200), (200, 7), (129, 257), (500, 300), (63, 65), (640, 640), (2, 3)]
+             (7, 200), (200, 7), (129, 257), (500, 300), (63, 65), (640, 640), (2, 3),
+             (128, 192), (128, 104), (129, 10), (100, 193), (127, 111), (5, 191)]  # tiny / small / large path boundaries
     rois = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
     out = eng16.test_roi_resize(rois)
     for roi, got in zip(rois, out):

@@ -21,6 +21,7 @@ struct ConvLayer {
   // MFMA tiling
   int NT = 1, nsplits = 1, CK = 0, CGc = 0, nchunks = 1, steps = 0, LW = 0, PS = 0, bwh = 2, bww = 2;
   size_t lds_bytes = 0;
+  unsigned rcp_cg = 0, rcp_ps = 0;  // 16-bit reciprocals of CGc and PS/16 for the 3x3 kernel's prologue
   bool direct = false;  // 3x3 stride-2: gather B fragments from global memory (no LDS input tile)
   DevBuf d_w, d_bias;
   // fused 1x1 tail conv (second GEMM in the epilogue): 0 = none, else its 16-channel output tiles

@@ -120,14 +120,23 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0,
 // registers (hoisted out of the epilogue: 20 dependent global loads per lane otherwise), fp16
 // results leave as 16-byte stores (two channel quads at a time).
 template <typename T, int NT, int ACT>
+__device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int Cout, const floatx4 (&v)[NT], const floatx4 (&bias)[NT]);
+
+template <typename T, int NT, int ACT>
 __device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chbase, const floatx4 (&v)[NT],
                                            const floatx4 (&bias)[NT]) {
   T* o = reinterpret_cast<T*>(a.out) + pix * a.out_pitch + chbase;
   const T* r = a.res ? reinterpret_cast<const T*>(a.res) + pix * a.res_pitch + chbase : nullptr;
+  store_lane_at<T, NT, ACT>(o, r, chbase, a.Cout, v, bias);
+}
+
+// o / r already point at this lane's first channel of the pixel
+template <typename T, int NT, int ACT>
+__device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int Cout, const floatx4 (&v)[NT], const floatx4 (&bias)[NT]) {
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int t = 0; t + 1 < NT; t += 2) {
-      if (chbase + t * 4 < a.Cout) {
+      if (chbase + t * 4 < Cout) {
         half8 q;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -144,7 +153,7 @@ __device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chba
     }
     if (NT & 1) {
       constexpr int t = NT - 1;
-      if (chbase + t * 4 < a.Cout) {
+      if (chbase + t * 4 < Cout) {
         half4 q;
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = (half_t)activate_ct<T, ACT>(v[t][i] + bias[t][i]);
@@ -159,7 +168,7 @@ __device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chba
   } else {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (chbase + t * 4 < a.Cout) {
+      if (chbase + t * 4 < Cout) {
         floatx4 q;
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = activate_ct<T, ACT>(v[t][i] + bias[t][i]);
@@ -235,15 +244,20 @@ __device__ __forceinline__ void tail_load(const ConvArgs& a, int lane, int g, ty
 template <typename T, int NT, int ACT>
 __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const floatx4 (&acc)[NT][5], const floatx4 (&bias)[NT], int n,
                                               int ns, int g, int oy, int oxb) {
+  if (oy >= a.Hout) return;
+  // the five patches of a strip are 4 pixels apart on one row: one address computation, then fixed strides
+  const int chbase = ns * 16 * NT + g * 4 * NT;
+  const long pix0 = (long)(n * a.Hout + oy) * a.Wout + oxb;
+  T* o = reinterpret_cast<T*>(a.out) + pix0 * a.out_pitch + chbase;
+  const T* r = a.res ? reinterpret_cast<const T*>(a.res) + pix0 * a.res_pitch + chbase : nullptr;
+  const int ostep = 4 * a.out_pitch, rstep = 4 * a.res_pitch;
 #pragma unroll
   for (int p = 0; p < 5; ++p) {
-    const int ox = oxb + p * 4;
-    if (oy < a.Hout && ox < a.Wout) {
-      const long pix = (long)(n * a.Hout + oy) * a.Wout + ox;
+    if (oxb + p * 4 < a.Wout) {
       floatx4 v[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) v[t] = acc[t][p];
-      store_lane<T, NT, ACT>(a, pix, ns * 16 * NT + g * 4 * NT, v, bias);
+      store_lane_at<T, NT, ACT>(o + p * ostep, r ? r + p * rstep : nullptr, chbase, a.Cout, v, bias);
     }
   }
 }
@@ -295,9 +309,11 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int g = lane >> 4, col = lane & 15;
-  const int wy = wave / a.bww, wx = wave - wy * a.bww;
+  // prologue arithmetic is a large part of a small layer's workgroup life (hundreds of instructions per integer
+  // division): every division here is a multiply by a host-checked 16-bit reciprocal (ConvLayer::launch)
+  const int wy = a.bww == 2 ? wave >> 1 : wave, wx = wave - wy * a.bww;
   const int TH = 4 * a.bwh, TW = 20 * a.bww;
-  const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+  const int ty = (int)((blockIdx.x * a.rcp_tx) >> 16), tx = blockIdx.x - ty * a.tiles_x;
   const int n = blockIdx.y, ns = blockIdx.z;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
@@ -311,10 +327,10 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
   const int RS = LW * (PS >> 4);           // 16-byte slots per tile row (pads included)
   const int bufbytes = wbytes + IH * RS * 16;
   for (int q = tid; q < Sc * 4; q += nthr) {  // byte offset of K group q inside the input tile: (tap, channel group)
-    int tap = q / CGc;
+    int tap = (int)(((unsigned)q * a.rcp_cg) >> 16);
     const int cg = q - tap * CGc;
     tap = tap > 8 ? 8 : tap;  // K padding slots: weights are zero, read any finite data
-    const int ky = tap / 3, kx = tap - 3 * ky;
+    const int ky = (tap * 21846) >> 16, kx = tap - 3 * ky;
     lds_toff[q] = (ky * LW + kx) * PS + cg * 16;
   }
 
@@ -334,11 +350,13 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
   int soff[MAXP];
 #pragma unroll
   for (int pc = 0; pc < MAXP; ++pc) {
-    const int sl = pc * 64 + lane;
-    const int ix = sl / PSs, cgs = sl - ix * PSs;
-    const int gx = ix0 + ix;
-    soff[pc] = (ix < IW && cgs < CGc && gx >= 0 && gx < a.Win) ? (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : -1;
-    if (sl >= RS) soff[pc] = -2;  // no slot: lane stays idle for this piece
+    soff[pc] = -2;  // no slot: lane stays idle for this piece
+    if (pc < pcs) {
+      const int sl = pc * 64 + lane;
+      const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
+      const int gx = ix0 + ix;
+      if (sl < RS) soff[pc] = (ix < IW && cgs < CGc && gx >= 0 && gx < a.Win) ? (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : -1;
+    }
   }
   const char* zeros = reinterpret_cast<const char*>(a.zeros);
   const char* in_b = reinterpret_cast<const char*>(a.in);
@@ -899,6 +917,13 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     LP_CHECK(steps * 4 <= 128, LP_ERR_GRAPH, "conv3x3: too many K steps per chunk");
     lds_bytes = 512 + (nchunks > 1 ? 2 : 1) * ((size_t)steps * NT * 1024 + (size_t)IH * LW * PS);
     LP_CHECK(ceil_div(LW * (PS / 16), 64) <= 8, LP_ERR_GRAPH, "conv3x3: LDS tile row too wide");
+    auto rcp16 = [&](int d, int range) {  // x / d == (x * m) >> 16 for x < range (kernel prologue)
+      const unsigned m = (65536u + d - 1) / d;
+      for (int x = 0; x < range; ++x) LP_CHECK((int)((x * m) >> 16) == x / d, LP_ERR_STATE, "reciprocal of %d not exact at %d", d, x);
+      return m;
+    };
+    rcp_cg = rcp16(CGc, 128);
+    rcp_ps = rcp16(PS / 16, 512);
     LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv3x3 tile does not fit LDS (%zu B)", lds_bytes);
   } else {
     NT = pick_nt(ceil_div((long)B * hout * wout, 256));
@@ -1077,6 +1102,14 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
     a.tiles_y = ceil_div(a.Hout, TH);
     dim3 grid(a.tiles_x * a.tiles_y, io.N, nsplits);
     const int threads = 64 * bwh * bww;
+    // 16-bit reciprocals for the kernel's prologue: x / d == (x * ceil(65536 / d)) >> 16 on the ranges used
+    auto rcp16 = [&](int d, int range) {
+      const unsigned m = (65536u + d - 1) / d;
+      for (int x = 0; x < range; ++x) LP_CHECK((int)((x * m) >> 16) == x / d, LP_ERR_STATE, "reciprocal of %d not exact at %d", d, x);
+      return m;
+    };
+    a.rcp_tx = rcp16(a.tiles_x, a.tiles_x * a.tiles_y);
+    a.rcp_cg = rcp_cg; a.rcp_ps = rcp_ps;  // checked once in build()
 #define LP_L3(TT)                                                                  \
   switch (NT) {                                                                    \
     case 1: launch3x3<TT, 1>(a, stride, grid, threads, lds_bytes, st); break;      \
