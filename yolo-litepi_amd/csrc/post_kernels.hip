@@ -334,35 +334,34 @@ void launch_roi_index(const int* counts, const RoiTable& t, int N, int max_det, 
 // ------------------------------------------------------------------------------------
 #define RR_THREADS 1024  /* 16 waves: the byte gathers are latency-bound, TLP hides them */
 #define RR_PRECISION_BITS 22
-// "tiny" variant (the usual traffic-sign crop): sides <= 128 x 192 px and <= 40 KB of pixels.  The crop is first
-// copied into LDS with coalesced dword loads (the horizontal pass gathers 3..7 bytes per output sample: from
-// global memory that is one texture-path request per byte and was the whole cost of this kernel), then both
-// passes run out of LDS; 69 KB per workgroup, so two ROIs per CU.
-// "small" variant: ROI sides <= 384 px (support <= 6 -> at most 13 taps); the whole
-// horizontally-resampled crop [in_h][S][3] lives in LDS, so a ROI costs two barriers.
-// "large" variant: sides up to 4096 px (129 taps), one output row at a time.
+// "banded" variants (sides <= 384 px: support <= 6 -> at most 13 taps): the crop is copied into LDS in bands of
+// rows with coalesced dword loads (the horizontal pass gathers 3..13 bytes per output sample: from global memory
+// that is one texture-path request per byte and was the whole cost of this kernel), each band is resampled
+// horizontally into the uint8 intermediate image [in_h][S][3] (Pillow's intermediate), then the vertical pass runs.
+//   tiny : in_h <= 128 (the usual traffic-sign crop): 72 KB of LDS per workgroup, two ROIs per CU
+//   small: in_h <= 384: 121 KB
+// "large" variant: sides up to 4096 px (129 taps), one output row at a time, taps gathered from global memory.
 #define RR_TINY_H 128
-#define RR_TINY_W 192
-#define RR_TINY_K 8
-#define RR_TINY_SRC (40 * 1024)
 #define RR_SMALL_SIDE 384
 #define RR_SMALL_K 13
+#define RR_BAND_BYTES (40 * 1024)
 #define RR_LARGE_K 129
 enum { RR_MODE_TINY = 0, RR_MODE_SMALL = 1, RR_MODE_LARGE = 2 };
 
 size_t roi_resize_lds_bytes() { return (size_t)2 * 64 * RR_LARGE_K * 4 + 4 * 64 * 4 + (size_t)RR_LARGE_K * 64 * 3 + 64; }
-static size_t roi_resize_small_lds() { return (size_t)2 * 64 * RR_SMALL_K * 4 + 4 * 64 * 4 + (size_t)RR_SMALL_SIDE * 64 * 3 + 64; }
-static size_t roi_resize_tiny_lds() { return (size_t)2 * 64 * RR_TINY_K * 4 + 4 * 64 * 4 + (size_t)RR_TINY_H * 64 * 3 + RR_TINY_SRC + 64; }
+static size_t roi_resize_banded_lds(int rows) { return (size_t)2 * 64 * RR_SMALL_K * 4 + 4 * 64 * 4 + (size_t)rows * 64 * 3 + RR_BAND_BYTES + 64; }
 
 // row pitch of the crop's LDS copy: the row's bytes keep their global address modulo 4 (aligned dword copies)
-__device__ __forceinline__ int rr_tiny_pitch(int in_w) { return (in_w * 3 + 3 + 3) & ~3; }
+__device__ __forceinline__ int rr_band_pitch(int in_w) { return (in_w * 3 + 3 + 3) & ~3; }
 __device__ __forceinline__ int rr_mode(int in_w, int in_h) {
-  if (in_w <= RR_TINY_W && in_h <= RR_TINY_H && rr_tiny_pitch(in_w) * in_h <= RR_TINY_SRC) return RR_MODE_TINY;
+  if (in_w <= RR_SMALL_SIDE && in_h <= RR_TINY_H) return RR_MODE_TINY;
   if (in_w <= RR_SMALL_SIDE && in_h <= RR_SMALL_SIDE) return RR_MODE_SMALL;
   return RR_MODE_LARGE;
 }
 
-__device__ void pil_coeffs(int in_size, int out_size, int xx, int* k, int* xmin_out, int* n_out) {
+// tap x of output index xx (Pillow's precompute_coeffs + normalize_coeffs_8bpc, one tap per thread); the x == 0 thread also
+// writes the window bounds {xmin, n}
+__device__ void pil_coeff_tap(int in_size, int out_size, int xx, int x, int* k, int* bounds) {
   const double scale = (double)in_size / (double)out_size;
   const double filterscale = scale < 1.0 ? 1.0 : scale;
   const double support = 1.0 * filterscale;
@@ -373,21 +372,19 @@ __device__ void pil_coeffs(int in_size, int out_size, int xx, int* k, int* xmin_
   int xmax = (int)(center + support + 0.5);
   if (xmax > in_size) xmax = in_size;
   xmax -= xmin;
+  if (x == 0) { bounds[0] = xmin; bounds[1] = xmax; }
+  if (x >= xmax) return;
   double ww = 0.0;
-  for (int x = 0; x < xmax; ++x) {
-    double v = (x + xmin - center + 0.5) * ss;
+  for (int t = 0; t < xmax; ++t) {
+    double v = (t + xmin - center + 0.5) * ss;
     v = v < 0 ? -v : v;
     ww += v < 1.0 ? 1.0 - v : 0.0;
   }
-  for (int x = 0; x < xmax; ++x) {
-    double v = (x + xmin - center + 0.5) * ss;
-    v = v < 0 ? -v : v;
-    double w = v < 1.0 ? 1.0 - v : 0.0;
-    if (ww != 0.0) w /= ww;
-    k[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << RR_PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << RR_PRECISION_BITS));
-  }
-  *xmin_out = xmin;
-  *n_out = xmax;
+  double v = (x + xmin - center + 0.5) * ss;
+  v = v < 0 ? -v : v;
+  double w = v < 1.0 ? 1.0 - v : 0.0;
+  if (ww != 0.0) w /= ww;
+  k[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << RR_PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << RR_PRECISION_BITS));
 }
 
 __device__ __forceinline__ uint8_t clip8(int v) {
@@ -421,102 +418,78 @@ __global__ __launch_bounds__(RR_THREADS) void roi_resize_kernel(const RoiResizeA
       continue;
     }
     __syncthreads();
-    if (tid < S)
-      pil_coeffs(in_w, S, tid, kx + tid * MAXK, bx + 2 * tid, bx + 2 * tid + 1);
-    else if (tid >= 64 && tid < 64 + S)
-      pil_coeffs(in_h, S, tid - 64, ky + (tid - 64) * MAXK, by + 2 * (tid - 64), by + 2 * (tid - 64) + 1);
+    // one thread per (axis, output index, tap): Pillow's double arithmetic in Pillow's order (the weight sum is
+    // re-done by every tap's thread), so the table costs one division of latency instead of a serial loop
+    for (int i = tid; i < 2 * 64 * MAXK; i += RR_THREADS) {
+      const int axis = i / (64 * MAXK), rem = i - axis * (64 * MAXK);
+      const int xx = rem / MAXK, x = rem - xx * MAXK;
+      if (xx < S) pil_coeff_tap(axis ? in_h : in_w, S, xx, x, (axis ? ky : kx) + xx * MAXK, (axis ? by : bx) + 2 * xx);
+    }
     __syncthreads();
-    if (MODE == RR_MODE_TINY) {
-      // 1. crop -> LDS, aligned dwords (a row's bytes keep their address modulo 4)
-      uint8_t* crop = tmp + RR_TINY_H * 64 * 3;
-      const int pitch = rr_tiny_pitch(in_w);
+    if (MODE != RR_MODE_LARGE) {
+      constexpr int TMP_ROWS = MODE == RR_MODE_TINY ? RR_TINY_H : RR_SMALL_SIDE;
+      uint8_t* crop = tmp + TMP_ROWS * 64 * 3;
+      const int pitch = rr_band_pitch(in_w);
       const uint8_t* img_end = src + (long)gm.h * gm.w * 3;
       const int dpr = pitch >> 2;  // dwords per row
-      for (int i = tid; i < in_h * dpr; i += RR_THREADS) {
-        const int row = i / dpr, j = i - row * dpr;
-        const uint8_t* rp = src + ((long)(ry + row) * gm.w + rx) * 3;
-        const uint8_t* ap = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(rp) & ~(uintptr_t)3) + 4 * j;
-        uint32_t v = 0;
-        if (ap >= src && ap + 4 <= img_end) {
-          v = *reinterpret_cast<const uint32_t*>(ap);
-        } else {  // the image's first / last bytes: never read outside the caller's buffer
-          for (int b = 0; b < 4; ++b)
-            if (ap + b >= src && ap + b < img_end) v |= (uint32_t)ap[b] << (8 * b);
-        }
-        *reinterpret_cast<uint32_t*>(crop + row * pitch + 4 * j) = v;
-      }
-      __syncthreads();
-      // 2. horizontal pass: one thread per (row, xx), three channels
-      for (int i = tid; i < in_h * S; i += RR_THREADS) {
-        const int row = S == 64 ? i >> 6 : i / S, xx = i - row * S;
-        const int xmin = bx[2 * xx], nx = bx[2 * xx + 1];
-        const uint8_t* rp = src + ((long)(ry + row) * gm.w + rx) * 3;
-        const uint8_t* p = crop + row * pitch + (int)(reinterpret_cast<uintptr_t>(rp) & 3) + xmin * 3;
-        uint8_t* o = tmp + (row * S + xx) * 3;
-        if (in_w == S) {  // Pillow skips the pass when the width already matches (identity either way)
-          o[0] = p[2]; o[1] = p[1]; o[2] = p[0];
-        } else {
-          const int* k = kx + xx * MAXK;
-          int a0 = half, a1 = half, a2 = half;
-          for (int x = 0; x < nx; ++x) {
-            const int w = k[x];
-            a0 += (int)p[x * 3 + 2] * w;  // BGR -> RGB
-            a1 += (int)p[x * 3 + 1] * w;
-            a2 += (int)p[x * 3 + 0] * w;
+      const int rpb = RR_BAND_BYTES / pitch;  // rows per band (>= 35)
+      for (int r0 = 0; r0 < in_h; r0 += rpb) {
+        const int nb = in_h - r0 < rpb ? in_h - r0 : rpb;
+        // 1. band -> LDS, aligned dwords
+        for (int i = tid; i < nb * dpr; i += RR_THREADS) {
+          const int row = i / dpr, j = i - row * dpr;
+          const uint8_t* rp = src + ((long)(ry + r0 + row) * gm.w + rx) * 3;
+          const uint8_t* ap = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(rp) & ~(uintptr_t)3) + 4 * j;
+          uint32_t v = 0;
+          if (ap >= src && ap + 4 <= img_end) {
+            v = *reinterpret_cast<const uint32_t*>(ap);
+          } else {  // the image's first / last bytes: never read outside the caller's buffer
+            for (int b = 0; b < 4; ++b)
+              if (ap + b >= src && ap + b < img_end) v |= (uint32_t)ap[b] << (8 * b);
           }
-          o[0] = clip8(a0); o[1] = clip8(a1); o[2] = clip8(a2);
+          *reinterpret_cast<uint32_t*>(crop + row * pitch + 4 * j) = v;
         }
-      }
-      __syncthreads();
-      for (int i = tid; i < S * S * 3; i += RR_THREADS) {
-        const int yy = i / (S * 3), j = i - yy * S * 3;
-        const int ymin = by[2 * yy], ny = by[2 * yy + 1];
-        uint8_t v;
-        if (in_h == S) {
-          v = tmp[(ymin)*S * 3 + j];
-        } else {
-          const int* k = ky + yy * MAXK;
-          int acc = half;
-          for (int y = 0; y < ny; ++y) acc += (int)tmp[(ymin + y) * S * 3 + j] * k[y];
-          v = clip8(acc);
-        }
-        out[i] = v;
-      }
-    } else if (MODE == RR_MODE_SMALL) {
-      // horizontal pass of every source row into LDS (uint8, as Pillow's intermediate image)
-      for (int i = tid; i < in_h * S * 3; i += RR_THREADS) {
-        const int c = i % 3, xx = (i / 3) % S, row = i / (3 * S);
-        const int xmin = bx[2 * xx], nx = bx[2 * xx + 1];
-        const uint8_t* p = src + ((long)(ry + row) * gm.w + rx + xmin) * 3 + (2 - c);  // BGR -> RGB
-        uint8_t v;
-        if (in_w == S) {
-          v = p[0];  // Pillow skips the pass when the width already matches (identity either way)
-        } else {
-          const int* k = kx + xx * MAXK;
-          int acc = half;
-#pragma unroll
-          for (int x = 0; x < MAXK; ++x) {  // fixed trip count: every tap's byte load is in flight at once
-            const int xi = x < nx ? x : nx - 1;
-            acc += (int)p[xi * 3] * (x < nx ? k[x] : 0);
+        __syncthreads();
+        // 2. horizontal pass of the band: one thread per (row, xx), three channels, BGR -> RGB
+        for (int i = tid; i < nb * S; i += RR_THREADS) {
+          const int row = S == 64 ? i >> 6 : i / S, xx = i - row * S;
+          const int xmin = bx[2 * xx], nx = bx[2 * xx + 1];
+          const uint8_t* rp = src + ((long)(ry + r0 + row) * gm.w + rx) * 3;
+          const uint8_t* p = crop + row * pitch + (int)(reinterpret_cast<uintptr_t>(rp) & 3) + xmin * 3;
+          uint8_t* o = tmp + ((r0 + row) * S + xx) * 3;
+          if (in_w == S) {  // Pillow skips the pass when the width already matches (identity either way)
+            o[0] = p[2]; o[1] = p[1]; o[2] = p[0];
+          } else {
+            const int* k = kx + xx * MAXK;
+            int a0 = half, a1 = half, a2 = half;
+            for (int x = 0; x < nx; ++x) {
+              const int w = k[x];
+              a0 += (int)p[x * 3 + 2] * w;
+              a1 += (int)p[x * 3 + 1] * w;
+              a2 += (int)p[x * 3 + 0] * w;
+            }
+            o[0] = clip8(a0); o[1] = clip8(a1); o[2] = clip8(a2);
           }
-          v = clip8(acc);
         }
-        tmp[i] = v;
+        __syncthreads();
       }
-      __syncthreads();
-      for (int i = tid; i < S * S * 3; i += RR_THREADS) {
-        const int yy = i / (S * 3), j = i - yy * S * 3;
-        const int ymin = by[2 * yy], ny = by[2 * yy + 1];
-        uint8_t v;
-        if (in_h == S) {
-          v = tmp[(ymin)*S * 3 + j];
-        } else {
-          const int* k = ky + yy * MAXK;
-          int acc = half;
-          for (int y = 0; y < ny; ++y) acc += (int)tmp[(ymin + y) * S * 3 + j] * k[y];
-          v = clip8(acc);
+      // 3. vertical pass: a thread keeps its column (j = byte of the 3S-byte output row) and strides over rows
+      const int rowb = S * 3, lanes_rows = RR_THREADS / rowb;
+      const int yo = tid / rowb, j = tid - yo * rowb;
+      if (yo < lanes_rows) {
+        for (int yy = yo; yy < S; yy += lanes_rows) {
+          const int ymin = by[2 * yy], ny = by[2 * yy + 1];
+          uint8_t v;
+          if (in_h == S) {
+            v = tmp[ymin * rowb + j];
+          } else {
+            const int* k = ky + yy * MAXK;
+            int acc = half;
+            for (int y = 0; y < ny; ++y) acc += (int)tmp[(ymin + y) * rowb + j] * k[y];
+            v = clip8(acc);
+          }
+          out[yy * rowb + j] = v;
         }
-        out[i] = v;
       }
     } else {
       for (int yy = 0; yy < S; ++yy) {
@@ -560,12 +533,12 @@ void launch_roi_resize(const RoiResizeArgs& a, hipStream_t st) {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
                       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel<RR_SMALL_K, RR_MODE_SMALL>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel<RR_TINY_K, RR_MODE_TINY>),
+                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel<RR_SMALL_K, RR_MODE_TINY>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
   (void)once;
   LP_CHECK(a.S <= 64, LP_ERR_ARG, "classifier input larger than 64 unsupported by the resize kernel");
-  hipLaunchKernelGGL((roi_resize_kernel<RR_TINY_K, RR_MODE_TINY>), dim3(512), dim3(RR_THREADS), roi_resize_tiny_lds(), st, a);
-  hipLaunchKernelGGL((roi_resize_kernel<RR_SMALL_K, RR_MODE_SMALL>), dim3(256), dim3(RR_THREADS), roi_resize_small_lds(), st, a);
+  hipLaunchKernelGGL((roi_resize_kernel<RR_SMALL_K, RR_MODE_TINY>), dim3(512), dim3(RR_THREADS), roi_resize_banded_lds(RR_TINY_H), st, a);
+  hipLaunchKernelGGL((roi_resize_kernel<RR_SMALL_K, RR_MODE_SMALL>), dim3(256), dim3(RR_THREADS), roi_resize_banded_lds(RR_SMALL_SIDE), st, a);
   hipLaunchKernelGGL((roi_resize_kernel<RR_LARGE_K, RR_MODE_LARGE>), dim3(128), dim3(RR_THREADS), roi_resize_lds_bytes(), st, a);
   LP_HIP(hipGetLastError());
 }
