@@ -118,6 +118,21 @@ struct ConvArgs {
   unsigned long long* stamps;  // diagnostic only (lp_test_conv + LITEPI_STAMPS): 16 clock stamps per workgroup
 };
 
+// Fused C2f bottleneck: out = in + silu(conv3x3(silu(conv3x3(in)))) (bottleneck_mfma_kernel)
+struct BneckArgs {
+  const void* in;
+  void* out;
+  const void* w1;   // fragment-ordered weights of the two convs, all of K in one chunk: [step][tile][lane][16 B]
+  const void* w2;
+  const float* b1;
+  const float* b2;
+  const void* zeros;
+  int N, H, W, C;   // C: physical channels (in == mid == out)
+  int in_pitch, out_pitch;
+  int TH, TW, tiles_x, LW, PS, CG, steps;
+  unsigned rcp_tx, rcp_cg, rcp_ps, rcp_w1, rcp_tw;
+};
+
 enum ConvImpl { IMPL_MFMA = 0, IMPL_NAIVE = 1 };
 enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 

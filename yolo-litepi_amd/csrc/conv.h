@@ -35,13 +35,31 @@ struct ConvLayer {
   // per call at capacity -- together they pick the tile shape and the channel split.
   void build(int prec, int impl, int k, int stride, int cin, int cout, int act,
              const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout, int batch_hint,
-             bool full_n = false);
+             bool full_n = false, bool single_chunk = false);
   // Fuse a following 1x1 conv (weights w2_phys [cout2][Cout] over physical channels) into this 3x3 layer.
   // Requires build(..., full_n = true) (one workgroup holds every intermediate channel).  The fused layer's
   // output view then has cout2 channels.
   static bool tail_supported(int k, int stride, int cmid_phys, int cout2_phys);
   void attach_tail(int cout2_phys, int act2, const std::vector<float>& w2_phys, const std::vector<float>& bias2_phys);
   void launch(const ConvIO& io, hipStream_t st) const;
+};
+
+// C2f bottleneck x + silu(conv3x3(silu(conv3x3(x)))) as ONE launch (bottleneck_mfma_kernel): the
+// intermediate lives in LDS.  The two ConvLayers only carry the packed weights (all of K in one chunk).
+struct BottleneckPair {
+  ConvLayer a, b;
+  int prec = LP_FP16, C = 0, NT = 1, TH = 8, TW = 40, LW = 0, PS = 0, CG = 0, steps = 0;
+  unsigned rcp_cg = 0, rcp_ps = 0, rcp_w1 = 0, rcp_tw = 0;
+  size_t lds_bytes = 0;
+  std::string name;
+  // can a C->C bottleneck on an h x w map (batch_hint images) run fused?  (LDS capacity, tile limits)
+  static bool supported(int prec, int impl, int c_phys, int h, int w, int batch_hint);
+  // weights as for ConvLayer::build: fp32 [C][9][C] over physical channels, bias [C]
+  void build(int prec, int c_phys, const std::vector<float>& wa, const std::vector<float>& ba, const std::vector<float>& wb,
+             const std::vector<float>& bb, int h, int w, int batch_hint);
+  void launch(const View& in, const View& out, int N, hipStream_t st) const;
+ private:
+  static bool plan(int prec, int c_phys, int h, int w, int batch_hint, int& th, int& tw, int& lw, size_t& lds);
 };
 
 // First layer: 3x3 stride-2 conv reading the uint8 BGR image directly.

@@ -451,6 +451,189 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
   if (a.stamps && threadIdx.x == 0) a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 12] = wall_clock64();
 }
 
+
+// ------------------------------------------------------------------------------------
+// Fused C2f bottleneck (two 3x3 convs + SiLU + shortcut) in one launch:
+//     out = x + silu(conv_b(silu(conv_a(x))))          (reference graph: C2f.m[i], model.ncnn.param)
+// One workgroup (4 waves) owns a TH x TW output tile.  It stages the (TH+4) x (TW+4) input tile and BOTH
+// weight sets by LDS-DMA, computes conv_a on the (TH+2) x (TW+2) region conv_b needs (zero outside the image:
+// that is conv_b's padding), writes it back over the input tile in LDS (rounded to T, exactly what a store +
+// reload would give), runs conv_b from there and finishes with the usual bias/SiLU/residual epilogue.  The
+// intermediate never leaves the CU: one launch and one HBM round trip less per bottleneck.
+// Pixels are mapped linearly (tile q of a wave = 16 consecutive pixels of the region, row-major), so the
+// (TH+2) x (TW+2) region costs ceil(/16) MFMA column tiles instead of whole 4x4 patches.
+// ------------------------------------------------------------------------------------
+// P1 / P2: pixel tiles per wave for conv_a / conv_b (compile time: the K loops are branch-free, a wave's surplus
+// tile recomputes the region's last pixel and is never written)
+template <typename T, int NT, int P1, int P2>
+__global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel(const BneckArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = Tr<T>::G;
+  constexpr int MAXP = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int ty = (int)((blockIdx.x * a.rcp_tx) >> 16), tx = blockIdx.x - ty * a.tiles_x;
+  const int n = blockIdx.y;
+  const int TH = a.TH, TW = a.TW, LW = a.LW, PS = a.PS, S = a.steps, CG = a.CG;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int IH = TH + 4, IW = TW + 4, H1 = TH + 2, W1 = TW + 2;
+  const int R1 = H1 * W1, R2 = TH * TW;
+  const int n1 = (R1 + 15) >> 4, n2 = (R2 + 15) >> 4;
+
+  // LDS: [tap table 512 B][conv_a fragments S*NT KB][conv_b fragments S*NT KB][tile: input, later the intermediate]
+  int* lds_toff = reinterpret_cast<int*>(smem);
+  const int wbytes = S * NT * 1024;
+  const u32x4* lds_w1 = reinterpret_cast<const u32x4*>(smem + 512);
+  const u32x4* lds_w2 = reinterpret_cast<const u32x4*>(smem + 512 + wbytes);
+  char* tile = smem + 512 + 2 * wbytes;
+  for (int q = tid; q < S * 4; q += 256) {
+    int tap = (int)(((unsigned)q * a.rcp_cg) >> 16);
+    const int cg = q - tap * CG;
+    tap = tap > 8 ? 8 : tap;
+    const int ky = (tap * 21846) >> 16, kx = tap - 3 * ky;
+    lds_toff[q] = (ky * LW + kx) * PS + cg * 16;
+  }
+
+  // ---- stage: both weight sets and the halo-2 input tile (see conv3x3_mfma_kernel for the slot map)
+  const int RS = LW * (PS >> 4), PSs = PS >> 4;
+  const int pcs = (RS + 63) >> 6;
+  const int iy0 = oy0 - 2, ix0 = ox0 - 2;
+  const char* zeros = reinterpret_cast<const char*>(a.zeros);
+  {
+    for (int p = wave; p < 2 * S * NT; p += 4) {
+      const u32x4* src = p < S * NT ? reinterpret_cast<const u32x4*>(a.w1) + p * 64 : reinterpret_cast<const u32x4*>(a.w2) + (p - S * NT) * 64;
+      LP_GLDS16(src + lane, smem + 512 + p * 1024);
+    }
+    int soff[MAXP];
+#pragma unroll
+    for (int pc = 0; pc < MAXP; ++pc) {
+      soff[pc] = -2;
+      if (pc < pcs) {
+        const int sl = pc * 64 + lane;
+        const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
+        const int gx = ix0 + ix;
+        if (sl < RS) soff[pc] = (ix < IW && cgs < CG && gx >= 0 && gx < a.W) ? (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : -1;
+      }
+    }
+    const char* in_b = reinterpret_cast<const char*>(a.in);
+    for (int iy = wave; iy < IH; iy += 4) {
+      const int gy = iy0 + iy;
+      const bool rowok = gy >= 0 && gy < a.H;
+      const char* rowp = in_b + ((long)(n * a.H + gy) * a.W + ix0) * a.in_pitch * (long)sizeof(T);
+#pragma unroll
+      for (int pc = 0; pc < MAXP; ++pc) {
+        if (pc < pcs && soff[pc] != -2) {
+          const char* src = (rowok && soff[pc] >= 0) ? rowp + soff[pc] : zeros;
+          LP_GLDS16(src, tile + (iy * RS + pc * 64) * 16);
+        }
+      }
+    }
+  }
+  floatx4 bias1[NT], bias2[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    bias1[t] = *reinterpret_cast<const floatx4*>(a.b1 + g * 4 * NT + t * 4);
+    bias2[t] = *reinterpret_cast<const floatx4*>(a.b2 + g * 4 * NT + t * 4);
+  }
+
+  // ---- conv_a over the (TH+2) x (TW+2) region
+  int pk1[P1], pb1[P1];  // (py << 16) | px of this lane's pixel in tile i (clamped inside the region); its LDS offset
+#pragma unroll
+  for (int i = 0; i < P1; ++i) {
+    int p = (wave + 4 * i) * 16 + col;
+    p = p < R1 ? p : R1 - 1;
+    const int py = (int)(((unsigned)p * a.rcp_w1) >> 16), px = p - py * W1;
+    pk1[i] = (py << 16) | px;
+    pb1[i] = (py * LW + px) * PS;
+  }
+  floatx4 acc[NT][P1];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < P1; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < S; ++s) {
+    const int toff = lds_toff[4 * s + g];
+    typename Tr<T>::frag af[NT], bf[P1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w1[(s * NT + t) * 64 + lane]);
+#pragma unroll
+    for (int i = 0; i < P1; ++i) bf[i] = as_frag<T>(*reinterpret_cast<const u32x4*>(tile + pb1[i] + toff));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < P1; ++i) acc[t][i] = Tr<T>::mma(af[t], bf[i], acc[t][i]);
+  }
+  // ---- the intermediate replaces the input tile (every wave is done reading it after the barrier)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < P1; ++i) {
+    const int p = (wave + 4 * i) * 16 + col;
+    if (wave + 4 * i < n1 && p < R1) {
+      const int py = pk1[i] >> 16, px = pk1[i] & 0xffff;
+      const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
+      const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      T* dst = reinterpret_cast<T*>(tile + (py * LW + px) * PS) + g * 4 * NT;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (g * 4 * NT + t * 4 < a.C) {
+          typename Tr<T>::quad q;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q[r] = inside ? (T)activate_ct<T, ACT_SILU>(acc[t][i][r] + bias1[t][r]) : (T)0.f;
+          *reinterpret_cast<typename Tr<T>::quad*>(dst + t * 4) = q;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- conv_b over the TH x TW output tile
+  int pk2[P2], pb2[P2];
+#pragma unroll
+  for (int i = 0; i < P2; ++i) {
+    int p = (wave + 4 * i) * 16 + col;
+    p = p < R2 ? p : R2 - 1;
+    const int oy = (int)(((unsigned)p * a.rcp_tw) >> 16), ox = p - oy * TW;
+    pk2[i] = (oy << 16) | ox;
+    pb2[i] = (oy * LW + ox) * PS;
+  }
+  floatx4 acc2[NT][P2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < P2; ++i) acc2[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    const int toff = lds_toff[4 * s + g];
+    typename Tr<T>::frag af[NT], bf[P2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w2[(s * NT + t) * 64 + lane]);
+#pragma unroll
+    for (int i = 0; i < P2; ++i) bf[i] = as_frag<T>(*reinterpret_cast<const u32x4*>(tile + pb2[i] + toff));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < P2; ++i) acc2[t][i] = Tr<T>::mma(af[t], bf[i], acc2[t][i]);
+  }
+  // ---- epilogue: bias, SiLU, shortcut (x re-read from global: L2-hot, this workgroup just staged it)
+  const int chbase = g * 4 * NT;
+#pragma unroll
+  for (int i = 0; i < P2; ++i) {
+    const int p = (wave + 4 * i) * 16 + col;
+    const int gy = oy0 + (pk2[i] >> 16), gx = ox0 + (pk2[i] & 0xffff);
+    if (wave + 4 * i < n2 && p < R2 && gy < a.H && gx < a.W) {
+      const long pix = (long)(n * a.H + gy) * a.W + gx;
+      floatx4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = acc2[t][i];
+      store_lane_at<T, NT, ACT_SILU>(reinterpret_cast<T*>(a.out) + pix * a.out_pitch + chbase,
+                                     reinterpret_cast<const T*>(a.in) + pix * a.in_pitch + chbase, chbase, a.C, v, bias2);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // 1x1 conv = GEMM over flattened pixels.  Every pixel is read exactly once, so the pixel
 // operand goes straight from global memory to registers (16 B per lane); the weights of
@@ -827,7 +1010,7 @@ static void put_elem(std::vector<uint8_t>& buf, size_t idx, int prec, float v) {
 
 void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int cout, int act_,
                       const std::vector<float>& w_phys, const std::vector<float>& bias_phys, int hout, int wout, int batch_hint,
-                      bool full_n) {
+                      bool full_n, bool single_chunk) {
   prec = prec_; impl = impl_; k = k_; stride = stride_; Cin = cin; Cout = cout; act = act_;
   LP_CHECK(k == 1 || k == 3, LP_ERR_GRAPH, "conv kernel size %d unsupported", k);
   LP_CHECK(Cin % 8 == 0 && Cout % 8 == 0, LP_ERR_GRAPH, "physical channels must be multiples of 8");
@@ -862,7 +1045,15 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
   const int B = batch_hint > 0 ? batch_hint : 1;
 
   direct = (k == 3 && stride == 2);
-  if (direct) {
+  if (single_chunk) {
+    // weights only (BottleneckPair): every channel tile in one workgroup, all of K in one chunk
+    LP_CHECK(k == 3 && stride == 1, LP_ERR_STATE, "single-chunk packing is for 3x3 stride-1 layers");
+    direct = false;
+    NT = tiles_total; nsplits = 1; CK = Cin; CGc = Cin / G; nchunks = 1;
+    steps = ceil_div(taps * CGc, 4);
+    PS = lds_pixel_slots(CGc) * 16;
+    LP_CHECK(steps * 4 <= 128, LP_ERR_GRAPH, "conv3x3: too many K steps for one chunk");
+  } else if (direct) {
     // stride-2: no input staging (see conv3x3s2_direct_kernel); all of K for this block's channel split in LDS
     NT = pick_nt(ceil_div((long)B * hout * wout, 256));
     CK = Cin;
@@ -1147,6 +1338,103 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
   }
     if (f16) { LP_L1(half_t) } else { LP_L1(float) }
 #undef LP_L1
+  }
+  LP_HIP(hipGetLastError());
+}
+
+
+// ---- fused bottleneck pair ---------------------------------------------------------------------
+bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, int& th, int& tw, int& lw, size_t& lds) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  if (c % 8 != 0 || c > 64) return false;
+  const int nt = ceil_div(c, 16), cg = c / G;
+  if (nt > 4) return false;
+  const int steps = ceil_div(9 * cg, 4);
+  if (steps * 4 > 128) return false;
+  const int pss = lds_pixel_slots(cg);
+  const int cand[3][2] = {{8, 40}, {8, 20}, {4, 20}};
+  const int B = batch_hint > 0 ? batch_hint : 1;
+  long best = -1;
+  for (auto& cd : cand) {
+    const int TH = cd[0], TW = cd[1];
+    int l = TW + 4;
+    if (cg <= 1) while (l % 16 != 2) ++l;  // one K group per pixel: 16 consecutive pixels x 4 taps conflict-free
+    if (ceil_div(l * pss, 64) > 8) continue;
+    const size_t need = 512 + (size_t)2 * steps * nt * 1024 + (size_t)(TH + 4) * l * pss * 16;
+    if (need > 150 * 1024) continue;
+    const long tiles = (long)ceil_div(h, TH) * ceil_div(w, TW);
+    const int util = (int)(100.0 * h * w / ((double)tiles * TH * TW));
+    // enough workgroups to fill the chip first, then two workgroups per CU, then no idle lanes, then the larger tile
+    const long score = (tiles * B >= 512 ? 8 : tiles * B >= 256 ? 4 : 0) * 1000L + (need <= 80 * 1024 ? 2000L : 0L) +
+                       (util >= 95 ? 500L : util >= 80 ? 250L : 0L) + TH * TW / 10;
+    if (score > best) { best = score; th = TH; tw = TW; lw = l; lds = need; }
+  }
+  return best >= 0;
+}
+
+bool BottleneckPair::supported(int prec, int impl, int c_phys, int h, int w, int batch_hint) {
+  int th, tw, lw;
+  size_t lds;
+  return impl == IMPL_MFMA && plan(prec, c_phys, h, w, batch_hint, th, tw, lw, lds);
+}
+
+void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, const std::vector<float>& ba,
+                           const std::vector<float>& wb, const std::vector<float>& bb, int h, int w, int batch_hint) {
+  prec = prec_; C = c_phys;
+  LP_CHECK(plan(prec, C, h, w, batch_hint, TH, TW, LW, lds_bytes), LP_ERR_GRAPH, "bottleneck %d ch on %dx%d: no fused plan", C, h, w);
+  a.name = name; b.name = name;
+  a.build(prec, IMPL_MFMA, 3, 1, C, C, ACT_SILU, wa, ba, h, w, batch_hint, true, true);
+  b.build(prec, IMPL_MFMA, 3, 1, C, C, ACT_SILU, wb, bb, h, w, batch_hint, true, true);
+  NT = a.NT; CG = a.CGc; PS = a.PS; steps = a.steps;
+  auto rcp16 = [&](int d, int range) {
+    const unsigned m = (65536u + d - 1) / d;
+    for (int x = 0; x < range; ++x) LP_CHECK((int)((x * m) >> 16) == x / d, LP_ERR_STATE, "reciprocal of %d not exact at %d", d, x);
+    return m;
+  };
+  rcp_cg = rcp16(CG, 128);
+  rcp_ps = rcp16(PS / 16, 512);
+  rcp_w1 = rcp16(TW + 2, 512);
+  rcp_tw = rcp16(TW, 512);
+  LP_CHECK((TH + 2) * (TW + 2) <= 7 * 4 * 16 && TH * TW <= 5 * 4 * 16, LP_ERR_STATE, "bottleneck tile exceeds the kernel's pixel-tile budget");
+}
+
+template <typename T, int NT, int P1, int P2>
+static void launch_bneck_(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  hipLaunchKernelGGL((bottleneck_mfma_kernel<T, NT, P1, P2>), grid, dim3(256), lds, st, a);
+}
+
+// pixel tiles per wave = ceil(ceil(region / 16) / 4 waves) for the three tile shapes of plan()
+template <typename T, int NT>
+static void launch_bneck(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  if (a.TH == 8 && a.TW == 40) launch_bneck_<T, NT, 7, 5>(a, grid, lds, st);       // 10x42 = 27 tiles, 8x40 = 20
+  else if (a.TH == 8 && a.TW == 20) launch_bneck_<T, NT, 4, 3>(a, grid, lds, st);  // 10x22 = 14 tiles, 8x20 = 10
+  else if (a.TH == 4 && a.TW == 20) launch_bneck_<T, NT, 3, 2>(a, grid, lds, st);  //  6x22 =  9 tiles, 4x20 = 5
+  else throw Error(LP_ERR_STATE, "bottleneck: no kernel for this tile shape");
+}
+
+void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t st) const {
+  LP_CHECK(in.C == C && out.C >= C && in.H == out.H && in.W == out.W, LP_ERR_STATE, "bottleneck: view mismatch");
+  LP_CHECK((in.pitch % 8) == 0 && (out.pitch % 4) == 0, LP_ERR_STATE, "unaligned channel pitch");
+  BneckArgs k;
+  memset(&k, 0, sizeof(k));
+  k.in = in.base; k.out = out.base; k.w1 = a.d_w.p; k.w2 = b.d_w.p; k.b1 = a.d_bias.as<float>(); k.b2 = b.d_bias.as<float>();
+  k.zeros = a.d_bias.as<float>() + round_up(C, 64);
+  k.N = N; k.H = in.H; k.W = in.W; k.C = C; k.in_pitch = in.pitch; k.out_pitch = out.pitch;
+  k.TH = TH; k.TW = TW; k.tiles_x = ceil_div(in.W, TW); k.LW = LW; k.PS = PS; k.CG = CG; k.steps = steps;
+  const int tiles_y = ceil_div(in.H, TH);
+  const unsigned m = (65536u + k.tiles_x - 1) / k.tiles_x;
+  for (int x = 0; x < k.tiles_x * tiles_y; ++x) LP_CHECK((int)((x * m) >> 16) == x / k.tiles_x, LP_ERR_STATE, "tile reciprocal not exact");
+  k.rcp_tx = m; k.rcp_cg = rcp_cg; k.rcp_ps = rcp_ps; k.rcp_w1 = rcp_w1; k.rcp_tw = rcp_tw;
+  dim3 grid(k.tiles_x * tiles_y, N);
+  const bool f16 = prec == LP_FP16;
+  switch (NT) {
+    case 1: if (f16) launch_bneck<half_t, 1>(k, grid, lds_bytes, st); else launch_bneck<float, 1>(k, grid, lds_bytes, st); break;
+    case 2: if (f16) launch_bneck<half_t, 2>(k, grid, lds_bytes, st); else launch_bneck<float, 2>(k, grid, lds_bytes, st); break;
+    case 3: if (f16) launch_bneck<half_t, 3>(k, grid, lds_bytes, st); else launch_bneck<float, 3>(k, grid, lds_bytes, st); break;
+    default: if (f16) launch_bneck<half_t, 4>(k, grid, lds_bytes, st); else launch_bneck<float, 4>(k, grid, lds_bytes, st); break;
   }
   LP_HIP(hipGetLastError());
 }

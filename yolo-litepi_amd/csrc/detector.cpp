@@ -343,6 +343,60 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
           done[cs[0]] = 1;
         }
       }
+      // bottleneck fusion: this 3x3 conv feeds exactly one 3x3 conv whose activation is added to THIS conv's
+      // input (C2f.m[i] with shortcut): both convs, the SiLUs and the add become one launch, the intermediate
+      // stays in LDS (BottleneckPair).  LITEPI_NO_BNECK=1 keeps the layer-at-a-time plan (A/B measurements).
+      static const bool no_bneck = getenv("LITEPI_NO_BNECK") != nullptr;
+      if (!no_bneck && res < 0 && k == 3 && s == 1 && Cin == Cout && tin != input_tensor && impl_ == IMPL_MFMA &&
+          fused_act[i] == ACT_SILU && tensors_[tout].segs.size() == 1 && tensors_[tin].segs.size() == 1) {
+        auto& csb = canon_consumers[tensors_[tout].name];
+        if (csb.size() == 1 && L[csb[0]].type == "Convolution" && !is_tail(csb[0]) && !done[csb[0]]) {
+          const int j = csb[0];
+          const NcnnLayer& lb = L[j];
+          const int tb = cinfo[j].tout;
+          auto& csa = canon_consumers[tensors_[tb].name];
+          if (lb.ipar(1, 1) == 3 && lb.ipar(3, 1) == 1 && lb.ipar(0) == Cout && lb.in_ch == Cout && fused_act[j] == ACT_SILU &&
+              csa.size() == 1 && L[csa[0]].type == "BinaryOp" && !is_tail(csa[0])) {
+            const NcnnLayer& add = L[csa[0]];
+            const int ta = get(add.inputs[0]), tb2 = get(add.inputs[1]);
+            const int other = ta == tb ? tb2 : ta;
+            const int tfinal = get(add.outputs[0]);
+            const Tensor& TI = tensors_[tin];
+            if (other == tin && TI.Cp == tensors_[tfinal].Cp && TI.Cp == tensors_[tout].Cp &&
+                BottleneckPair::supported(prec_, impl_, TI.Cp, TI.H, TI.W, maxB_)) {
+              ensure_buffer(tfinal);
+              const Tensor& TM = tensors_[tout];
+              const Tensor& TF = tensors_[tfinal];
+              auto pack = [&](const NcnnLayer& lc, const Tensor& A, const Tensor& O, std::vector<float>& w, std::vector<float>& b) {
+                w.assign((size_t)O.Cp * 9 * A.Cp, 0.f);
+                b.assign(O.Cp, 0.f);
+                for (int co = 0; co < Cout; ++co) {
+                  const int pc = O.phys(co);
+                  for (int ci = 0; ci < Cin; ++ci)
+                    for (int t = 0; t < 9; ++t) w[((size_t)pc * 9 + t) * A.Cp + A.phys(ci)] = lc.weight[((size_t)co * Cin + ci) * 9 + t];
+                  if (!lc.bias.empty()) b[pc] = lc.bias[co];
+                }
+              };
+              std::vector<float> wa, ba, wb, bb;
+              pack(l, TI, TM, wa, ba);
+              pack(lb, TM, TF, wb, bb);
+              bnecks_.emplace_back(new BottleneckPair());
+              bnecks_.back()->name = l.name + "+" + lb.name;
+              bnecks_.back()->build(prec_, TI.Cp, wa, ba, wb, bb, TI.H, TI.W, maxB_);
+              const double macs = 2.0 * 9.0 * Cin * Cout * TI.H * TI.W;
+              macs_ += macs;
+              DetOp op;
+              op.kind = DetOp::BNECK; op.layer = bnecks_.back()->name; op.conv = (int)bnecks_.size() - 1;
+              op.flops = 2.0 * macs;
+              op.bytes = 2.0 * TI.C * TI.H * TI.W * esd + (double)(l.weight.size() + lb.weight.size()) * esd;
+              op.in = tin; op.out = tfinal;
+              ops_.push_back(op);
+              done[j] = 1; done[csa[0]] = 1;
+              continue;
+            }
+          }
+        }
+      }
       // 1x1 tail fusion: this 3x3 conv's activation output feeds exactly one 1x1 conv (Detect-head
       // projections, C2f cv1 after a stride-2 conv): the second GEMM runs on the accumulator tile
       int tail = -1, tmid = -1;
@@ -544,6 +598,10 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         kname = std::string(c.impl == IMPL_NAIVE ? "conv_naive" : (c.direct ? "conv3x3s2_direct" : (c.k == 3 ? "conv3x3_mfma" : "conv1x1_mfma"))) + (c.T2 ? "+1x1" : "") + sfx;
         break;
       }
+      case DetOp::BNECK:
+        bnecks_[op.conv]->launch(view(op.in), view(op.out), B, st);
+        kname = std::string("bottleneck3x3x2") + sfx;
+        break;
       case DetOp::UPSAMPLE:
         launch_upsample2x(prec_, view(op.in), view(op.out), B, st);
         kname = std::string("upsample2x") + sfx;

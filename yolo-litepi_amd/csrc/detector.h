@@ -35,8 +35,8 @@ struct Tensor {
 struct Buffer { int Cp = 0, H = 0, W = 0; DevBuf mem; };
 
 struct DetOp {
-  enum Kind { STEM, CONV, UPSAMPLE, SPPF, ADD, COPY } kind = CONV;
-  int conv = -1;                 // index into convs (CONV)
+  enum Kind { STEM, CONV, BNECK, UPSAMPLE, SPPF, ADD, COPY } kind = CONV;
+  int conv = -1;                 // index into convs (CONV) / bnecks (BNECK)
   int in = -1, in2 = -1, res = -1, out = -1, out2 = -1, out3 = -1;
   std::string layer;
   double flops = 0, bytes = 0;   // per image
@@ -67,6 +67,7 @@ class Detector {
   std::map<std::string, int> blob2tensor_;   // every blob name (aliases included) -> tensor index
   std::vector<Buffer> buffers_;
   std::vector<std::unique_ptr<ConvLayer>> convs_;
+  std::vector<std::unique_ptr<BottleneckPair>> bnecks_;
   StemLayer stem_;
   std::vector<DetOp> ops_;
   // detect tail
