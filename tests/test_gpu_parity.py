@@ -236,6 +236,32 @@ def test_detector_fp32_out0(synth_models, preset, impl):
     assert err_s <= 1e-3, f"score row: max err {err_s}"
 
 
+@pytest.mark.parametrize("preset,size,max_batch", [("v1", 640, 64), ("v2", 640, 64), ("v1", 416, 3), ("v1", 352, 64)])
+def test_detector_fp32_plans_and_sizes(tmp_path, synth_models, preset, size, max_batch):
+    """The tile / fusion plan depends on the batch capacity and on the map sizes: check the plans the benchmark
+    uses (capacity 64) and input sizes whose maps do not divide into whole tiles (416 -> 208/104/52/26/13,
+    352 -> 176/88/44/22/11), fp32 exact-MFMA path against the CPU oracle at the north_star tolerance."""
+    from litepi import Engine, ncnn_export
+    if size == 640:
+        param, binf = synth_models[preset]
+    else:
+        param, binf = str(tmp_path / "d.param"), str(tmp_path / "d.bin")
+        ncnn_export.export_detector(param, binf, preset, seed=77, cls_bias=-2.0, size=size)
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, (2, size, size, 3), dtype=np.uint8)
+    ref, _ = _oracle_out0(param, binf, imgs)
+    e = Engine(precision="fp32", max_batch=max_batch, det_input=size)
+    try:
+        e.load_detector(param, binf)
+        got = e.detect_raw(imgs)
+    finally:
+        e.close()
+    assert got.shape == ref.shape
+    err_box = np.abs(got[:, :4] - ref[:, :4])
+    assert (err_box <= 1e-3 + 1e-3 * np.abs(ref[:, :4])).all(), f"box rows: max err {err_box.max()}"
+    assert np.abs(got[:, 4] - ref[:, 4]).max() <= 1e-3
+
+
 @pytest.mark.parametrize("preset", ["v1", "v2"])
 def test_detector_fp16_out0(synth_models, preset):
     """fp16 storage / fp32 accumulate: not expected to meet the 1e-3 fp32 bound.  Documented bound:
