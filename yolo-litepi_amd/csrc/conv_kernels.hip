@@ -740,6 +740,14 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a)
       if (i < nW) lds_w[i] = wv[u];
     }
   }
+  // K group q = (tap, channel group): element offset from the window's top-left pixel and (valid, ky, kx), once
+  // per workgroup instead of two integer divisions per lane per K step
+  int2* lds_tab = reinterpret_cast<int2*>(smem + (size_t)nW * 16);
+  for (int q = tid; q < S * 4; q += 256) {
+    const int tap = q / CG, cg = q - tap * CG;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    lds_tab[q] = make_int2((ky * a.Win + kx) * a.in_pitch + cg * G, tap < 9 ? ((ky << 8) | kx) : -1);
+  }
   __syncthreads();
   const T* in = reinterpret_cast<const T*>(a.in);
   const int HWo = a.Hout * a.Wout;
@@ -770,16 +778,14 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a)
       for (int p = 0; p < NP; ++p) acc[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     for (int s = 0; s < S; ++s) {
-      const int q = 4 * s + g;
-      const int tap = q / CG, cg = q - tap * CG;
-      const int ky = tap / 3, kx = tap - 3 * ky;
-      const long toff = ((long)ky * a.Win + kx) * a.in_pitch + cg * G;
+      const int2 te = lds_tab[4 * s + g];
+      const int toff = te.x, ky = te.y >> 8, kx = te.y & 0xff;
       typename Tr<T>::frag af[NT], bf[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
         const int iy = iy0[p] + ky, ix = ix0[p] + kx;
-        if (tap < 9 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) v = *reinterpret_cast<const u32x4*>(src[p] + toff);
+        if (te.y >= 0 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) v = *reinterpret_cast<const u32x4*>(src[p] + toff);
         bf[p] = as_frag<T>(v);
       }
 #pragma unroll
@@ -1044,7 +1050,10 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
   };
   const int B = batch_hint > 0 ? batch_hint : 1;
 
-  direct = (k == 3 && stride == 2);
+  // stride-2: gather straight from global memory, except deep-K layers without a fused tail (every K step of the
+  // gather is a dependent memory round trip; the LDS-DMA staged kernel pipelines chunks instead)
+  static const int s2_staged_min_cin = getenv("LITEPI_S2_STAGED") ? atoi(getenv("LITEPI_S2_STAGED")) : 64;
+  direct = (k == 3 && stride == 2) && (full_n || Cin < s2_staged_min_cin);
   if (single_chunk) {
     // weights only (BottleneckPair): every channel tile in one workgroup, all of K in one chunk
     LP_CHECK(k == 3 && stride == 1, LP_ERR_STATE, "single-chunk packing is for 3x3 stride-1 layers");
@@ -1062,7 +1071,7 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     steps = ceil_div(taps * CGc, 4);
     while (!full_n && NT > 1 && (size_t)steps * NT * 1024 > 64 * 1024) --NT;
     nsplits = ceil_div(tiles_total, NT);
-    lds_bytes = (size_t)steps * NT * 1024;
+    lds_bytes = (size_t)steps * NT * 1024 + (size_t)steps * 4 * 8;  // weight fragments + K-group table
     LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv3x3/s2 weights do not fit LDS (%zu B)", lds_bytes);
   } else if (k == 3) {
     // Tile shape (bwh x bww waves of 4x20 pixels) and K chunk CK (multiple of 8, divides Cin):
