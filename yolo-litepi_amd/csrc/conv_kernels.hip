@@ -1039,13 +1039,16 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     return;
   }
 
-  // channel tiles per block: 4 when the layer has plenty of pixel tiles; fewer (more channel
-  // splits -> more workgroups) when the map is small, so that ~2 workgroups per CU exist
+  // channel tiles per block: 4 when the layer has plenty of pixel tiles; fewer (more channel splits -> more
+  // workgroups, but the input is read once per split) when the map is small.  The floor of 128 workgroups is
+  // measured on the pipelined benchmark (3 batches in flight share the GPU: 512 gave the best isolated layer
+  // times but 5 % less throughput; LITEPI_MIN_WGS overrides it for such sweeps)
   auto pick_nt = [&](long pixel_blocks) {
     if (full_n) return tiles_total;  // a fused tail needs every intermediate channel in one workgroup
     int nt = tiles_total >= 4 ? 4 : tiles_total;
     if (tiles_total % 4 != 0 && tiles_total > 4) nt = (tiles_total % 3 == 0) ? 3 : 4;
-    while (nt > 1 && pixel_blocks * ceil_div(tiles_total, nt) < 512) nt = (nt == 4 && tiles_total % 4 == 0) ? 2 : nt - 1;
+    static const long min_wgs = getenv("LITEPI_MIN_WGS") ? atol(getenv("LITEPI_MIN_WGS")) : 128;
+    while (nt > 1 && pixel_blocks * ceil_div(tiles_total, nt) < min_wgs) nt = (nt == 4 && tiles_total % 4 == 0) ? 2 : nt - 1;
     return nt;
   };
   const int B = batch_hint > 0 ? batch_hint : 1;
@@ -1080,7 +1083,7 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     // largest workgroup (weights are staged once per workgroup), then the largest chunk.
     const bool small_map = (hout <= 20 && wout <= 20);
     const int cand[6][2] = {{5, 1}, {2, 2}, {2, 1}, {1, 2}, {4, 1}, {1, 1}};
-    const size_t budget = 80 * 1024;
+    static const size_t budget = (getenv("LITEPI_LDS_KB") ? atol(getenv("LITEPI_LDS_KB")) : 80) * 1024;
     long best_score = -1;
     CK = 8; bwh = 1; bww = 1; LW = 0; NT = 1;
     for (int ci = 0; ci < 6; ++ci) {
@@ -1374,7 +1377,8 @@ bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, int& th
     const long tiles = (long)ceil_div(h, TH) * ceil_div(w, TW);
     const int util = (int)(100.0 * h * w / ((double)tiles * TH * TW));
     // enough workgroups to fill the chip first, then two workgroups per CU, then no idle lanes, then the larger tile
-    const long score = (tiles * B >= 512 ? 8 : tiles * B >= 256 ? 4 : 0) * 1000L + (need <= 80 * 1024 ? 2000L : 0L) +
+    static const long bn_wgs = getenv("LITEPI_BNECK_WGS") ? atol(getenv("LITEPI_BNECK_WGS")) : 256;
+    const long score = (tiles * B >= bn_wgs ? 8 : tiles * B >= bn_wgs / 2 ? 4 : 0) * 1000L + (need <= 80 * 1024 ? 2000L : 0L) +
                        (util >= 95 ? 500L : util >= 80 ? 250L : 0L) + TH * TW / 10;
     if (score > best) { best = score; th = TH; tw = TW; lw = l; lds = need; }
   }
