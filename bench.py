@@ -176,6 +176,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         gathered = step()
+    host_enqueue_s = time.perf_counter() - t0   # host time to enqueue all timed steps (no GPU wait unless a queue fills)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -257,6 +258,7 @@ def main():
                             f"{flop_img / 1e9:.3f} GFLOP/image, class bias calibrated to ~{TARGET_CANDIDATES} candidates/image",
                 "classifier": f"ShuffleNetV2 x1.0, {NUM_CLASSES} classes, seeded random weights, 64x64 ROIs",
                 "conf": CONF, "iou": IOU, "min_area": MIN_AREA, "max_det": args.max_det, "steps_in_flight": len(engs),
+                "host_enqueue_ms_per_step": round(host_enqueue_s * 1e3 / args.steps, 4),
                 "global_batch": world * B,
                 "rois_per_step_rank0": int(kept), "boxes_pre_area_filter_rank0": int(prefilter),
                 "detector_fp16_roofline_frac_e2e": (total_images / elapsed) * flop_img / (world * PEAK_FP16_TFLOPS * 1e12),

@@ -66,6 +66,7 @@ struct BottleneckPair {
 struct StemLayer {
   int prec = LP_FP16, CO = 8, act = ACT_SILU;
   DevBuf d_w, d_bias;
+  DevBuf d_afrag;  // fp16, 8 channels: MFMA A fragments (stem_mfma_kernel)
   // w_bgr: fp32 [27][CO], row = (ky*3+kx)*3 + c with c in BGR order
   void build(int prec, int cout_phys, int act, const std::vector<float>& w_bgr, const std::vector<float>& bias);
   void launch(const uint8_t* img, int N, int Hin, int Win, const View& out, hipStream_t st) const;

@@ -982,6 +982,79 @@ __global__ __launch_bounds__(256) void stem_conv_lds_kernel(const uint8_t* __res
   }
 }
 
+
+// Stem on the matrix cores (fp16, 8 output channels).  K = the 3 x 9 window bytes is only 27 deep and 8 channels
+// fill half an MFMA tile, so two horizontally adjacent output pixels share one column: rows 0-7 = channels of the
+// even pixel, rows 8-15 = channels of the odd one, K = 3 rows x the 15-byte union of the two windows (padded to
+// 16 -> K = 48 of 64 used, two 16x16x32 steps).  A lane's 8 K values are 8 consecutive bytes of one staged row:
+// 3 dword LDS reads + v_alignbyte, then bytes -> fp16 exactly via 0x6400|b (= 1024 + b) minus 1024.  The 1/255 of
+// preprocess (e2e.py:222-238) is folded into the fp16 weights.  Against the scalar kernel above this drops the
+// per-pixel VALU work (27 x 8 FMAs + 27 conversions) that made the stem the largest single launch.
+#define STEMM_TH 8
+#define STEMM_TW 64
+#define STEMM_ROWW 100 /* dwords per staged row: 1 + 129*3 bytes -> 97, + the lanes' 3rd dword */
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restrict__ img, half_t* __restrict__ out,
+                                                        const u32x4* __restrict__ afrag, const float* __restrict__ bias,
+                                                        int N, int Hin, int Win, int Hout, int Wout, int out_pitch) {
+  __shared__ uint32_t tile[(2 * STEMM_TH + 1) * STEMM_ROWW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int n = blockIdx.z, oy0 = blockIdx.y * STEMM_TH, ox0 = blockIdx.x * STEMM_TW;
+  const int row_words = Win * 3 / 4;
+  const int w0 = (6 * ox0 - 3) >> 2;  // first staged dword of a row (tile byte 1 = window byte 0 of column ox0)
+  const uint32_t* im = reinterpret_cast<const uint32_t*>(img + (long)n * Hin * Win * 3);
+  for (int i = tid; i < (2 * STEMM_TH + 1) * STEMM_ROWW; i += 256) {
+    const int r = i / STEMM_ROWW, c = i - r * STEMM_ROWW;
+    const int iy = 2 * oy0 - 1 + r, wi = w0 + c;
+    uint32_t v = 0u;
+    if (iy >= 0 && iy < Hin && wi >= 0 && wi < row_words) v = im[(long)iy * row_words + wi];
+    tile[i] = v;
+  }
+  const half8 af0 = __builtin_bit_cast(half8, afrag[lane]);
+  const half8 af1 = __builtin_bit_cast(half8, afrag[64 + lane]);
+  const int c0 = (g & 1) * 4;
+  const floatx4 b4 = *reinterpret_cast<const floatx4*>(bias + c0);
+  __syncthreads();
+  const half2v k1024 = {(half_t)1024.f, (half_t)1024.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mt = wave * 4 + i;
+    const int r = mt >> 1, hx = mt & 1;
+    const int txe = 32 * hx + 2 * col;  // even pixel of this lane's pair, tile-relative
+    half8 bf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int q = 4 * s + g;
+      const int ky = q >> 1, h = q & 1;
+      const int bo = 1 + 6 * txe + 8 * h;
+      const uint32_t* rw = tile + (2 * r + (ky < 3 ? ky : 2)) * STEMM_ROWW + (bo >> 2);
+      const int sh = bo & 3;
+      const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
+      uint32_t wa = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      uint32_t wb = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      if (q >= 6) { wa = 0u; wb = 0u; }  // K padding (weights are zero as well)
+      // bytes -> (1024 + b) as fp16 pairs, then - 1024
+      const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04010400u);
+      const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04030402u);
+      const uint32_t p2 = __builtin_amdgcn_perm(0x64646464u, wb, 0x04010400u);
+      const uint32_t p3 = __builtin_amdgcn_perm(0x64646464u, wb, 0x04030402u);
+      const half2v h0 = __builtin_bit_cast(half2v, p0) - k1024, h1 = __builtin_bit_cast(half2v, p1) - k1024;
+      const half2v h2 = __builtin_bit_cast(half2v, p2) - k1024, h3 = __builtin_bit_cast(half2v, p3) - k1024;
+      bf[s] = half8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+    }
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0, bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1, bf[1], acc, 0, 0, 0);
+    const int oy = oy0 + r, ox = ox0 + txe + (g >> 1);
+    if (oy < Hout && ox < Wout) {
+      half4 q4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q4[j] = (half_t)Tr<half_t>::silu(acc[j] + b4[j]);
+      *reinterpret_cast<half4*>(out + ((long)(n * Hout + oy) * Wout + ox) * out_pitch + c0) = q4;
+    }
+  }
+}
+
 // ====================================================================================
 // Host side: weight packing and launch
 // ====================================================================================
@@ -1461,10 +1534,39 @@ void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<floa
   for (size_t i = 0; i < bias.size() && i < (size_t)CO; ++i) b[i] = bias[i];
   d_bias.alloc(CO * 4);
   LP_HIP(hipMemcpy(d_bias.p, b.data(), CO * 4, hipMemcpyHostToDevice));
+  if (prec == LP_FP16 && CO == 8 && act == ACT_SILU) {
+    // stem_mfma_kernel A fragments [2 steps][64 lanes][8]: row m = (pixel parity, channel); K group q = 4s+g ->
+    // (ky = q/2, byte half h = q%2) of the 15-byte union of the two windows; the even pixel uses union bytes 0..8,
+    // the odd one 6..14.  1/255 folded in.
+    std::vector<uint8_t> buf((size_t)2 * 64 * 16, 0);
+    for (int s = 0; s < 2; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, m = lane & 15, par = m >> 3, ch = m & 7;
+        const int q = 4 * s + g;
+        if (q >= 6) continue;
+        const int ky = q >> 1, h = q & 1;
+        for (int j = 0; j < 8; ++j) {
+          const int jj = 8 * h + j, jw = jj - 6 * par;
+          if (jw < 0 || jw > 8) continue;
+          put_elem(buf, ((size_t)s * 64 + lane) * 8 + j, LP_FP16, w_bgr[(size_t)(ky * 9 + jw) * CO + ch] / 255.f);
+        }
+      }
+    d_afrag.alloc(buf.size());
+    LP_HIP(hipMemcpy(d_afrag.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+  }
 }
 
 void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& out, hipStream_t st) const {
-  if (Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 && out.H == (Hin + 1) / 2 && out.W == (Win + 1) / 2) {
+  const bool aligned = Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 && out.H == (Hin + 1) / 2 && out.W == (Win + 1) / 2;
+  static const bool no_mfma_stem = getenv("LITEPI_NO_MFMA_STEM") != nullptr;
+  if (aligned && d_afrag.p && !no_mfma_stem) {
+    dim3 g3(ceil_div(out.W, STEMM_TW), ceil_div(out.H, STEMM_TH), N);
+    hipLaunchKernelGGL(stem_mfma_kernel, g3, dim3(256), 0, st, img, reinterpret_cast<half_t*>(out.base),
+                       reinterpret_cast<const u32x4*>(d_afrag.p), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch);
+    LP_HIP(hipGetLastError());
+    return;
+  }
+  if (aligned) {
     dim3 g2(ceil_div(out.W, STEM_TW), ceil_div(out.H, STEM_TH), N);
 #define LP_STL(TT, C)                                                                                            \
   hipLaunchKernelGGL((stem_conv_lds_kernel<TT, C>), g2, dim3(256), 0, st, img, reinterpret_cast<TT*>(out.base), \
