@@ -343,6 +343,67 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
           done[cs[0]] = 1;
         }
       }
+      // sibling merge: another plain 3x3 conv reads the same input (Detect head: the box and class branches of a
+      // level both start with a 3x3 conv on the neck output): one launch computes both, output channels side by
+      // side in one buffer -- the input is read once and a launch disappears.  LITEPI_NO_SIBLING=1 disables it.
+      static const bool no_sibling = getenv("LITEPI_NO_SIBLING") != nullptr;
+      int sib = -1;
+      if (!no_sibling && res < 0 && k == 3 && s == 1 && tin != input_tensor && impl_ == IMPL_MFMA && tensors_[tout].buf < 0 &&
+          tensors_[tout].parent < 0 && tensors_[tout].segs.size() == 1) {
+        auto plain_successor = [&](int t) {  // the output must stay a plain tensor: no fused add on it
+          for (int c : canon_consumers[tensors_[t].name])
+            if (L[c].type == "BinaryOp") return false;
+          return true;
+        };
+        for (int j = i + 1; j < first_tail && sib < 0; ++j) {
+          if (L[j].type != "Convolution" || done[j] || skip[j] || is_tail(j) || cinfo[j].tin != tin) continue;
+          const int tj = cinfo[j].tout;
+          if (L[j].ipar(1, 1) == 3 && L[j].ipar(3, 1) == 1 && fused_act[j] == fused_act[i] && tensors_[tj].buf < 0 &&
+              tensors_[tj].parent < 0 && tensors_[tj].segs.size() == 1 && plain_successor(tj) && plain_successor(tout) &&
+              L[j].bias.empty() == l.bias.empty())
+            sib = j;
+        }
+      }
+      if (sib >= 0) {
+        const NcnnLayer& l2 = L[sib];
+        const int t2 = cinfo[sib].tout;
+        const int cpa = tensors_[tout].Cp, cpb = tensors_[t2].Cp, Ho = tensors_[tout].H, Wo = tensors_[tout].W;
+        const int CpO = cpa + cpb;
+        const int nb = alloc_buffer(CpO, Ho, Wo);
+        tensors_[tout].buf = nb; tensors_[tout].off = 0; tensors_[tout].materialised = true;
+        tensors_[t2].buf = nb; tensors_[t2].off = cpa; tensors_[t2].materialised = true;
+        const Tensor& TI = tensors_[tin];
+        std::vector<float> w((size_t)CpO * 9 * TI.Cp, 0.f), b(CpO, 0.f);
+        auto put = [&](const NcnnLayer& lc, const Tensor& O, int base) {
+          const int co_n = lc.ipar(0);
+          for (int co = 0; co < co_n; ++co) {
+            const int pc = base + O.phys(co);
+            for (int ci = 0; ci < Cin; ++ci)
+              for (int t = 0; t < 9; ++t) w[((size_t)pc * 9 + t) * TI.Cp + TI.phys(ci)] = lc.weight[((size_t)co * Cin + ci) * 9 + t];
+            if (!lc.bias.empty()) b[pc] = lc.bias[co];
+          }
+        };
+        put(l, tensors_[tout], 0);
+        put(l2, tensors_[t2], cpa);
+        convs_.emplace_back(new ConvLayer());
+        convs_.back()->name = l.name + "|" + l2.name;
+        convs_.back()->build(prec_, impl_, 3, 1, TI.Cp, CpO, fused_act[i], w, b, Ho, Wo, maxB_);
+        const double macs = 9.0 * Cin * (Cout + l2.ipar(0)) * Ho * Wo;
+        macs_ += macs;
+        DetOp op;
+        op.kind = DetOp::CONV; op.layer = convs_.back()->name; op.conv = (int)convs_.size() - 1;
+        op.flops = 2.0 * macs;
+        op.bytes = ((double)TI.C * TI.H * TI.W + (double)(Cout + l2.ipar(0)) * Ho * Wo) * esd + (double)(l.weight.size() + l2.weight.size()) * esd;
+        // a tensor that stands for the merged buffer (the conv's output view); pushed last: it invalidates references
+        Tensor M = tensors_[tout];
+        M.name = tensors_[tout].name + "|" + tensors_[t2].name; M.C = tensors_[tout].C + tensors_[t2].C; M.Cp = CpO;
+        M.segs = {cpa, cpb}; M.buf = nb; M.off = 0;
+        tensors_.push_back(M);
+        op.in = tin; op.out = (int)tensors_.size() - 1;
+        ops_.push_back(op);
+        done[sib] = 1;
+        continue;
+      }
       // bottleneck fusion: this 3x3 conv feeds exactly one 3x3 conv whose activation is added to THIS conv's
       // input (C2f.m[i] with shortcut): both convs, the SiLUs and the add become one launch, the intermediate
       // stays in LDS (BottleneckPair).  LITEPI_NO_BNECK=1 keeps the layer-at-a-time plan (A/B measurements).
