@@ -313,8 +313,10 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
   // division): every division here is a multiply by a host-checked 16-bit reciprocal (ConvLayer::launch)
   const int wy = a.bww == 2 ? wave >> 1 : wave, wx = wave - wy * a.bww;
   const int TH = 4 * a.bwh, TW = 20 * a.bww;
-  const int ty = (int)((blockIdx.x * a.rcp_tx) >> 16), tx = blockIdx.x - ty * a.tiles_x;
-  const int n = blockIdx.y, ns = blockIdx.z;
+  // grid = (image, tile, channel split): consecutive workgroup ids round-robin over the 8 XCDs, so with the image
+  // index fastest all tiles of an image (which share halo rows and columns) meet in one XCD's L2
+  const int ty = (int)((blockIdx.y * a.rcp_tx) >> 16), tx = blockIdx.y - ty * a.tiles_x;
+  const int n = blockIdx.x, ns = blockIdx.z;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
   const int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
@@ -472,8 +474,8 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
   constexpr int MAXP = 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, col = lane & 15;
-  const int ty = (int)((blockIdx.x * a.rcp_tx) >> 16), tx = blockIdx.x - ty * a.tiles_x;
-  const int n = blockIdx.y;
+  const int ty = (int)((blockIdx.y * a.rcp_tx) >> 16), tx = blockIdx.y - ty * a.tiles_x;
+  const int n = blockIdx.x;  // image index fastest: an image's tiles share one XCD's L2 (see conv3x3_mfma_kernel)
   const int TH = a.TH, TW = a.TW, LW = a.LW, PS = a.PS, S = a.steps, CG = a.CG;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int IH = TH + 4, IW = TW + 4, H1 = TH + 2, W1 = TW + 2;
@@ -999,7 +1001,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restric
   __shared__ uint32_t tile[(2 * STEMM_TH + 1) * STEMM_ROWW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, col = lane & 15;
-  const int n = blockIdx.z, oy0 = blockIdx.y * STEMM_TH, ox0 = blockIdx.x * STEMM_TW;
+  const int n = blockIdx.x, oy0 = blockIdx.z * STEMM_TH, ox0 = blockIdx.y * STEMM_TW;  // image fastest: XCD-local halos
   const int row_words = Win * 3 / 4;
   const int w0 = (6 * ox0 - 3) >> 2;  // first staged dword of a row (tile byte 1 = window byte 0 of column ox0)
   const uint32_t* im = reinterpret_cast<const uint32_t*>(img + (long)n * Hin * Win * 3);
@@ -1376,7 +1378,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
     const int TH = 4 * bwh, TW = 20 * bww;
     a.tiles_x = ceil_div(a.Wout, TW);
     a.tiles_y = ceil_div(a.Hout, TH);
-    dim3 grid(a.tiles_x * a.tiles_y, io.N, nsplits);
+    dim3 grid(io.N, a.tiles_x * a.tiles_y, nsplits);
     const int threads = 64 * bwh * bww;
     // 16-bit reciprocals for the kernel's prologue: x / d == (x * ceil(65536 / d)) >> 16 on the ranges used
     auto rcp16 = [&](int d, int range) {
@@ -1514,7 +1516,7 @@ void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t 
   const unsigned m = (65536u + k.tiles_x - 1) / k.tiles_x;
   for (int x = 0; x < k.tiles_x * tiles_y; ++x) LP_CHECK((int)((x * m) >> 16) == x / k.tiles_x, LP_ERR_STATE, "tile reciprocal not exact");
   k.rcp_tx = m; k.rcp_cg = rcp_cg; k.rcp_ps = rcp_ps; k.rcp_w1 = rcp_w1; k.rcp_tw = rcp_tw;
-  dim3 grid(k.tiles_x * tiles_y, N);
+  dim3 grid(N, k.tiles_x * tiles_y);
   const bool f16 = prec == LP_FP16;
   switch (NT) {
     case 1: if (f16) launch_bneck<half_t, 1>(k, grid, lds_bytes, st); else launch_bneck<float, 1>(k, grid, lds_bytes, st); break;
@@ -1560,7 +1562,7 @@ void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& 
   const bool aligned = Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 && out.H == (Hin + 1) / 2 && out.W == (Win + 1) / 2;
   static const bool no_mfma_stem = getenv("LITEPI_NO_MFMA_STEM") != nullptr;
   if (aligned && d_afrag.p && !no_mfma_stem) {
-    dim3 g3(ceil_div(out.W, STEMM_TW), ceil_div(out.H, STEMM_TH), N);
+    dim3 g3(N, ceil_div(out.W, STEMM_TW), ceil_div(out.H, STEMM_TH));
     hipLaunchKernelGGL(stem_mfma_kernel, g3, dim3(256), 0, st, img, reinterpret_cast<half_t*>(out.base),
                        reinterpret_cast<const u32x4*>(d_afrag.p), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch);
     LP_HIP(hipGetLastError());
