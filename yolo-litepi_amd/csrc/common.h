@@ -113,6 +113,7 @@ struct ConvArgs {
   const void* w2;
   const float* bias2;
   int act2, Cout2;
+  int tile_major;              // 0: grid = (image, tile, split) (XCD-aware, default); 1: (tile, image, split)
   unsigned rcp_tx, rcp_cg, rcp_ps;  // 3x3 kernel: 16-bit reciprocals of tiles_x, CGc, PS/16 (set by launch)
   const void* zeros;           // >= 16 zero bytes (source of the 3x3 kernel's padding slots)
   unsigned long long* stamps;  // diagnostic only (lp_test_conv + LITEPI_STAMPS): 16 clock stamps per workgroup
@@ -131,6 +132,7 @@ struct BneckArgs {
   int in_pitch, out_pitch;
   int TH, TW, tiles_x, LW, PS, CG, steps;
   unsigned rcp_tx, rcp_cg, rcp_ps, rcp_w1, rcp_tw;
+  int tile_major;
 };
 
 enum ConvImpl { IMPL_MFMA = 0, IMPL_NAIVE = 1 };

@@ -315,8 +315,9 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
   const int TH = 4 * a.bwh, TW = 20 * a.bww;
   // grid = (image, tile, channel split): consecutive workgroup ids round-robin over the 8 XCDs, so with the image
   // index fastest all tiles of an image (which share halo rows and columns) meet in one XCD's L2
-  const int ty = (int)((blockIdx.y * a.rcp_tx) >> 16), tx = blockIdx.y - ty * a.tiles_x;
-  const int n = blockIdx.x, ns = blockIdx.z;
+  const int tile_id = a.tile_major ? blockIdx.x : blockIdx.y;
+  const int ty = (int)((tile_id * a.rcp_tx) >> 16), tx = tile_id - ty * a.tiles_x;
+  const int n = a.tile_major ? blockIdx.y : blockIdx.x, ns = blockIdx.z;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
   const int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
@@ -474,8 +475,9 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
   constexpr int MAXP = 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, col = lane & 15;
-  const int ty = (int)((blockIdx.y * a.rcp_tx) >> 16), tx = blockIdx.y - ty * a.tiles_x;
-  const int n = blockIdx.x;  // image index fastest: an image's tiles share one XCD's L2 (see conv3x3_mfma_kernel)
+  const int tile_id = a.tile_major ? blockIdx.x : blockIdx.y;
+  const int ty = (int)((tile_id * a.rcp_tx) >> 16), tx = tile_id - ty * a.tiles_x;
+  const int n = a.tile_major ? blockIdx.y : blockIdx.x;  // image index fastest: an image's tiles share one XCD's L2 (see conv3x3_mfma_kernel)
   const int TH = a.TH, TW = a.TW, LW = a.LW, PS = a.PS, S = a.steps, CG = a.CG;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int IH = TH + 4, IW = TW + 4, H1 = TH + 2, W1 = TW + 2;
@@ -1378,7 +1380,10 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
     const int TH = 4 * bwh, TW = 20 * bww;
     a.tiles_x = ceil_div(a.Wout, TW);
     a.tiles_y = ceil_div(a.Hout, TH);
+    static const bool tile_major = getenv("LITEPI_TILE_MAJOR") != nullptr;  // A/B switch: pre-XCD-aware block order
+    a.tile_major = tile_major;
     dim3 grid(io.N, a.tiles_x * a.tiles_y, nsplits);
+    if (tile_major) grid = dim3(a.tiles_x * a.tiles_y, io.N, nsplits);
     const int threads = 64 * bwh * bww;
     // 16-bit reciprocals for the kernel's prologue: x / d == (x * ceil(65536 / d)) >> 16 on the ranges used
     auto rcp16 = [&](int d, int range) {
@@ -1516,7 +1521,10 @@ void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t 
   const unsigned m = (65536u + k.tiles_x - 1) / k.tiles_x;
   for (int x = 0; x < k.tiles_x * tiles_y; ++x) LP_CHECK((int)((x * m) >> 16) == x / k.tiles_x, LP_ERR_STATE, "tile reciprocal not exact");
   k.rcp_tx = m; k.rcp_cg = rcp_cg; k.rcp_ps = rcp_ps; k.rcp_w1 = rcp_w1; k.rcp_tw = rcp_tw;
+  static const bool tile_major = getenv("LITEPI_TILE_MAJOR") != nullptr;
+  k.tile_major = tile_major;
   dim3 grid(N, k.tiles_x * tiles_y);
+  if (tile_major) grid = dim3(k.tiles_x * tiles_y, N);
   const bool f16 = prec == LP_FP16;
   switch (NT) {
     case 1: if (f16) launch_bneck<half_t, 1>(k, grid, lds_bytes, st); else launch_bneck<float, 1>(k, grid, lds_bytes, st); break;
