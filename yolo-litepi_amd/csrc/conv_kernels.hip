@@ -468,7 +468,10 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
 // ------------------------------------------------------------------------------------
 // P1 / P2: pixel tiles per wave for conv_a / conv_b (compile time: the K loops are branch-free, a wave's surplus
 // tile recomputes the region's last pixel and is never written)
-template <typename T, int NT, int P1, int P2>
+// SEP: the intermediate gets its own LDS region instead of overwriting the input tile, so the shortcut operand x is
+// taken from LDS too (narrow layers on big maps are HBM-bound: this drops one of the 2.65 input reads per output;
+// used when LDS allows, i.e. NT == 1)
+template <typename T, int NT, int P1, int P2, bool SEP>
 __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel(const BneckArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
   const u32x4* lds_w1 = reinterpret_cast<const u32x4*>(smem + 512);
   const u32x4* lds_w2 = reinterpret_cast<const u32x4*>(smem + 512 + wbytes);
   char* tile = smem + 512 + 2 * wbytes;
+  char* tile2 = SEP ? tile + (TH + 4) * LW * PS : tile;  // where the intermediate goes
   for (int q = tid; q < S * 4; q += 256) {
     int tap = (int)(((unsigned)q * a.rcp_cg) >> 16);
     const int cg = q - tap * CG;
@@ -569,9 +573,12 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
 #pragma unroll
       for (int i = 0; i < P1; ++i) acc[t][i] = Tr<T>::mma(af[t], bf[i], acc[t][i]);
   }
-  // ---- the intermediate replaces the input tile (every wave is done reading it after the barrier)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  // ---- the intermediate replaces the input tile (every wave is done reading it after the barrier), or goes
+  //      to its own region (SEP: no barrier needed before writing)
+  if (!SEP) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 #pragma unroll
   for (int i = 0; i < P1; ++i) {
     const int p = (wave + 4 * i) * 16 + col;
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
       const int py = pk1[i] >> 16, px = pk1[i] & 0xffff;
       const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
       const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      T* dst = reinterpret_cast<T*>(tile + (py * LW + px) * PS) + g * 4 * NT;
+      T* dst = reinterpret_cast<T*>(tile2 + (py * LW + px) * PS) + g * 4 * NT;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (g * 4 * NT + t * 4 < a.C) {
@@ -615,13 +622,13 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
 #pragma unroll
     for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w2[(s * NT + t) * 64 + lane]);
 #pragma unroll
-    for (int i = 0; i < P2; ++i) bf[i] = as_frag<T>(*reinterpret_cast<const u32x4*>(tile + pb2[i] + toff));
+    for (int i = 0; i < P2; ++i) bf[i] = as_frag<T>(*reinterpret_cast<const u32x4*>(tile2 + pb2[i] + toff));
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < P2; ++i) acc2[t][i] = Tr<T>::mma(af[t], bf[i], acc2[t][i]);
   }
-  // ---- epilogue: bias, SiLU, shortcut (x re-read from global: L2-hot, this workgroup just staged it)
+  // ---- epilogue: bias, SiLU, shortcut (x from the preserved input tile, or re-read from global memory)
   const int chbase = g * 4 * NT;
 #pragma unroll
   for (int i = 0; i < P2; ++i) {
@@ -632,8 +639,9 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
       floatx4 v[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) v[t] = acc2[t][i];
-      store_lane_at<T, NT, ACT_SILU>(reinterpret_cast<T*>(a.out) + pix * a.out_pitch + chbase,
-                                     reinterpret_cast<const T*>(a.in) + pix * a.in_pitch + chbase, chbase, a.C, v, bias2);
+      const T* xres = SEP ? reinterpret_cast<const T*>(tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PS) + chbase
+                          : reinterpret_cast<const T*>(a.in) + pix * a.in_pitch + chbase;
+      store_lane_at<T, NT, ACT_SILU>(reinterpret_cast<T*>(a.out) + pix * a.out_pitch + chbase, xres, chbase, a.C, v, bias2);
     }
   }
 }
@@ -1444,15 +1452,18 @@ bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, int& th
   const int steps = ceil_div(9 * cg, 4);
   if (steps * 4 > 128) return false;
   const int pss = lds_pixel_slots(cg);
-  const int cand[3][2] = {{8, 40}, {8, 20}, {4, 20}};
+  const int cand[4][2] = {{16, 40}, {8, 40}, {8, 20}, {4, 20}};
   const int B = batch_hint > 0 ? batch_hint : 1;
+  const bool sep = nt == 1;  // separate LDS region for the intermediate (see the kernel's SEP)
   long best = -1;
   for (auto& cd : cand) {
     const int TH = cd[0], TW = cd[1];
+    static const bool no_big = getenv("LITEPI_BNECK_SMALL") != nullptr;  // A/B switch
+    if (TH == 16 && (nt != 1 || no_big)) continue;  // 12 + 10 pixel tiles per wave: only the single-channel-tile variant has the registers
     int l = TW + 4;
     if (cg <= 1) while (l % 16 != 2) ++l;  // one K group per pixel: 16 consecutive pixels x 4 taps conflict-free
     if (ceil_div(l * pss, 64) > 8) continue;
-    const size_t need = 512 + (size_t)2 * steps * nt * 1024 + (size_t)(TH + 4) * l * pss * 16;
+    const size_t need = 512 + (size_t)2 * steps * nt * 1024 + (size_t)(TH + 4 + (sep ? TH + 2 : 0)) * l * pss * 16;
     if (need > 150 * 1024) continue;
     const long tiles = (long)ceil_div(h, TH) * ceil_div(w, TW);
     const int util = (int)(100.0 * h * w / ((double)tiles * TH * TW));
@@ -1488,23 +1499,27 @@ void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, 
   rcp_ps = rcp16(PS / 16, 512);
   rcp_w1 = rcp16(TW + 2, 512);
   rcp_tw = rcp16(TW, 512);
-  LP_CHECK((TH + 2) * (TW + 2) <= 7 * 4 * 16 && TH * TW <= 5 * 4 * 16, LP_ERR_STATE, "bottleneck tile exceeds the kernel's pixel-tile budget");
+  LP_CHECK((TH + 2) * (TW + 2) <= 12 * 4 * 16 && TH * TW <= 10 * 4 * 16, LP_ERR_STATE, "bottleneck tile exceeds the kernel's pixel-tile budget");
 }
 
 template <typename T, int NT, int P1, int P2>
 static void launch_bneck_(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2>),
+  constexpr bool SEP = NT == 1;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  hipLaunchKernelGGL((bottleneck_mfma_kernel<T, NT, P1, P2>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((bottleneck_mfma_kernel<T, NT, P1, P2, SEP>), grid, dim3(256), lds, st, a);
 }
 
-// pixel tiles per wave = ceil(ceil(region / 16) / 4 waves) for the three tile shapes of plan()
+// pixel tiles per wave = ceil(ceil(region / 16) / 4 waves) for the tile shapes of plan()
 template <typename T, int NT>
 static void launch_bneck(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  if (a.TH == 8 && a.TW == 40) launch_bneck_<T, NT, 7, 5>(a, grid, lds, st);       // 10x42 = 27 tiles, 8x40 = 20
-  else if (a.TH == 8 && a.TW == 20) launch_bneck_<T, NT, 4, 3>(a, grid, lds, st);  // 10x22 = 14 tiles, 8x20 = 10
-  else if (a.TH == 4 && a.TW == 20) launch_bneck_<T, NT, 3, 2>(a, grid, lds, st);  //  6x22 =  9 tiles, 4x20 = 5
+  if (a.TH == 16 && a.TW == 40) {                                                   // 18x42 = 48 tiles, 16x40 = 40
+    if constexpr (NT == 1) launch_bneck_<T, 1, 12, 10>(a, grid, lds, st);
+    else throw Error(LP_ERR_STATE, "bottleneck: 16x40 tiles need NT == 1");
+  } else if (a.TH == 8 && a.TW == 40) launch_bneck_<T, NT, 7, 5>(a, grid, lds, st);  // 10x42 = 27 tiles, 8x40 = 20
+  else if (a.TH == 8 && a.TW == 20) launch_bneck_<T, NT, 4, 3>(a, grid, lds, st);    // 10x22 = 14 tiles, 8x20 = 10
+  else if (a.TH == 4 && a.TW == 20) launch_bneck_<T, NT, 3, 2>(a, grid, lds, st);    //  6x22 =  9 tiles, 4x20 = 5
   else throw Error(LP_ERR_STATE, "bottleneck: no kernel for this tile shape");
 }
 
