@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
 // of K = 9 x Cin) in LDS, B fragments gathered straight from global memory with per-tap bounds
 // checks (zero padding), flattened output pixels.
 // ------------------------------------------------------------------------------------
-template <typename T, int NT, int NP, int T2 = 0>
+template <typename T, int NT, int NP, int T2 = 0, int U = 4>
 __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
@@ -789,23 +789,38 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a)
 #pragma unroll
       for (int p = 0; p < NP; ++p) acc[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    for (int s = 0; s < S; ++s) {
-      const int2 te = lds_tab[4 * s + g];
+    // Every K step's gather is a memory round trip of its own, so the loads run U steps ahead of the MFMAs in a
+    // register ring of U steps (deep-K layers have 9-36 steps; without the ring each step waited for its own loads;
+    // shallow layers use U = 1: they are HBM-bound and want the registers for occupancy instead).
+    typename Tr<T>::frag ring[U][NP];
+    auto gather = [&](int s, typename Tr<T>::frag (&dst)[NP]) {
+      const int2 te = s < S ? lds_tab[4 * s + g] : make_int2(0, -1);
       const int toff = te.x, ky = te.y >> 8, kx = te.y & 0xff;
-      typename Tr<T>::frag af[NT], bf[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
         const int iy = iy0[p] + ky, ix = ix0[p] + kx;
         if (te.y >= 0 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) v = *reinterpret_cast<const u32x4*>(src[p] + toff);
-        bf[p] = as_frag<T>(v);
+        dst[p] = as_frag<T>(v);
       }
+    };
 #pragma unroll
-      for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w[(s * NT + t) * 64 + lane]);
+    for (int u = 0; u < U; ++u) gather(u, ring[u]);
+    for (int s0 = 0; s0 < S; s0 += U) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int u = 0; u < U; ++u) {
+        const int s = s0 + u;
+        if (s < S) {
+          typename Tr<T>::frag af[NT];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) acc[t][p] = Tr<T>::mma(af[t], bf[p], acc[t][p]);
+          for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w[(s * NT + t) * 64 + lane]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) acc[t][p] = Tr<T>::mma(af[t], ring[u][p], acc[t][p]);
+        }
+        gather(s + U, ring[u]);
+      }
     }
     if constexpr (T2 > 0) {
       typename Tr<T>::frag w2f[T2][TailSteps<T>::per_nt(NT)];
@@ -1077,15 +1092,23 @@ static size_t elem_size(int prec) { return prec == LP_FP16 ? 2 : 4; }
 // per pixel, a pixel pitch of p = (smallest value >= cg with p % 4 == 2) 16-byte slots and a row
 // width = 12 (mod 16) pixels make the 4x4-pixel x 4-K-group fragment read conflict-free (4 LDS
 // cycles); the former odd-pitch rule cost 8.  One group per pixel (cg = 1): pitch 1, row = 4 (mod 16).
-static int lds_pixel_slots(int cg) {
+static int lds_pixel_slots(int cg, int stride = 1) {
   if (cg <= 1) return 1;
   int p = cg;
+  if (stride == 2) {  // patches of every other pixel: an odd pitch (and a row width = 4 mod 8) is the conflict-free one
+    while (p % 2 != 1) ++p;
+    return p;
+  }
   while (p % 4 != 2) ++p;
   return p;
 }
-static int lds_row_width(int iw, int cg) {
-  const int want = cg <= 1 ? 4 : 12;
+static int lds_row_width(int iw, int cg, int stride = 1) {
   int lw = iw;
+  if (stride == 2 && cg > 1) {
+    while (lw % 8 != 4) ++lw;
+    return lw;
+  }
+  const int want = cg <= 1 ? 4 : 12;
   while (lw % 16 != want) ++lw;
   return lw;
 }
@@ -1138,9 +1161,10 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
   };
   const int B = batch_hint > 0 ? batch_hint : 1;
 
-  // stride-2: gather straight from global memory, except deep-K layers without a fused tail (every K step of the
-  // gather is a dependent memory round trip; the LDS-DMA staged kernel pipelines chunks instead)
-  static const int s2_staged_min_cin = getenv("LITEPI_S2_STAGED") ? atoi(getenv("LITEPI_S2_STAGED")) : 64;
+  // stride-2: gather straight from global memory (conv3x3s2_direct_kernel).  LITEPI_S2_STAGED=<min Cin> routes deep-K
+  // layers without a fused tail through the LDS-staged kernel instead (A/B switch; slower since the gather kernel
+  // keeps its loads a few K steps ahead)
+  static const int s2_staged_min_cin = getenv("LITEPI_S2_STAGED") ? atoi(getenv("LITEPI_S2_STAGED")) : 1 << 30;
   direct = (k == 3 && stride == 2) && (full_n || Cin < s2_staged_min_cin);
   if (single_chunk) {
     // weights only (BottleneckPair): every channel tile in one workgroup, all of K in one chunk
@@ -1184,10 +1208,10 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
       for (int ck = 8; ck <= Cin && ck <= 64; ck += 8) {
         if (Cin % ck) continue;
         const int cgc = ck / G;
-        const int l = lds_row_width(IW, cgc);
-        const size_t one = (size_t)ceil_div(taps * cgc, 4) * nt * 1024 + (size_t)IH * l * lds_pixel_slots(cgc) * 16;
+        const int l = lds_row_width(IW, cgc, stride);
+        const size_t one = (size_t)ceil_div(taps * cgc, 4) * nt * 1024 + (size_t)IH * l * lds_pixel_slots(cgc, stride) * 16;
         const size_t lds = 512 + (ck == Cin ? one : 2 * one);
-        if (lds <= budget && ceil_div(taps * cgc, 4) * 4 <= 128 && ceil_div(l * lds_pixel_slots(cgc), 64) <= 8) { ck_fit = ck; lw = l; }
+        if (lds <= budget && ceil_div(taps * cgc, 4) * 4 <= 128 && ceil_div(l * lds_pixel_slots(cgc, stride), 64) <= 8) { ck_fit = ck; lw = l; }
       }
       if (!ck_fit) continue;
       const int util = (int)(100.0 * hout * wout / ((double)tiles * TH * TW));
@@ -1199,7 +1223,7 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     nsplits = ceil_div(tiles_total, NT);
     const int IH = (4 * bwh - 1) * stride + 3;
     CGc = CK / G;
-    PS = lds_pixel_slots(CGc) * 16;
+    PS = lds_pixel_slots(CGc, stride) * 16;
     nchunks = Cin / CK;
     steps = ceil_div(taps * CGc, 4);
     LP_CHECK(steps * 4 <= 128, LP_ERR_GRAPH, "conv3x3: too many K steps per chunk");
@@ -1302,12 +1326,17 @@ static void launch3x3(const ConvArgs& a, int stride, dim3 grid, int threads, siz
   }
 }
 
-template <typename T, int NT>
-static void launch_s2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<T, NT, 4>),
+template <typename T, int NT, int U>
+static void launch_s2_u(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<T, NT, 4, 0, U>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  hipLaunchKernelGGL((conv3x3s2_direct_kernel<T, NT, 4>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3s2_direct_kernel<T, NT, 4, 0, U>), grid, dim3(256), lds, st, a);
+}
+template <typename T, int NT>
+static void launch_s2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  if (a.steps >= 5) launch_s2_u<T, NT, 4>(a, grid, lds, st);
+  else launch_s2_u<T, NT, 1>(a, grid, lds, st);
 }
 
 template <typename T, int NT, int NP, int EPI>
@@ -1369,17 +1398,22 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
   }
     if (T2) {
       LP_CHECK(!io.res.base, LP_ERR_STATE, "fused tail with residual unsupported");
-#define LP_LDT(TT, N_, T_)                                                                                              \
-  {                                                                                                                     \
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<TT, N_, 4, T_>),  \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);       \
-    (void)once;                                                                                                         \
-    hipLaunchKernelGGL((conv3x3s2_direct_kernel<TT, N_, 4, T_>), grid, dim3(256), lds_bytes, st, a);                     \
+#define LP_LDT_(TT, N_, T_, U_)                                                                                              \
+  {                                                                                                                          \
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<TT, N_, 4, T_, U_>),  \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);            \
+    (void)once;                                                                                                              \
+    hipLaunchKernelGGL((conv3x3s2_direct_kernel<TT, N_, 4, T_, U_>), grid, dim3(256), lds_bytes, st, a);                      \
+  }
+#define LP_LDT(TT, N_, T_)                               \
+  {                                                      \
+    if (a.steps >= 5) LP_LDT_(TT, N_, T_, 4) else LP_LDT_(TT, N_, T_, 1) \
   }
       if (NT == 1 && T2 == 1) { if (f16) LP_LDT(half_t, 1, 1) else LP_LDT(float, 1, 1) }
       else if (NT == 2 && T2 == 2) { if (f16) LP_LDT(half_t, 2, 2) else LP_LDT(float, 2, 2) }
       else if (NT == 4 && T2 == 4) { if (f16) LP_LDT(half_t, 4, 4) else LP_LDT(float, 4, 4) }
       else throw Error(LP_ERR_STATE, "conv3x3/s2: unsupported fused tail shape");
+#undef LP_LDT_
 #undef LP_LDT
     } else if (f16) { LP_LD(half_t) } else { LP_LD(float) }
 #undef LP_LD
