@@ -210,14 +210,28 @@ def main():
             f["ms"] /= n; f["flops"] /= n; f["bytes"] /= n; f["launches"] = int(f["launches"] / n)
         dom = max(families, key=lambda k: families[k]["ms"])
         f = families[dom]
-        if f["flops"] > 0:
-            ach = f["flops"] / (f["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_FP16_TFLOPS, "traffic": None}
+        # which roof bounds the dominant family: its algorithmic intensity against the ridge (2.5 PFLOP/s / 8 TB/s)
+        ridge = PEAK_FP16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        tfl = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+        if f["flops"] > 0 and f["bytes"] > 0 and f["flops"] / f["bytes"] >= ridge:
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": tfl, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tfl / PEAK_FP16_TFLOPS, "traffic": None}
         else:
-            ach = f["bytes"] / (f["ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": ach / PEAK_HBM_GBS, "traffic": None}
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": gbs / PEAK_HBM_GBS, "traffic": None}
+        roofline["flop_per_byte"] = f["flops"] / f["bytes"] if f["bytes"] > 0 else None
+        roofline["achieved_tflops"] = tfl
+        roofline["algorithmic_bytes_per_launch"] = f["bytes"] / max(f["launches"], 1)
+        # HBM bytes per launch from the PMC passes (separate rocprofv3 runs, tools/pmc_profile.sh + tools/pmc_traffic.py;
+        # committed under profiles/): offline by nature, read here so that the line carries it next to `achieved`
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tfile) and args.preset == "v1" and args.precision == "fp16" and B == 64:
+            with open(tfile) as fh:
+                fam = json.load(fh).get("families", {}).get(dom)
+            if fam:
+                roofline["traffic"] = fam["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same workload)"
         roofline["launches_per_step"] = f["launches"]
         roofline["avg_launch_ms"] = f["ms"] / max(f["launches"], 1)
         roofline["algorithmic_per_step"] = f["flops"] if f["flops"] > 0 else f["bytes"]

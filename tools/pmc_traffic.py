@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Per-kernel-family HBM traffic of ONE bench step from the rocprofv3 --pmc passes of tools/pmc_profile.sh.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_r01_final > profiles/r01_pmc_traffic.json
+
+Uses pass3 (FETCH_SIZE) and pass4 (WRITE_SIZE, TCC hit/miss) and only the dispatches of the last step of each pass
+(the earlier ones are the untimed calibration passes at a smaller batch).  FETCH_SIZE is doubled as
+MI355X_MICROARCH.md prescribes for gfx950 (16-byte-per-lane coalesced reads are tallied at half their size);
+both counters are in KiB.  bench.py reads the resulting file to fill roofline.traffic for the dominant family.
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def family(name):
+    f16 = "_f16" if "DF16_" in name or "<f16" in name else "_f32"
+    ints = [int(v) for v in re.findall(r"Li(\d+)E", name)]
+    if "bottleneck_mfma_kernel" in name:
+        return "bottleneck3x3x2" + f16
+    if "conv3x3s2_direct_kernel" in name:
+        return "conv3x3s2_direct" + ("+1x1" if len(ints) > 2 and ints[2] > 0 else "") + f16
+    if "conv3x3_mfma_kernel" in name:
+        return "conv3x3_mfma" + ("+1x1" if len(ints) > 2 and ints[2] > 0 else "") + f16
+    if "conv1x1_mfma_kernel" in name:
+        return "conv1x1_mfma" + f16
+    if "stem_mfma_kernel" in name or "stem_conv" in name:
+        return "stem_conv_f16" if "stem_mfma" in name else "stem_conv" + f16
+    for key, fam in (("roi_resize_kernel", "roi_resize_pil"), ("shuffle_stage_kernel", "shuffle_stage_fused_f16"),
+                     ("cls_head_kernel", "cls_head_fused_f16"), ("nms_kernel", "nms"), ("roi_index_kernel", "roi_index")):
+        if key in name:
+            return fam
+    m = re.search(r"lp::(\w+)|_ZN2lp\d+([a-z0-9_]+?)I", name)
+    base = (m.group(1) or m.group(2)) if m else name
+    return base.replace("_kernel", "") + (f16 if "I" in name and "lp::" not in name else "")
+
+
+def last_step(root, p):
+    tr = glob.glob(f"{root}/pass{p}/**/*kernel_trace.csv", recursive=True)[0]
+    cc = glob.glob(f"{root}/pass{p}/**/*counter_collection.csv", recursive=True)[0]
+    disp = {r["Dispatch_Id"]: (r["Kernel_Name"], int(r["Start_Timestamp"])) for r in csv.DictReader(open(tr))}
+    ctr = collections.defaultdict(dict)
+    for r in csv.DictReader(open(cc)):
+        ctr[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+    ids = sorted(disp, key=lambda k: disp[k][1])
+    stems = [i for i in ids if "stem" in disp[i][0] and "cls_stem" not in disp[i][0]]
+    start = disp[stems[-1]][1]
+    return [(disp[i][0], ctr[i]) for i in ids if disp[i][1] >= start and "lp" in disp[i][0]]
+
+
+def main(root):
+    out = collections.OrderedDict()
+    for name, c in last_step(root, 3):
+        f = out.setdefault(family(name), {"launches": 0, "hbm_read_bytes": 0.0, "hbm_write_bytes": 0.0})
+        f["launches"] += 1
+        f["hbm_read_bytes"] += 2.0 * c.get("FETCH_SIZE", 0.0) * 1024.0
+    for name, c in last_step(root, 4):
+        out[family(name)]["hbm_write_bytes"] += c.get("WRITE_SIZE", 0.0) * 1024.0
+    for f in out.values():
+        f["hbm_bytes_per_launch"] = (f["hbm_read_bytes"] + f["hbm_write_bytes"]) / max(f["launches"], 1)
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) / WRITE_SIZE, one 64-image step, tools/pmc_profile.sh",
+               "families": out}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -113,6 +113,9 @@ struct ConvArgs {
   const void* w2;
   const float* bias2;
   int act2, Cout2;
+  // 1x1 kernel, fused nearest-x2 upsample: the first up_cg K groups come from a half-resolution tensor
+  const void* up;
+  int up_pitch, up_cg;
   int tile_major;              // 0: grid = (image, tile, split) (XCD-aware, default); 1: (tile, image, split)
   unsigned rcp_tx, rcp_cg, rcp_ps;  // 3x3 kernel: 16-bit reciprocals of tiles_x, CGc, PS/16 (set by launch)
   const void* zeros;           // >= 16 zero bytes (source of the 3x3 kernel's padding slots)

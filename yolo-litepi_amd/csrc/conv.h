@@ -6,6 +6,7 @@ namespace lp {
 
 struct ConvIO {
   View in, out, res, x1;
+  View up;                     // 1x1 only: half-resolution source of the leading up.C input channels (fused Interp x2 + Concat)
   int N = 0;
   const int* m_dyn = nullptr;  // device scalar item count (classifier); M = *m_dyn * out.H * out.W
   int half_c = 0, half_cp = 0; // shuffle epilogue geometry (x1.base != nullptr)

@@ -652,7 +652,10 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
 // this block's channel split live in LDS for the whole (grid-stride) pixel loop.  M may come
 // from device memory (m_dyn): the classifier's ROI count is only known on the GPU.
 // ------------------------------------------------------------------------------------
-template <typename T, int NT, int NP, int EPI>
+// UPS: the layer reads concat(upsample2x(u), x) (FPN top-down path: Interp + Concat + C2f.cv1 in the reference graph).
+// The first up_cg K groups are then gathered from the half-resolution tensor u at (y/2, x/2) -- nearest-neighbour
+// upsampling is pure addressing -- and the 4x larger copy of u is never written or re-read.
+template <typename T, int NT, int NP, int EPI, bool UPS = false>
 __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
@@ -680,11 +683,19 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
     const long pix0 = (tile * 4 + wave) * 16 * NP;
     if (pix0 >= M) continue;
     const T* src[NP];
+    const T* src2[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       long pix = pix0 + p * 16 + col;
       pix = pix < M ? pix : M - 1;
       src[p] = in + pix * a.in_pitch;
+      src2[p] = nullptr;
+      if constexpr (UPS) {
+        const int hw = a.Hout * a.Wout;
+        const int n = (int)(pix / hw), rem = (int)(pix - (long)n * hw);
+        const int y = rem / a.Wout, x = rem - y * a.Wout;
+        src2[p] = reinterpret_cast<const T*>(a.up) + ((long)(n * (a.Hout >> 1) + (y >> 1)) * (a.Wout >> 1) + (x >> 1)) * a.up_pitch;
+      }
     }
     floatx4 acc[NT][NP];
 #pragma unroll
@@ -698,7 +709,11 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (q < CG) v = *reinterpret_cast<const u32x4*>(src[p] + q * G);
+        if constexpr (UPS) {
+          if (q < CG) v = *reinterpret_cast<const u32x4*>(q < a.up_cg ? src2[p] + q * G : src[p] + (q - a.up_cg) * G);
+        } else {
+          if (q < CG) v = *reinterpret_cast<const u32x4*>(src[p] + q * G);
+        }
         bf[p] = as_frag<T>(v);
       }
 #pragma unroll
@@ -1349,7 +1364,12 @@ static void launch1x1_(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st)
 
 template <typename T, int NT>
 static void launch1x1(const ConvArgs& a, bool shuffle, dim3 grid, size_t lds, hipStream_t st) {
-  if (shuffle)
+  if (a.up) {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_mfma_kernel<T, NT, 4, EPI_PLAIN, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((conv1x1_mfma_kernel<T, NT, 4, EPI_PLAIN, true>), grid, dim3(256), lds, st, a);
+  } else if (shuffle)
     launch1x1_<T, NT, 4, EPI_SHUFFLE>(a, grid, lds, st);
   else
     launch1x1_<T, NT, 4, EPI_PLAIN>(a, grid, lds, st);
@@ -1369,7 +1389,13 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
   a.half_c = io.half_c; a.half_cp = io.half_cp; a.out_f32 = io.out_f32; a.stamps = io.stamps;
   a.w2 = d_w2.p; a.bias2 = d_bias2.as<float>(); a.act2 = act2; a.Cout2 = Cout2;
   a.zeros = d_bias.as<float>() + round_up(Cout, 64);  // the bias buffer ends in 64 zero floats
-  LP_CHECK(io.in.C == Cin, LP_ERR_STATE, "conv input view has %d channels, layer expects %d", io.in.C, Cin);
+  LP_CHECK(io.in.C + (io.up.base ? io.up.C : 0) == Cin, LP_ERR_STATE, "conv input view has %d channels, layer expects %d", io.in.C, Cin);
+  if (io.up.base) {
+    const int Gk = prec == LP_FP16 ? 8 : 4;
+    LP_CHECK(k == 1 && impl == IMPL_MFMA && !io.x1.base && !io.m_dyn && !io.out_f32 && io.up.C % Gk == 0 && (io.up.pitch % Gk) == 0 &&
+                 io.up.H * 2 == io.out.H && io.up.W * 2 == io.out.W, LP_ERR_STATE, "conv %s: fused upsample source does not fit", name.c_str());
+    a.up = io.up.base; a.up_pitch = io.up.pitch; a.up_cg = io.up.C / Gk;
+  }
   LP_CHECK(io.x1.base || io.out.C >= (T2 ? Cout2 : Cout) || io.out_f32, LP_ERR_STATE, "conv output view too narrow (%d < %d)", io.out.C, T2 ? Cout2 : Cout);
   LP_CHECK((io.in.pitch % 8) == 0 && (io.out.pitch % 4) == 0, LP_ERR_STATE, "unaligned channel pitch");
   const bool f16 = prec == LP_FP16;

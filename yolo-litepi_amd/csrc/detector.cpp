@@ -321,6 +321,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
 
   // ---- pass D: emit ops ------------------------------------------------------------------------
   std::vector<char> done(n, 0);
+  std::map<int, int> fuse_up;  // 1x1 conv layer -> half-resolution tensor it upsamples on the fly
   macs_ = 0;
   const double esd = (double)es;
   for (int i = 0; i < first_tail; ++i) {
@@ -537,6 +538,11 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         }
         op.kind = DetOp::CONV;
         op.conv = (int)convs_.size() - 1;
+        if (fuse_up.count(i)) {
+          op.in2 = fuse_up[i];
+          op.layer = l.name + "(up)";
+          op.bytes -= 0.75 * tensors_[op.in2].C * 4.0 * tensors_[op.in2].H * tensors_[op.in2].W * esd;  // u is read once, not its x4 copy
+        }
       }
       ops_.push_back(op);
     } else if (l.type == "BinaryOp") {
@@ -566,6 +572,22 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
       op.bytes = 4.0 * T.C * T.H * T.W * esd;
       ops_.push_back(op);
     } else if (l.type == "Interp") {
+      // upsample fusion: Interp x2 -> first input of a Concat -> exactly one 1x1 conv (FPN top-down: C2f.cv1).  The conv
+      // gathers those channels from the half-resolution tensor itself; the upsampled copy is never materialised.
+      static const bool no_upfuse = getenv("LITEPI_NO_UPFUSE") != nullptr;
+      if (!no_upfuse && impl_ == IMPL_MFMA) {
+        auto& c1 = canon_consumers[canon(l.outputs[0])];
+        if (c1.size() == 1 && L[c1[0]].type == "Concat" && canon(L[c1[0]].inputs[0]) == canon(l.outputs[0])) {
+          auto& c2 = canon_consumers[canon(L[c1[0]].outputs[0])];
+          const int tsrc = get(l.inputs[0]);
+          if (c2.size() == 1 && L[c2[0]].type == "Convolution" && L[c2[0]].ipar(1, 1) == 1 && L[c2[0]].ipar(3, 1) == 1 &&
+              !is_tail(c2[0]) && tensors_[get(l.outputs[0])].off == 0 && tensors_[tsrc].Cp % 8 == 0 &&
+              tensors_[tsrc].Cp == tensors_[get(l.outputs[0])].Cp) {
+            fuse_up[c2[0]] = tsrc;
+            continue;
+          }
+        }
+      }
       DetOp op;
       op.kind = DetOp::UPSAMPLE; op.layer = l.name;
       op.in = get(l.inputs[0]); op.out = get(l.outputs[0]);
@@ -655,6 +677,11 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         ConvIO io;
         io.in = view(op.in); io.out = view(op.out); io.N = B;
         if (op.res >= 0) io.res = view(op.res);
+        if (op.in2 >= 0) {  // fused upsample: leading channels from the half-resolution tensor, the rest from the concat buffer
+          io.up = view(op.in2);
+          io.in.base = static_cast<char*>(io.in.base) + (size_t)io.up.C * (prec_ == LP_FP16 ? 2 : 4);
+          io.in.C -= io.up.C;
+        }
         c.launch(io, st);
         kname = std::string(c.impl == IMPL_NAIVE ? "conv_naive" : (c.direct ? "conv3x3s2_direct" : (c.k == 3 ? "conv3x3_mfma" : "conv1x1_mfma"))) + (c.T2 ? "+1x1" : "") + sfx;
         break;
