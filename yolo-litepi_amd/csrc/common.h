@@ -136,6 +136,14 @@ struct BneckArgs {
   int TH, TW, tiles_x, LW, PS, CG, steps;
   unsigned rcp_tx, rcp_cg, rcp_ps, rcp_w1, rcp_tw;
   int tile_major;
+  // fused C2f.cv2 (1x1 over the concat [y0, y1, .., y_last]): y_last comes from the accumulators, the other
+  // segments are read from the concat buffer `cat` (channels [0, kg*G)); `out` is not written then
+  const void* w3;   // cv2 fragments [T2][sg + sr][lane][16 B]
+  const float* b3;
+  const void* cat;
+  void* out3;
+  int cat_pitch, out3_pitch, C3, act3;
+  int kg, sg;       // global K groups and their K steps (sr = register steps, fixed by NT)
 };
 
 enum ConvImpl { IMPL_MFMA = 0, IMPL_NAIVE = 1 };

@@ -53,14 +53,26 @@ struct BottleneckPair {
   unsigned rcp_cg = 0, rcp_ps = 0, rcp_w1 = 0, rcp_tw = 0;
   size_t lds_bytes = 0;
   std::string name;
-  // can a C->C bottleneck on an h x w map (batch_hint images) run fused?  (LDS capacity, tile limits)
-  static bool supported(int prec, int impl, int c_phys, int h, int w, int batch_hint);
+  // optional fused C2f.cv2 (1x1 over concat[stored segments .., y_last]); y_last = this bottleneck's output
+  struct Cv2 {
+    int cat_global = 0;          // physical channels of the concat that precede y_last (read from the concat buffer)
+    int c3 = 0, act = ACT_NONE;  // cv2 output channels (physical), activation
+    const std::vector<float>* w = nullptr;  // fp32 [c3][cat_global + C] over physical concat channels
+    const std::vector<float>* bias = nullptr;
+  };
+  int T2 = 0, C3 = 0, act3 = ACT_NONE, kg = 0, sg = 0;
+  DevBuf d_w3, d_b3;
+  // can a C->C bottleneck on an h x w map (batch_hint images) run fused?  (LDS capacity, tile limits); cv2 = nullptr: without tail
+  static bool supported(int prec, int impl, int c_phys, int h, int w, int batch_hint, const Cv2* cv2 = nullptr);
   // weights as for ConvLayer::build: fp32 [C][9][C] over physical channels, bias [C]
   void build(int prec, int c_phys, const std::vector<float>& wa, const std::vector<float>& ba, const std::vector<float>& wb,
-             const std::vector<float>& bb, int h, int w, int batch_hint);
-  void launch(const View& in, const View& out, int N, hipStream_t st) const;
+             const std::vector<float>& bb, int h, int w, int batch_hint, const Cv2* cv2 = nullptr);
+  // without cv2: out = bottleneck output.  With cv2: cat = the concat buffer view (its leading cat_global channels are read),
+  // out = cv2's output view; the bottleneck output itself is not stored.
+  void launch(const View& in, const View& out, int N, hipStream_t st, const View* cat = nullptr) const;
  private:
-  static bool plan(int prec, int c_phys, int h, int w, int batch_hint, int& th, int& tw, int& lw, size_t& lds);
+  static bool plan(int prec, int c_phys, int h, int w, int batch_hint, size_t extra_lds, bool tail, int& th, int& tw, int& lw, size_t& lds);
+  static bool cv2_shape(int prec, int c_phys, const Cv2& cv2, int& t2, int& kg, int& sg);
 };
 
 // First layer: 3x3 stride-2 conv reading the uint8 BGR image directly.

@@ -471,7 +471,10 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
 // SEP: the intermediate gets its own LDS region instead of overwriting the input tile, so the shortcut operand x is
 // taken from LDS too (narrow layers on big maps are HBM-bound: this drops one of the 2.65 input reads per output;
 // used when LDS allows, i.e. NT == 1)
-template <typename T, int NT, int P1, int P2, bool SEP>
+// T2 > 0: the C2f's closing 1x1 conv (cv2 over concat[y0, y1, .., y_last]) runs here as well, T2 = its 16-channel
+// output tiles.  y_last never leaves the registers (the accumulator tile is already a B operand, as in tail_store);
+// the other concat segments are gathered from the concat buffer, 16 B per lane per K step.
+template <typename T, int NT, int P1, int P2, bool SEP, int T2 = 0>
 __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel(const BneckArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
@@ -487,12 +490,15 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
   const int R1 = H1 * W1, R2 = TH * TW;
   const int n1 = (R1 + 15) >> 4, n2 = (R2 + 15) >> 4;
 
-  // LDS: [tap table 512 B][conv_a fragments S*NT KB][conv_b fragments S*NT KB][tile: input, later the intermediate]
+  // LDS: [tap table 512 B][conv_a fragments S*NT KB][conv_b fragments S*NT KB][cv2 fragments][tile: input, later the intermediate]
   int* lds_toff = reinterpret_cast<int*>(smem);
   const int wbytes = S * NT * 1024;
   const u32x4* lds_w1 = reinterpret_cast<const u32x4*>(smem + 512);
   const u32x4* lds_w2 = reinterpret_cast<const u32x4*>(smem + 512 + wbytes);
-  char* tile = smem + 512 + 2 * wbytes;
+  constexpr int SR = TailSteps<T>::per_nt(NT);  // cv2 K steps fed from the accumulators
+  const int w3frags = T2 > 0 ? T2 * (a.sg + SR) : 0;
+  const u32x4* lds_w3 = reinterpret_cast<const u32x4*>(smem + 512 + 2 * wbytes);
+  char* tile = smem + 512 + 2 * wbytes + w3frags * 1024;
   char* tile2 = SEP ? tile + (TH + 4) * LW * PS : tile;  // where the intermediate goes
   for (int q = tid; q < S * 4; q += 256) {
     int tap = (int)(((unsigned)q * a.rcp_cg) >> 16);
@@ -512,6 +518,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
       const u32x4* src = p < S * NT ? reinterpret_cast<const u32x4*>(a.w1) + p * 64 : reinterpret_cast<const u32x4*>(a.w2) + (p - S * NT) * 64;
       LP_GLDS16(src + lane, smem + 512 + p * 1024);
     }
+    for (int p = wave; p < w3frags; p += 4) LP_GLDS16(reinterpret_cast<const u32x4*>(a.w3) + p * 64 + lane, smem + 512 + 2 * wbytes + p * 1024);
     int soff[MAXP];
 #pragma unroll
     for (int pc = 0; pc < MAXP; ++pc) {
@@ -630,18 +637,93 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
   }
   // ---- epilogue: bias, SiLU, shortcut (x from the preserved input tile, or re-read from global memory)
   const int chbase = g * 4 * NT;
+  if constexpr (T2 == 0) {
 #pragma unroll
-  for (int i = 0; i < P2; ++i) {
-    const int p = (wave + 4 * i) * 16 + col;
-    const int gy = oy0 + (pk2[i] >> 16), gx = ox0 + (pk2[i] & 0xffff);
-    if (wave + 4 * i < n2 && p < R2 && gy < a.H && gx < a.W) {
-      const long pix = (long)(n * a.H + gy) * a.W + gx;
-      floatx4 v[NT];
+    for (int i = 0; i < P2; ++i) {
+      const int p = (wave + 4 * i) * 16 + col;
+      const int gy = oy0 + (pk2[i] >> 16), gx = ox0 + (pk2[i] & 0xffff);
+      if (wave + 4 * i < n2 && p < R2 && gy < a.H && gx < a.W) {
+        const long pix = (long)(n * a.H + gy) * a.W + gx;
+        floatx4 v[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) v[t] = acc2[t][i];
+        for (int t = 0; t < NT; ++t) v[t] = acc2[t][i];
+        const T* xres = SEP ? reinterpret_cast<const T*>(tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PS) + chbase
+                            : reinterpret_cast<const T*>(a.in) + pix * a.in_pitch + chbase;
+        store_lane_at<T, NT, ACT_SILU>(reinterpret_cast<T*>(a.out) + pix * a.out_pitch + chbase, xres, chbase, a.C, v, bias2);
+      }
+    }
+  } else {
+    // ---- ... and cv2 on concat[.., y_last]: per pixel tile, gather the stored segments, turn the accumulators into
+    //      y_last (rounded to T and shortcut added exactly as the stand-alone store does), two small GEMMs, store
+    constexpr int SGMAX = sizeof(T) == 2 ? 3 : 6;
+    const int ST = a.sg + SR;
+    floatx4 bias3[T2];
+#pragma unroll
+    for (int t = 0; t < T2; ++t) bias3[t] = *reinterpret_cast<const floatx4*>(a.b3 + g * 4 * T2 + t * 4);
+#pragma unroll
+    for (int i = 0; i < P2; ++i) {
+      if (wave + 4 * i >= n2) continue;  // wave-uniform
+      const int p = (wave + 4 * i) * 16 + col;
+      const int gy = oy0 + (pk2[i] >> 16), gx = ox0 + (pk2[i] & 0xffff);
+      const bool valid = p < R2 && gy < a.H && gx < a.W;
+      const long pix = valid ? (long)(n * a.H + gy) * a.W + gx : 0;
+      typename Tr<T>::frag bg[SGMAX];
+#pragma unroll
+      for (int s = 0; s < SGMAX; ++s) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (valid && 4 * s + g < a.kg) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.cat) + pix * a.cat_pitch + (4 * s + g) * G);
+        bg[s] = as_frag<T>(v);
+      }
+      // y_last: activation, round to T, add the shortcut, round again (= store_lane_at), kept as the register B operand
       const T* xres = SEP ? reinterpret_cast<const T*>(tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PS) + chbase
                           : reinterpret_cast<const T*>(a.in) + pix * a.in_pitch + chbase;
-      store_lane_at<T, NT, ACT_SILU>(reinterpret_cast<T*>(a.out) + pix * a.out_pitch + chbase, xres, chbase, a.C, v, bias2);
+      T yl[NT][4];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        typename Tr<T>::quad xr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xr[r] = (T)0.f;
+        if (valid && chbase + t * 4 < a.C) xr = *reinterpret_cast<const typename Tr<T>::quad*>(xres + t * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const T q = (T)activate_ct<T, ACT_SILU>(acc2[t][i][r] + bias2[t][r]);
+          yl[t][r] = (T)((float)q + (float)xr[r]);
+        }
+      }
+      typename Tr<T>::frag bq[SR];
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int s = 0; s < SR; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bq[s][r] = yl[2 * s][r];
+            bq[s][4 + r] = (2 * s + 1 < NT) ? yl[(2 * s + 1 < NT) ? 2 * s + 1 : 0][r] : (T)0.f;
+          }
+      } else {
+#pragma unroll
+        for (int s = 0; s < SR; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bq[s][r] = yl[s][r];
+      }
+      floatx4 o[T2];
+#pragma unroll
+      for (int t = 0; t < T2; ++t) o[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < SGMAX; ++s) {
+        if (s < a.sg) {
+#pragma unroll
+          for (int t = 0; t < T2; ++t) o[t] = Tr<T>::mma(as_frag<T>(lds_w3[(t * ST + s) * 64 + lane]), bg[s], o[t]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < SR; ++s)
+#pragma unroll
+        for (int t = 0; t < T2; ++t) o[t] = Tr<T>::mma(as_frag<T>(lds_w3[(t * ST + a.sg + s) * 64 + lane]), bq[s], o[t]);
+      if (valid) {
+        T* o3 = reinterpret_cast<T*>(a.out3) + pix * a.out3_pitch + g * 4 * T2;
+        if (a.act3 == ACT_SILU) store_lane_at<T, T2, ACT_SILU>(o3, nullptr, g * 4 * T2, a.C3, o, bias3);
+        else store_lane_at<T, T2, ACT_NONE>(o3, nullptr, g * 4 * T2, a.C3, o, bias3);
+      }
     }
   }
 }
@@ -1504,7 +1586,19 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
 
 
 // ---- fused bottleneck pair ---------------------------------------------------------------------
-bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, int& th, int& tw, int& lw, size_t& lds) {
+bool BottleneckPair::cv2_shape(int prec, int c, const Cv2& cv2, int& t2, int& kg, int& sg) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const int nt = ceil_div(c, 16);
+  if (cv2.cat_global <= 0 || cv2.cat_global % G != 0 || cv2.c3 % 8 != 0) return false;
+  t2 = ceil_div(cv2.c3, 16);
+  kg = cv2.cat_global / G;
+  sg = ceil_div(kg, 4);
+  // kernel instantiations: NT = 1 with T2 in {1, 2}, NT = 2 with T2 in {2, 4}; at most 3 (fp16) / 6 (fp32) gathered K steps
+  if (!((nt == 1 && (t2 == 1 || t2 == 2)) || (nt == 2 && (t2 == 2 || t2 == 4)))) return false;
+  return sg <= (prec == LP_FP16 ? 3 : 6);
+}
+
+bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, size_t extra_lds, bool tail, int& th, int& tw, int& lw, size_t& lds) {
   const int G = prec == LP_FP16 ? 8 : 4;
   if (c % 8 != 0 || c > 64) return false;
   const int nt = ceil_div(c, 16), cg = c / G;
@@ -1520,10 +1614,11 @@ bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, int& th
     const int TH = cd[0], TW = cd[1];
     static const bool no_big = getenv("LITEPI_BNECK_SMALL") != nullptr;  // A/B switch
     if (TH == 16 && (nt != 1 || no_big)) continue;  // 12 + 10 pixel tiles per wave: only the single-channel-tile variant has the registers
+    if (tail && TH == 4) continue;                  // no cv2 instantiation for the smallest tile
     int l = TW + 4;
     if (cg <= 1) while (l % 16 != 2) ++l;  // one K group per pixel: 16 consecutive pixels x 4 taps conflict-free
     if (ceil_div(l * pss, 64) > 8) continue;
-    const size_t need = 512 + (size_t)2 * steps * nt * 1024 + (size_t)(TH + 4 + (sep ? TH + 2 : 0)) * l * pss * 16;
+    const size_t need = 512 + (size_t)2 * steps * nt * 1024 + extra_lds + (size_t)(TH + 4 + (sep ? TH + 2 : 0)) * l * pss * 16;
     if (need > 150 * 1024) continue;
     const long tiles = (long)ceil_div(h, TH) * ceil_div(w, TW);
     const int util = (int)(100.0 * h * w / ((double)tiles * TH * TW));
@@ -1536,16 +1631,30 @@ bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, int& th
   return best >= 0;
 }
 
-bool BottleneckPair::supported(int prec, int impl, int c_phys, int h, int w, int batch_hint) {
-  int th, tw, lw;
-  size_t lds;
-  return impl == IMPL_MFMA && plan(prec, c_phys, h, w, batch_hint, th, tw, lw, lds);
+bool BottleneckPair::supported(int prec, int impl, int c_phys, int h, int w, int batch_hint, const Cv2* cv2) {
+  int th, tw, lw, t2 = 0, kg = 0, sg = 0;
+  size_t lds, extra = 0;
+  if (impl != IMPL_MFMA) return false;
+  if (cv2) {
+    if (!cv2_shape(prec, c_phys, *cv2, t2, kg, sg)) return false;
+    const int nt = ceil_div(c_phys, 16);
+    extra = (size_t)t2 * (sg + (prec == LP_FP16 ? (nt + 1) / 2 : nt)) * 1024;
+  }
+  return plan(prec, c_phys, h, w, batch_hint, extra, cv2 != nullptr, th, tw, lw, lds);
 }
 
 void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, const std::vector<float>& ba,
-                           const std::vector<float>& wb, const std::vector<float>& bb, int h, int w, int batch_hint) {
+                           const std::vector<float>& wb, const std::vector<float>& bb, int h, int w, int batch_hint, const Cv2* cv2) {
   prec = prec_; C = c_phys;
-  LP_CHECK(plan(prec, C, h, w, batch_hint, TH, TW, LW, lds_bytes), LP_ERR_GRAPH, "bottleneck %d ch on %dx%d: no fused plan", C, h, w);
+  const int G = prec == LP_FP16 ? 8 : 4;
+  const int nt = ceil_div(C, 16);
+  const int SR = prec == LP_FP16 ? (nt + 1) / 2 : nt;
+  size_t extra = 0;
+  if (cv2) {
+    LP_CHECK(cv2_shape(prec, C, *cv2, T2, kg, sg), LP_ERR_GRAPH, "bottleneck %s: cv2 tail shape unsupported", name.c_str());
+    extra = (size_t)T2 * (sg + SR) * 1024;
+  }
+  LP_CHECK(plan(prec, C, h, w, batch_hint, extra, cv2 != nullptr, TH, TW, LW, lds_bytes), LP_ERR_GRAPH, "bottleneck %d ch on %dx%d: no fused plan", C, h, w);
   a.name = name; b.name = name;
   a.build(prec, IMPL_MFMA, 3, 1, C, C, ACT_SILU, wa, ba, h, w, batch_hint, true, true);
   b.build(prec, IMPL_MFMA, 3, 1, C, C, ACT_SILU, wb, bb, h, w, batch_hint, true, true);
@@ -1557,34 +1666,84 @@ void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, 
   };
   rcp_cg = rcp16(CG, 128);
   rcp_ps = rcp16(PS / 16, 512);
-  rcp_w1 = rcp16(TW + 2, 512);
-  rcp_tw = rcp16(TW, 512);
+  rcp_w1 = rcp16(TW + 2, 1024);
+  rcp_tw = rcp16(TW, 1024);
   LP_CHECK((TH + 2) * (TW + 2) <= 12 * 4 * 16 && TH * TW <= 10 * 4 * 16, LP_ERR_STATE, "bottleneck tile exceeds the kernel's pixel-tile budget");
+  if (cv2) {
+    // cv2 fragments [T2][sg + SR][lane][G]: K steps 0..sg-1 walk the stored concat channels (group q = 4s+g), the
+    // last SR steps the channels this lane's accumulators hold (same mapping as ConvLayer::attach_tail)
+    C3 = cv2->c3; act3 = cv2->act;
+    const int ccat = cv2->cat_global + C, ST = sg + SR;
+    std::vector<uint8_t> buf((size_t)T2 * ST * 64 * 16, 0);
+    for (int t = 0; t < T2; ++t)
+      for (int s = 0; s < ST; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int g = lane >> 4, m = lane & 15, gm = m >> 2, r = m & 3;
+          const int oc = gm * 4 * T2 + t * 4 + r;
+          if (oc >= C3) continue;
+          for (int j = 0; j < G; ++j) {
+            int ch;
+            if (s < sg) {
+              const int q = 4 * s + g;
+              if (q >= kg) continue;
+              ch = q * G + j;
+            } else {
+              const int s2 = s - sg;
+              if (G * s2 + j >= 4 * NT) continue;
+              const int mid = g * 4 * NT + G * s2 + j;
+              if (mid >= C) continue;
+              ch = cv2->cat_global + mid;
+            }
+            put_elem(buf, ((size_t)(t * ST + s) * 64 + lane) * G + j, prec, (*cv2->w)[(size_t)oc * ccat + ch]);
+          }
+        }
+    d_w3.alloc(buf.size());
+    LP_HIP(hipMemcpy(d_w3.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    std::vector<float> b3(round_up(C3, 64) + 64, 0.f);
+    for (int c = 0; c < C3 && cv2->bias && c < (int)cv2->bias->size(); ++c) b3[c] = (*cv2->bias)[c];
+    d_b3.alloc(b3.size() * 4);
+    LP_HIP(hipMemcpy(d_b3.p, b3.data(), b3.size() * 4, hipMemcpyHostToDevice));
+  }
 }
 
-template <typename T, int NT, int P1, int P2>
+template <typename T, int NT, int P1, int P2, int T2>
 static void launch_bneck_(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   constexpr bool SEP = NT == 1;
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP>),
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
-  hipLaunchKernelGGL((bottleneck_mfma_kernel<T, NT, P1, P2, SEP>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2>), grid, dim3(256), lds, st, a);
+}
+
+// cv2 tails exist for NT = 1 with T2 in {1, 2} and NT = 2 with T2 in {2, 4} (BottleneckPair::cv2_shape)
+template <typename T, int NT, int P1, int P2>
+static void launch_bneck_t(const BneckArgs& a, int t2, dim3 grid, size_t lds, hipStream_t st) {
+  if (t2 == 0) return launch_bneck_<T, NT, P1, P2, 0>(a, grid, lds, st);
+  if constexpr (NT == 1 && P1 != 3) {
+    if (t2 == 1) return launch_bneck_<T, NT, P1, P2, 1>(a, grid, lds, st);
+    if (t2 == 2) return launch_bneck_<T, NT, P1, P2, 2>(a, grid, lds, st);
+  }
+  if constexpr (NT == 2 && P1 != 3) {
+    if (t2 == 2) return launch_bneck_<T, NT, P1, P2, 2>(a, grid, lds, st);
+    if (t2 == 4) return launch_bneck_<T, NT, P1, P2, 4>(a, grid, lds, st);
+  }
+  throw Error(LP_ERR_STATE, "bottleneck: no kernel for this cv2 tail");
 }
 
 // pixel tiles per wave = ceil(ceil(region / 16) / 4 waves) for the tile shapes of plan()
 template <typename T, int NT>
-static void launch_bneck(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  if (a.TH == 16 && a.TW == 40) {                                                   // 18x42 = 48 tiles, 16x40 = 40
-    if constexpr (NT == 1) launch_bneck_<T, 1, 12, 10>(a, grid, lds, st);
+static void launch_bneck(const BneckArgs& a, int t2, dim3 grid, size_t lds, hipStream_t st) {
+  if (a.TH == 16 && a.TW == 40) {                                                        // 18x42 = 48 tiles, 16x40 = 40
+    if constexpr (NT == 1) launch_bneck_t<T, 1, 12, 10>(a, t2, grid, lds, st);
     else throw Error(LP_ERR_STATE, "bottleneck: 16x40 tiles need NT == 1");
-  } else if (a.TH == 8 && a.TW == 40) launch_bneck_<T, NT, 7, 5>(a, grid, lds, st);  // 10x42 = 27 tiles, 8x40 = 20
-  else if (a.TH == 8 && a.TW == 20) launch_bneck_<T, NT, 4, 3>(a, grid, lds, st);    // 10x22 = 14 tiles, 8x20 = 10
-  else if (a.TH == 4 && a.TW == 20) launch_bneck_<T, NT, 3, 2>(a, grid, lds, st);    //  6x22 =  9 tiles, 4x20 = 5
+  } else if (a.TH == 8 && a.TW == 40) launch_bneck_t<T, NT, 7, 5>(a, t2, grid, lds, st);  // 10x42 = 27 tiles, 8x40 = 20
+  else if (a.TH == 8 && a.TW == 20) launch_bneck_t<T, NT, 4, 3>(a, t2, grid, lds, st);    // 10x22 = 14 tiles, 8x20 = 10
+  else if (a.TH == 4 && a.TW == 20) launch_bneck_t<T, NT, 3, 2>(a, t2, grid, lds, st);    //  6x22 =  9 tiles, 4x20 = 5
   else throw Error(LP_ERR_STATE, "bottleneck: no kernel for this tile shape");
 }
 
-void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t st) const {
-  LP_CHECK(in.C == C && out.C >= C && in.H == out.H && in.W == out.W, LP_ERR_STATE, "bottleneck: view mismatch");
+void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t st, const View* cat) const {
+  LP_CHECK(in.C == C && in.H == out.H && in.W == out.W, LP_ERR_STATE, "bottleneck: view mismatch");
   LP_CHECK((in.pitch % 8) == 0 && (out.pitch % 4) == 0, LP_ERR_STATE, "unaligned channel pitch");
   BneckArgs k;
   memset(&k, 0, sizeof(k));
@@ -1592,6 +1751,14 @@ void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t 
   k.zeros = a.d_bias.as<float>() + round_up(C, 64);
   k.N = N; k.H = in.H; k.W = in.W; k.C = C; k.in_pitch = in.pitch; k.out_pitch = out.pitch;
   k.TH = TH; k.TW = TW; k.tiles_x = ceil_div(in.W, TW); k.LW = LW; k.PS = PS; k.CG = CG; k.steps = steps;
+  if (T2) {
+    LP_CHECK(cat && cat->base && cat->H == in.H && cat->W == in.W && out.C >= C3, LP_ERR_STATE, "bottleneck+cv2: concat view missing or output too narrow");
+    k.w3 = d_w3.p; k.b3 = d_b3.as<float>(); k.cat = cat->base; k.cat_pitch = cat->pitch;
+    k.out3 = out.base; k.out3_pitch = out.pitch; k.C3 = C3; k.act3 = act3; k.kg = kg; k.sg = sg;
+    k.out = nullptr;
+  } else {
+    LP_CHECK(out.C >= C, LP_ERR_STATE, "bottleneck: output view too narrow");
+  }
   const int tiles_y = ceil_div(in.H, TH);
   const unsigned m = (65536u + k.tiles_x - 1) / k.tiles_x;
   for (int x = 0; x < k.tiles_x * tiles_y; ++x) LP_CHECK((int)((x * m) >> 16) == x / k.tiles_x, LP_ERR_STATE, "tile reciprocal not exact");
@@ -1602,10 +1769,10 @@ void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t 
   if (tile_major) grid = dim3(k.tiles_x * tiles_y, N);
   const bool f16 = prec == LP_FP16;
   switch (NT) {
-    case 1: if (f16) launch_bneck<half_t, 1>(k, grid, lds_bytes, st); else launch_bneck<float, 1>(k, grid, lds_bytes, st); break;
-    case 2: if (f16) launch_bneck<half_t, 2>(k, grid, lds_bytes, st); else launch_bneck<float, 2>(k, grid, lds_bytes, st); break;
-    case 3: if (f16) launch_bneck<half_t, 3>(k, grid, lds_bytes, st); else launch_bneck<float, 3>(k, grid, lds_bytes, st); break;
-    default: if (f16) launch_bneck<half_t, 4>(k, grid, lds_bytes, st); else launch_bneck<float, 4>(k, grid, lds_bytes, st); break;
+    case 1: if (f16) launch_bneck<half_t, 1>(k, T2, grid, lds_bytes, st); else launch_bneck<float, 1>(k, T2, grid, lds_bytes, st); break;
+    case 2: if (f16) launch_bneck<half_t, 2>(k, T2, grid, lds_bytes, st); else launch_bneck<float, 2>(k, T2, grid, lds_bytes, st); break;
+    case 3: if (f16) launch_bneck<half_t, 3>(k, T2, grid, lds_bytes, st); else launch_bneck<float, 3>(k, T2, grid, lds_bytes, st); break;
+    default: if (f16) launch_bneck<half_t, 4>(k, T2, grid, lds_bytes, st); else launch_bneck<float, 4>(k, T2, grid, lds_bytes, st); break;
   }
   LP_HIP(hipGetLastError());
 }

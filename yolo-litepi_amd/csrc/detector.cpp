@@ -426,7 +426,49 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
             const Tensor& TI = tensors_[tin];
             if (other == tin && TI.Cp == tensors_[tfinal].Cp && TI.Cp == tensors_[tout].Cp &&
                 BottleneckPair::supported(prec_, impl_, TI.Cp, TI.H, TI.W, maxB_)) {
-              ensure_buffer(tfinal);
+              // cv2 fusion: y_last is the last segment of a zero-copy Concat whose only consumer is a 1x1 conv
+              // (C2f.cv2): that conv runs in the same launch, y_last stays in registers (LITEPI_NO_CV2FUSE=1: off)
+              static const bool no_cv2 = getenv("LITEPI_NO_CV2FUSE") != nullptr;
+              int jc = -1, tcat = -1;
+              BottleneckPair::Cv2 cv2;
+              std::vector<float> w3, b3;
+              {
+                auto& cf = canon_consumers[tensors_[tfinal].name];
+                if (!no_cv2 && cf.size() == 1 && L[cf[0]].type == "Concat" && canon(L[cf[0]].inputs.back()) == tensors_[tfinal].name) {
+                  const int cc = cf[0];
+                  bool copied = false;
+                  for (auto& cj : copies) copied = copied || cj.layer == cc;
+                  const int tO = get(L[cc].outputs[0]);
+                  auto& c2 = canon_consumers[tensors_[tO].name];
+                  if (!copied && c2.size() == 1 && L[c2[0]].type == "Convolution" && !is_tail(c2[0]) && !done[c2[0]] &&
+                      L[c2[0]].ipar(1, 1) == 1 && L[c2[0]].ipar(3, 1) == 1 && !fuse_up.count(c2[0]) &&
+                      tensors_[tfinal].buf == tensors_[tO].buf && tensors_[tO].parent < 0) {
+                    const NcnnLayer& l3 = L[c2[0]];
+                    const int t3 = cinfo[c2[0]].tout;
+                    bool feeds_add = false;
+                    for (int c : canon_consumers[tensors_[t3].name]) feeds_add = feeds_add || L[c].type == "BinaryOp";
+                    const Tensor& TO = tensors_[tO];
+                    const int glob = tensors_[tfinal].off - TO.off;
+                    if (!feeds_add && glob > 0 && glob + TI.Cp == TO.Cp && tensors_[t3].segs.size() == 1) {
+                      cv2.cat_global = glob; cv2.c3 = tensors_[t3].Cp; cv2.act = fused_act[c2[0]];
+                      if (BottleneckPair::supported(prec_, impl_, TI.Cp, TI.H, TI.W, maxB_, &cv2)) {
+                        jc = c2[0]; tcat = tO;
+                        const int cin3 = l3.in_ch, cout3 = l3.ipar(0);
+                        w3.assign((size_t)cv2.c3 * TO.Cp, 0.f);
+                        b3.assign(cv2.c3, 0.f);
+                        for (int co = 0; co < cout3; ++co) {
+                          const int pc = tensors_[t3].phys(co);
+                          for (int ci = 0; ci < cin3; ++ci) w3[(size_t)pc * TO.Cp + TO.phys(ci)] = l3.weight[(size_t)co * cin3 + ci];
+                          if (!l3.bias.empty()) b3[pc] = l3.bias[co];
+                        }
+                        cv2.w = &w3; cv2.bias = &b3;
+                      }
+                    }
+                  }
+                }
+              }
+              const int tdst = jc >= 0 ? cinfo[jc].tout : tfinal;
+              ensure_buffer(tdst);
               const Tensor& TM = tensors_[tout];
               const Tensor& TF = tensors_[tfinal];
               auto pack = [&](const NcnnLayer& lc, const Tensor& A, const Tensor& O, std::vector<float>& w, std::vector<float>& b) {
@@ -440,19 +482,27 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
                 }
               };
               std::vector<float> wa, ba, wb, bb;
-              pack(l, TI, TM, wa, ba);
+              pack(l, tensors_[tin], TM, wa, ba);
               pack(lb, TM, TF, wb, bb);
               bnecks_.emplace_back(new BottleneckPair());
-              bnecks_.back()->name = l.name + "+" + lb.name;
-              bnecks_.back()->build(prec_, TI.Cp, wa, ba, wb, bb, TI.H, TI.W, maxB_);
-              const double macs = 2.0 * 9.0 * Cin * Cout * TI.H * TI.W;
+              bnecks_.back()->name = l.name + "+" + lb.name + (jc >= 0 ? "+" + L[jc].name : std::string());
+              bnecks_.back()->build(prec_, tensors_[tin].Cp, wa, ba, wb, bb, tensors_[tin].H, tensors_[tin].W, maxB_, jc >= 0 ? &cv2 : nullptr);
+              double macs = 2.0 * 9.0 * Cin * Cout * tensors_[tin].H * tensors_[tin].W;
+              if (jc >= 0) macs += (double)L[jc].in_ch * L[jc].ipar(0) * tensors_[tin].H * tensors_[tin].W;
               macs_ += macs;
               DetOp op;
               op.kind = DetOp::BNECK; op.layer = bnecks_.back()->name; op.conv = (int)bnecks_.size() - 1;
               op.flops = 2.0 * macs;
-              op.bytes = 2.0 * TI.C * TI.H * TI.W * esd + (double)(l.weight.size() + lb.weight.size()) * esd;
-              op.in = tin; op.out = tfinal;
+              {
+                const Tensor& T0 = tensors_[tin];
+                op.bytes = 2.0 * T0.C * T0.H * T0.W * esd + (double)(l.weight.size() + lb.weight.size()) * esd;
+                if (jc >= 0)
+                  op.bytes = ((double)(tensors_[tcat].C - T0.C) + T0.C + tensors_[tdst].C) * T0.H * T0.W * esd +
+                             (double)(l.weight.size() + lb.weight.size() + L[jc].weight.size()) * esd;
+              }
+              op.in = tin; op.out = tdst; op.in2 = tcat;
               ops_.push_back(op);
+              if (jc >= 0) done[jc] = 1;
               done[j] = 1; done[csa[0]] = 1;
               continue;
             }
@@ -687,7 +737,12 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         break;
       }
       case DetOp::BNECK:
-        bnecks_[op.conv]->launch(view(op.in), view(op.out), B, st);
+        if (op.in2 >= 0) {
+          const View catv = view(op.in2);
+          bnecks_[op.conv]->launch(view(op.in), view(op.out), B, st, &catv);
+        } else {
+          bnecks_[op.conv]->launch(view(op.in), view(op.out), B, st);
+        }
         kname = std::string("bottleneck3x3x2") + sfx;
         break;
       case DetOp::UPSAMPLE:
