@@ -440,6 +440,65 @@ def test_pipeline_fp16_close_to_oracle(tmp_path):
         assert len([r for r in res if r["det_conf"] > 0.27]) <= len(exp) + 1
 
 
+def test_config4_large_images_map_vs_cpu(tmp_path):
+    """configs[4]: 2048x2048 inputs, letterboxed to 640 on the device (r = 0.3125), fp16.  There are no labels here, so the
+    CPU fp32 path's confident detections serve as pseudo ground truth and the HIP predictions are scored with the port of
+    the reference's evaluate_predictions (e2e.py:656-824).  Bounds: every confident CPU box is found (IoU >= 0.5), and
+    mAP@0.5 -- which also needs the classifier arg-max to agree -- stays high."""
+    from litepi import HybridPipeline, ncnn_export
+    from litepi.e2e import evaluate_predictions
+    from oracle import ncnn_ref, pipeline_ref, shufflenet_ref as S
+    p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    ncnn_export.export_detector(p, b, "v1", seed=77, cls_bias=0.0)
+    rng = np.random.default_rng(2)
+    imgs = []
+    for _ in range(3):  # low-frequency noise + pasted 40-80 px discs (BASELINE.json configs[4] recipe)
+        low = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+        img = np.repeat(np.repeat(low, 32, axis=0), 32, axis=1).copy()
+        yy, xx = np.mgrid[0:2048, 0:2048]
+        for _d in range(6):
+            cy, cx, rad = rng.integers(100, 1948), rng.integers(100, 1948), rng.integers(20, 41)
+            img[(yy - cy) ** 2 + (xx - cx) ** 2 <= rad * rad] = rng.integers(0, 256, 3, dtype=np.uint8)
+        imgs.append(img)
+    layers = ncnn_ref.load_model(p, b)
+    sd = S.seeded_state_dict(91)
+    cpu = pipeline_ref.CpuPipeline(layers, S.build(91, sd))
+    scores = np.concatenate([cpu.detect_raw(im)[0][4].astype(np.float64) for im in imgs])
+    s = np.sort(scores)[::-1]
+    k = 60 * len(imgs)  # candidates cluster on a random-weight detector: NMS keeps a fraction of them
+    logit = 0.5 * (np.log(s[k - 1] / (1 - s[k - 1])) + np.log(s[k] / (1 - s[k])))
+    ncnn_export.shift_cls_bias(p, b, float(np.log(0.25 / 0.75) - logit))
+    cpu = pipeline_ref.CpuPipeline(ncnn_ref.load_model(p, b), S.build(91, sd))
+    cls_path = str(tmp_path / "cls.pth")
+    torch.save(sd, cls_path)
+    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=3, max_det=300)
+    try:
+        outs = pipe.run_batch(imgs, 0.25, 0.45, 50)
+    finally:
+        pipe.engine.close()
+    all_preds, all_gts, found, total = [], [], 0, 0
+    for im, (res, _met) in zip(imgs, outs):
+        exp, _ = cpu.run(im, 0.25, 0.45, 50)
+        strong = [x for x in exp if x["det_conf"] > 0.27 and x["cls_class"] >= 0]
+        all_gts.append([(x["cls_class"],) + tuple(x["bbox"]) for x in strong])
+        all_preds.append([{"bbox": r["bbox"], "conf": r["det_conf"], "cls_class": r["cls_class"]} for r in res])
+        for x in strong:
+            bx = np.array(x["bbox"], np.float64)
+            best = 0.0
+            for r in res:
+                br = np.array(r["bbox"], np.float64)
+                iw = max(0.0, min(bx[2], br[2]) - max(bx[0], br[0])); ih = max(0.0, min(bx[3], br[3]) - max(bx[1], br[1]))
+                u = (bx[2] - bx[0]) * (bx[3] - bx[1]) + (br[2] - br[0]) * (br[3] - br[1]) - iw * ih
+                best = max(best, iw * ih / u if u > 0 else 0.0)
+            found += best >= 0.5
+            total += 1
+    assert total >= 6, "calibration produced too few confident detections"
+    m = evaluate_predictions(all_preds, all_gts, 91)
+    print(f"config4: {found}/{total} confident CPU boxes found; mAP50 {m['mAP50']:.3f} mAP50-95 {m['mAP50_95']:.3f}")
+    assert found >= total - 1
+    assert m["mAP50"] >= 0.6
+
+
 def test_empty_and_error_behaviour(synth_models, tmp_path):
     """Reference quirks: load failure -> RuntimeError (e2e.py:213-216); no detections -> float64
     empties (e2e.py:264); empty classifier batch -> two empty arrays (e2e.py:380-381)."""
