@@ -117,7 +117,7 @@ struct ConvArgs {
   const void* up;
   int up_pitch, up_cg;
   int tile_major;              // 0: grid = (image, tile, split) (XCD-aware, default); 1: (tile, image, split)
-  unsigned rcp_tx, rcp_cg, rcp_ps;  // 3x3 kernel: 16-bit reciprocals of tiles_x, CGc, PS/16 (set by launch)
+  unsigned rcp_tx, rcp_cg, rcp_ps, rcp_pcs;  // 3x3 kernel: 16-bit reciprocals of tiles_x, CGc, PS/16, pieces per tile row
   const void* zeros;           // >= 16 zero bytes (source of the 3x3 kernel's padding slots)
   unsigned long long* stamps;  // diagnostic only (lp_test_conv + LITEPI_STAMPS): 16 clock stamps per workgroup
 };
@@ -134,7 +134,7 @@ struct BneckArgs {
   int N, H, W, C;   // C: physical channels (in == mid == out)
   int in_pitch, out_pitch;
   int TH, TW, tiles_x, LW, PS, CG, steps;
-  unsigned rcp_tx, rcp_cg, rcp_ps, rcp_w1, rcp_tw;
+  unsigned rcp_tx, rcp_cg, rcp_ps, rcp_pcs, rcp_w1, rcp_tw;
   int tile_major;
   // fused C2f.cv2 (1x1 over the concat [y0, y1, .., y_last]): y_last comes from the accumulators, the other
   // segments are read from the concat buffer `cat` (channels [0, kg*G)); `out` is not written then

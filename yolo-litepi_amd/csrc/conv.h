@@ -22,7 +22,7 @@ struct ConvLayer {
   // MFMA tiling
   int NT = 1, nsplits = 1, CK = 0, CGc = 0, nchunks = 1, steps = 0, LW = 0, PS = 0, bwh = 2, bww = 2;
   size_t lds_bytes = 0;
-  unsigned rcp_cg = 0, rcp_ps = 0;  // 16-bit reciprocals of CGc and PS/16 for the 3x3 kernel's prologue
+  unsigned rcp_cg = 0, rcp_ps = 0, rcp_pcs = 0;  // 16-bit reciprocals of CGc, PS/16 and pieces per LDS tile row (3x3 kernel)
   bool direct = false;  // 3x3 stride-2: gather B fragments from global memory (no LDS input tile)
   DevBuf d_w, d_bias;
   // fused 1x1 tail conv (second GEMM in the epilogue): 0 = none, else its 16-channel output tiles
@@ -50,7 +50,7 @@ struct ConvLayer {
 struct BottleneckPair {
   ConvLayer a, b;
   int prec = LP_FP16, C = 0, NT = 1, TH = 8, TW = 40, LW = 0, PS = 0, CG = 0, steps = 0;
-  unsigned rcp_cg = 0, rcp_ps = 0, rcp_w1 = 0, rcp_tw = 0;
+  unsigned rcp_cg = 0, rcp_ps = 0, rcp_pcs = 0, rcp_w1 = 0, rcp_tw = 0;
   size_t lds_bytes = 0;
   std::string name;
   // optional fused C2f.cv2 (1x1 over concat[stored segments .., y_last]); y_last = this bottleneck's output

@@ -305,7 +305,6 @@ template <typename T, int NT, int STRIDE, int T2 = 0>
 __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(T) == 4)) ? 2 : 3))) void conv3x3_mfma_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
-  constexpr int MAXP = 8;  // 1 KiB pieces per LDS tile row (host checks)
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int g = lane >> 4, col = lane & 15;
@@ -345,22 +344,13 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
     pbase[p] = ((ly * STRIDE) * LW + lx * STRIDE) * PS;
   }
   // Staging map.  The LDS image of a tile row is RS consecutive 16-byte slots = pixel pitch x LW, filled by
-  // 1 KiB LDS-DMA pieces (64 lanes x 16 B, destination lane-linear).  Per piece this lane's slot is a fixed
-  // (column, channel group): its source byte offset inside the image row is computed once; slots that are
-  // pitch padding, beyond the tile, or outside the image read a 16-byte zero line instead (= zero padding).
+  // 1 KiB LDS-DMA pieces (64 lanes x 16 B, destination lane-linear).  The (row, piece) items of a chunk are dealt
+  // round-robin to the waves; a lane's slot in a piece is a (column, channel group): slots that are pitch padding,
+  // beyond the tile, or outside the image read a 16-byte zero line instead (= zero padding).  ~20 instructions per
+  // item, wave-uniform parts on the SALU (VALU issue slots are the scarce resource of the narrow layers).
   const int pcs = (RS + 63) >> 6;
   const int PSs = PS >> 4;
-  int soff[MAXP];
-#pragma unroll
-  for (int pc = 0; pc < MAXP; ++pc) {
-    soff[pc] = -2;  // no slot: lane stays idle for this piece
-    if (pc < pcs) {
-      const int sl = pc * 64 + lane;
-      const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
-      const int gx = ix0 + ix;
-      if (sl < RS) soff[pc] = (ix < IW && cgs < CGc && gx >= 0 && gx < a.Win) ? (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : -1;
-    }
-  }
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const char* zeros = reinterpret_cast<const char*>(a.zeros);
   const char* in_b = reinterpret_cast<const char*>(a.in);
 
@@ -368,20 +358,20 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
   auto issue = [&](int c, int b) {
     char* buf = smem + 512 + b * bufbytes;
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpk) + ((size_t)(ns * a.nchunks + c) * Sc * NT) * 64;
-    for (int p = wave; p < Sc * NT; p += nw) LP_GLDS16(wsrc + p * 64 + lane, buf + p * 1024);
+    for (int p = wave_s; p < Sc * NT; p += nw) LP_GLDS16(wsrc + p * 64 + lane, buf + p * 1024);
     char* lin = buf + wbytes;
     const int cbase = c * a.CK;
-    for (int iy = wave; iy < IH; iy += nw) {
+    const int nitems = IH * pcs;
+    for (int it = wave_s; it < nitems; it += nw) {
+      const int iy = (int)(((unsigned)it * a.rcp_pcs) >> 16), pc = it - iy * pcs;
       const int gy = iy0 + iy;
-      const bool rowok = gy >= 0 && gy < a.Hin;
       const char* rowp = in_b + (((long)(n * a.Hin + gy) * a.Win + ix0) * a.in_pitch + cbase) * (long)sizeof(T);
-#pragma unroll
-      for (int pc = 0; pc < MAXP; ++pc) {
-        if (pc < pcs && soff[pc] != -2) {
-          const char* src = (rowok && soff[pc] >= 0) ? rowp + soff[pc] : zeros;
-          LP_GLDS16(src, lin + (iy * RS + pc * 64) * 16);
-        }
-      }
+      const int sl = pc * 64 + lane;
+      const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
+      const int gx = ix0 + ix;
+      const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && ix < IW && cgs < CGc;
+      const char* src = ok ? rowp + (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : zeros;
+      if (sl < RS) LP_GLDS16(src, lin + (iy * RS + pc * 64) * 16);
     }
   };
 
@@ -478,7 +468,6 @@ template <typename T, int NT, int P1, int P2, bool SEP, int T2 = 0>
 __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel(const BneckArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
-  constexpr int MAXP = 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, col = lane & 15;
   const int tile_id = a.tile_major ? blockIdx.x : blockIdx.y;
@@ -514,34 +503,24 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
   const int iy0 = oy0 - 2, ix0 = ox0 - 2;
   const char* zeros = reinterpret_cast<const char*>(a.zeros);
   {
-    for (int p = wave; p < 2 * S * NT; p += 4) {
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    for (int p = wave_s; p < 2 * S * NT; p += 4) {
       const u32x4* src = p < S * NT ? reinterpret_cast<const u32x4*>(a.w1) + p * 64 : reinterpret_cast<const u32x4*>(a.w2) + (p - S * NT) * 64;
       LP_GLDS16(src + lane, smem + 512 + p * 1024);
     }
-    for (int p = wave; p < w3frags; p += 4) LP_GLDS16(reinterpret_cast<const u32x4*>(a.w3) + p * 64 + lane, smem + 512 + 2 * wbytes + p * 1024);
-    int soff[MAXP];
-#pragma unroll
-    for (int pc = 0; pc < MAXP; ++pc) {
-      soff[pc] = -2;
-      if (pc < pcs) {
-        const int sl = pc * 64 + lane;
-        const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
-        const int gx = ix0 + ix;
-        if (sl < RS) soff[pc] = (ix < IW && cgs < CG && gx >= 0 && gx < a.W) ? (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : -1;
-      }
-    }
+    for (int p = wave_s; p < w3frags; p += 4) LP_GLDS16(reinterpret_cast<const u32x4*>(a.w3) + p * 64 + lane, smem + 512 + 2 * wbytes + p * 1024);
     const char* in_b = reinterpret_cast<const char*>(a.in);
-    for (int iy = wave; iy < IH; iy += 4) {
+    const int nitems = IH * pcs;
+    for (int it = wave_s; it < nitems; it += 4) {
+      const int iy = (int)(((unsigned)it * a.rcp_pcs) >> 16), pc = it - iy * pcs;
       const int gy = iy0 + iy;
-      const bool rowok = gy >= 0 && gy < a.H;
       const char* rowp = in_b + ((long)(n * a.H + gy) * a.W + ix0) * a.in_pitch * (long)sizeof(T);
-#pragma unroll
-      for (int pc = 0; pc < MAXP; ++pc) {
-        if (pc < pcs && soff[pc] != -2) {
-          const char* src = (rowok && soff[pc] >= 0) ? rowp + soff[pc] : zeros;
-          LP_GLDS16(src, tile + (iy * RS + pc * 64) * 16);
-        }
-      }
+      const int sl = pc * 64 + lane;
+      const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
+      const int gx = ix0 + ix;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ix < IW && cgs < CG;
+      const char* src = ok ? rowp + (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : zeros;
+      if (sl < RS) LP_GLDS16(src, tile + (iy * RS + pc * 64) * 16);
     }
   }
   floatx4 bias1[NT], bias2[NT];
@@ -668,10 +647,13 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
       const bool valid = p < R2 && gy < a.H && gx < a.W;
       const long pix = valid ? (long)(n * a.H + gy) * a.W + gx : 0;
       typename Tr<T>::frag bg[SGMAX];
+      const T* catp = reinterpret_cast<const T*>(a.cat) + pix * a.cat_pitch + g * G;
 #pragma unroll
       for (int s = 0; s < SGMAX; ++s) {
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (valid && 4 * s + g < a.kg) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.cat) + pix * a.cat_pitch + (4 * s + g) * G);
+        if (s < a.sg) {  // wave-uniform: unused steps cost one scalar branch
+          if (valid && 4 * s + g < a.kg) v = *reinterpret_cast<const u32x4*>(catp + 4 * s * G);
+        }
         bg[s] = as_frag<T>(v);
       }
       // y_last: activation, round to T, add the shortcut, round again (= store_lane_at), kept as the register B operand
@@ -1333,6 +1315,7 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
     };
     rcp_cg = rcp16(CGc, 128);
     rcp_ps = rcp16(PS / 16, 512);
+    rcp_pcs = rcp16(ceil_div(LW * (PS / 16), 64), 1024);
     LP_CHECK(lds_bytes <= 160 * 1024, LP_ERR_GRAPH, "conv3x3 tile does not fit LDS (%zu B)", lds_bytes);
   } else {
     NT = pick_nt(ceil_div((long)B * hout * wout, 256));
@@ -1542,7 +1525,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
       return m;
     };
     a.rcp_tx = rcp16(a.tiles_x, a.tiles_x * a.tiles_y);
-    a.rcp_cg = rcp_cg; a.rcp_ps = rcp_ps;  // checked once in build()
+    a.rcp_cg = rcp_cg; a.rcp_ps = rcp_ps; a.rcp_pcs = rcp_pcs;  // checked once in build()
 #define LP_L3(TT)                                                                  \
   switch (NT) {                                                                    \
     case 1: launch3x3<TT, 1>(a, stride, grid, threads, lds_bytes, st); break;      \
@@ -1666,6 +1649,7 @@ void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, 
   };
   rcp_cg = rcp16(CG, 128);
   rcp_ps = rcp16(PS / 16, 512);
+  rcp_pcs = rcp16(ceil_div(LW * (PS / 16), 64), 1024);
   rcp_w1 = rcp16(TW + 2, 1024);
   rcp_tw = rcp16(TW, 1024);
   LP_CHECK((TH + 2) * (TW + 2) <= 12 * 4 * 16 && TH * TW <= 10 * 4 * 16, LP_ERR_STATE, "bottleneck tile exceeds the kernel's pixel-tile budget");
@@ -1762,7 +1746,7 @@ void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t 
   const int tiles_y = ceil_div(in.H, TH);
   const unsigned m = (65536u + k.tiles_x - 1) / k.tiles_x;
   for (int x = 0; x < k.tiles_x * tiles_y; ++x) LP_CHECK((int)((x * m) >> 16) == x / k.tiles_x, LP_ERR_STATE, "tile reciprocal not exact");
-  k.rcp_tx = m; k.rcp_cg = rcp_cg; k.rcp_ps = rcp_ps; k.rcp_w1 = rcp_w1; k.rcp_tw = rcp_tw;
+  k.rcp_tx = m; k.rcp_cg = rcp_cg; k.rcp_ps = rcp_ps; k.rcp_pcs = rcp_pcs; k.rcp_w1 = rcp_w1; k.rcp_tw = rcp_tw;
   static const bool tile_major = getenv("LITEPI_TILE_MAJOR") != nullptr;
   k.tile_major = tile_major;
   dim3 grid(N, k.tiles_x * tiles_y);
