@@ -84,18 +84,43 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0,
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = activate_ct<T, ACT>(v[i] + b[i]);
   if (EPI == EPI_SHUFFLE) {
-    // ShuffleNetV2 channel_shuffle(cat(x1, y), 2) fused into the store: logical output
-    // channel 2c = x1[c], 2c+1 = y[c]; each half of the output is padded to half_cp.
+    // ShuffleNetV2 channel_shuffle(cat(x1, y), 2) fused into the store: logical output channel 2c = x1[c],
+    // 2c+1 = y[c]; each half of the output is padded to half_cp.  This lane's 4 channels c..c+3 become the 8
+    // consecutive logical channels 2c..2c+7: one vector load of x1, then 4-byte (x1, y) pairs -- merged into one
+    // 16-byte store when the run stays inside one half and is 16-byte aligned (scalar 2-byte traffic made the
+    // stride-2 blocks' pointwise convs the slowest launches of the classifier).
     const T* x1 = reinterpret_cast<const T*>(a.x1) + pix * a.x1_pitch;
     T* o = reinterpret_cast<T*>(a.out) + pix * a.out_pitch;
+    if (ch0 + 4 <= a.half_c) {
+      const typename Tr<T>::quad xv = *reinterpret_cast<const typename Tr<T>::quad*>(x1 + ch0);
+      const int l0 = 2 * ch0;
+      const int p0 = l0 < a.half_c ? l0 : a.half_cp + (l0 - a.half_c);
+      const bool one_half = l0 + 8 <= a.half_c || l0 >= a.half_c;
+      if (sizeof(T) == 2 && one_half && (p0 & 7) == 0) {
+        half8 w;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = ch0 + i;
-      if (c < a.half_c) {
-        const int l = 2 * c;
-        const int phys = l < a.half_c ? l : a.half_cp + (l - a.half_c);
-        o[phys] = x1[c];
-        o[phys + 1] = (T)v[i];
+        for (int i = 0; i < 4; ++i) { w[2 * i] = (half_t)xv[i]; w[2 * i + 1] = (half_t)v[i]; }
+        *reinterpret_cast<half8*>(o + p0) = w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int l = l0 + 2 * i;
+          const int phys = l < a.half_c ? l : a.half_cp + (l - a.half_c);  // l is even and so is half_c: a pair never straddles
+          T pr[2] = {xv[i], (T)v[i]};
+          if (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(o + phys) = *reinterpret_cast<const uint32_t*>(pr);
+          else { o[phys] = pr[0]; o[phys + 1] = pr[1]; }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = ch0 + i;
+        if (c < a.half_c) {
+          const int l = 2 * c;
+          const int phys = l < a.half_c ? l : a.half_cp + (l - a.half_c);
+          o[phys] = x1[c];
+          o[phys + 1] = (T)v[i];
+        }
       }
     }
     return;
