@@ -232,6 +232,11 @@ def main():
             if fam:
                 roofline["traffic"] = fam["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same workload)"
+            with open(tfile) as fh:
+                fams = json.load(fh).get("families", {})
+            step_bytes = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in fams.values())
+            # whole-step view: every launch's PMC traffic over the measured step time (set below, once elapsed is known)
+            roofline["step_traffic_bytes"] = step_bytes
         roofline["launches_per_step"] = f["launches"]
         roofline["avg_launch_ms"] = f["ms"] / max(f["launches"], 1)
         roofline["algorithmic_per_step"] = f["flops"] if f["flops"] > 0 else f["bytes"]
@@ -251,6 +256,9 @@ def main():
         total_images = world * B * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         flop_img = 2.0 * eng.det_macs
+        if roofline is not None and roofline.get("step_traffic_bytes"):
+            roofline["step_hbm_gbs"] = roofline["step_traffic_bytes"] / (ms_per_step * 1e-3) / 1e9
+            roofline["step_hbm_frac"] = roofline["step_hbm_gbs"] / PEAK_HBM_GBS
         line = {
             "metric": "images/sec end-to-end (det+NMS+clf) 640x640 batch64",
             "value": total_images / elapsed,
