@@ -146,6 +146,19 @@ struct BneckArgs {
   int kg, sg;       // global K groups and their K steps (sr = register steps, fixed by NT)
 };
 
+// Fused network head: stem 3x3/s2 (uint8 -> 8 ch) + 3x3/s2 conv + its 1x1 tail (stem_block_kernel)
+struct StemBlockArgs {
+  const uint8_t* img;
+  const void* afrag;   // stem MFMA A fragments (StemLayer::d_afrag)
+  const float* sbias;  // stem bias
+  const void* w1;      // stride-2 conv fragments [3 steps][64 lanes][16 B] (K = 9 taps x 8 channels)
+  const float* b1;
+  const void* w2;      // 1x1 tail fragments (ConvLayer::d_w2)
+  const float* b2;
+  void* out;
+  int N, Hin, Win, H1, W1, H2, W2, out_pitch, C2, act2;
+};
+
 enum ConvImpl { IMPL_MFMA = 0, IMPL_NAIVE = 1 };
 enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 

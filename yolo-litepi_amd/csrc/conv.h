@@ -83,6 +83,9 @@ struct StemLayer {
   // w_bgr: fp32 [27][CO], row = (ky*3+kx)*3 + c with c in BGR order
   void build(int prec, int cout_phys, int act, const std::vector<float>& w_bgr, const std::vector<float>& bias);
   void launch(const uint8_t* img, int N, int Hin, int Win, const View& out, hipStream_t st) const;
+  // stem + the following stride-2 3x3 conv (+ its fused 1x1 tail) in one launch (stem_block_kernel); out = the tail's output
+  bool block_supported(const ConvLayer& c1) const;
+  void launch_block(const uint8_t* img, int N, int Hin, int Win, const ConvLayer& c1, const View& out, hipStream_t st) const;
 };
 
 }  // namespace lp

@@ -1186,6 +1186,123 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restric
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Network head in one launch (fp16, v1 widths): stem 3x3/s2 (uint8 BGR -> 8 ch, SiLU) -> 3x3/s2 conv (8 -> <=16 ch,
+// SiLU) -> its 1x1 tail (C2f.cv1).  The 320x320x8 stem map is the largest activation of the network and was written
+// and read back once per image (210 MB per 64-image step); here a workgroup computes the 17 x 65 stem pixels its
+// 8 x 32 output tile needs into LDS (stem_mfma_kernel's formulation; zero outside the map = the next conv's padding),
+// runs the stride-2 conv from there with static LDS offsets (the gather kernel spent its VALU on per-tap address and
+// bounds arithmetic) and finishes with tail_store.  Stem halo recompute: (17 x 65) / (16 x 64) = +8 %.
+// ------------------------------------------------------------------------------------
+#define SB_TH 8
+#define SB_TW 32
+#define SB_SH (2 * SB_TH + 1)       /* stem rows  */
+#define SB_SW (2 * SB_TW + 1)       /* stem cols  */
+#define SB_LW 66                    /* stem tile row pitch, pixels (16 B each) */
+#define SB_IR (2 * SB_SH + 1)       /* input rows */
+#define SB_ROWW 104                 /* dwords per staged input row: 3 + 131*3 bytes + the lanes' 3rd dword */
+#define SB_PAIRS ((SB_SW + 1) / 2)  /* pixel pairs per stem row */
+__global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) {
+  __shared__ uint32_t in_tile[SB_IR * SB_ROWW];
+  __shared__ __attribute__((aligned(16))) char st_tile[SB_SH * SB_LW * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int n = blockIdx.x, ox0 = blockIdx.y * SB_TW, oy0 = blockIdx.z * SB_TH;
+  // ---- 1. uint8 tile: input rows 4*oy0-3 .., bytes from (4*ox0-3)*3 (= 3 mod 4: tile byte 3 is that byte)
+  const int row_words = a.Win * 3 / 4;
+  const int w0 = (12 * ox0 - 9) >> 2;
+  const uint32_t* im = reinterpret_cast<const uint32_t*>(a.img + (long)n * a.Hin * a.Win * 3);
+  for (int i = tid; i < SB_IR * SB_ROWW; i += 256) {
+    const int r = i / SB_ROWW, c = i - r * SB_ROWW;
+    const int iy = 4 * oy0 - 3 + r, wi = w0 + c;
+    uint32_t v = 0u;
+    if (iy >= 0 && iy < a.Hin && wi >= 0 && wi < row_words) v = im[(long)iy * row_words + wi];
+    in_tile[i] = v;
+  }
+  const half8 af0 = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.afrag)[lane]);
+  const half8 af1 = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.afrag)[64 + lane]);
+  const int c0 = (g & 1) * 4;
+  const floatx4 sb4 = *reinterpret_cast<const floatx4*>(a.sbias + c0);
+  __syncthreads();
+  // ---- 2. stem on the matrix cores, two pixels per column (see stem_mfma_kernel); 17 x 33 pairs, 16 per MFMA tile
+  const half2v k1024 = {(half_t)1024.f, (half_t)1024.f};
+  constexpr int NPAIR = SB_SH * SB_PAIRS, NTILE = (NPAIR + 15) / 16;
+  for (int t = wave; t < NTILE; t += 4) {
+    int pi = t * 16 + col;
+    pi = pi < NPAIR ? pi : NPAIR - 1;
+    const int r = (pi * 1986) >> 16, pp = pi - r * SB_PAIRS;  // / 33 (exact below 2^11)
+    half8 bf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int q = 4 * s + g;
+      const int ky = q >> 1, h = q & 1;
+      const int bo = 3 + 12 * pp + 8 * h;
+      const uint32_t* rw = in_tile + (2 * r + (ky < 3 ? ky : 2)) * SB_ROWW + (bo >> 2);
+      const int sh = bo & 3;
+      const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
+      uint32_t wa = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      uint32_t wb = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      if (q >= 6) { wa = 0u; wb = 0u; }
+      const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04010400u);
+      const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04030402u);
+      const uint32_t p2 = __builtin_amdgcn_perm(0x64646464u, wb, 0x04010400u);
+      const uint32_t p3 = __builtin_amdgcn_perm(0x64646464u, wb, 0x04030402u);
+      const half2v h0 = __builtin_bit_cast(half2v, p0) - k1024, h1 = __builtin_bit_cast(half2v, p1) - k1024;
+      const half2v h2 = __builtin_bit_cast(half2v, p2) - k1024, h3 = __builtin_bit_cast(half2v, p3) - k1024;
+      bf[s] = half8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+    }
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0, bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1, bf[1], acc, 0, 0, 0);
+    const int c = 2 * pp + (g >> 1);
+    if (t * 16 + col < NPAIR && c < SB_SW) {
+      const int sy = 2 * oy0 - 1 + r, sx = 2 * ox0 - 1 + c;
+      const bool inside = sy >= 0 && sy < a.H1 && sx >= 0 && sx < a.W1;
+      half4 q4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q4[j] = inside ? (half_t)Tr<half_t>::silu(acc[j] + sb4[j]) : (half_t)0.f;
+      *reinterpret_cast<half4*>(st_tile + (r * SB_LW + c) * 16 + c0 * 2) = q4;
+    }
+  }
+  // ---- 3. stride-2 3x3 conv from the stem tile (K group = tap: 9 of 12 slots), then the 1x1 tail
+  half8 a1[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) a1[s] = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.w1)[s * 64 + lane]);
+  floatx4 bias1[1], bias2[1];
+  bias1[0] = *reinterpret_cast<const floatx4*>(a.b1 + g * 4);
+  half8 w2f[1][1];
+  ConvArgs a2;
+  a2.w2 = a.w2; a2.bias2 = a.b2;
+  tail_load<half_t, 1, 1>(a2, lane, g, w2f, bias2);
+  a2.out = a.out; a2.out_pitch = a.out_pitch; a2.Cout = a.C2; a2.act = a.act2; a2.res = nullptr; a2.res_pitch = 0;
+  int toff[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    int tap = 4 * s + g;
+    tap = tap > 8 ? 8 : tap;  // padded K slots: zero weights, any finite data
+    const int ky = (tap * 21846) >> 16, kx = tap - 3 * ky;
+    toff[s] = (ky * SB_LW + kx) * 16;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = wave * 4 + i;
+    const int oy = t >> 1, ox = (t & 1) * 16 + col;
+    const char* base = st_tile + ((2 * oy) * SB_LW + 2 * ox) * 16;
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s], __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(base + toff[s])), acc, 0, 0, 0);
+    const int gy = oy0 + oy, gx = ox0 + ox;
+    if (gy < a.H2 && gx < a.W2) {
+      const long pix = (long)(n * a.H2 + gy) * a.W2 + gx;
+      floatx4 v[1] = {acc};
+      tail_store<half_t, 1, 1, ACT_SILU>(a2, pix, g, v, bias1, w2f, bias2);
+    }
+  }
+}
+
 // ====================================================================================
 // Host side: weight packing and launch
 // ====================================================================================
@@ -1815,6 +1932,26 @@ void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<floa
     d_afrag.alloc(buf.size());
     LP_HIP(hipMemcpy(d_afrag.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
   }
+}
+
+
+bool StemLayer::block_supported(const ConvLayer& c1) const {
+  return prec == LP_FP16 && CO == 8 && d_afrag.p && c1.prec == LP_FP16 && c1.impl == IMPL_MFMA && c1.direct && c1.k == 3 && c1.stride == 2 &&
+         c1.Cin == 8 && c1.NT == 1 && c1.nsplits == 1 && c1.T2 == 1 && c1.act == ACT_SILU && c1.steps == 3;
+}
+
+void StemLayer::launch_block(const uint8_t* img, int N, int Hin, int Win, const ConvLayer& c1, const View& out, hipStream_t st) const {
+  LP_CHECK(block_supported(c1) && Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0, LP_ERR_STATE, "stem block: unsupported configuration");
+  StemBlockArgs a;
+  memset(&a, 0, sizeof(a));
+  a.img = img; a.afrag = d_afrag.p; a.sbias = d_bias.as<float>();
+  a.w1 = c1.d_w.p; a.b1 = c1.d_bias.as<float>(); a.w2 = c1.d_w2.p; a.b2 = c1.d_bias2.as<float>();
+  a.out = out.base; a.N = N; a.Hin = Hin; a.Win = Win; a.H1 = (Hin + 1) / 2; a.W1 = (Win + 1) / 2;
+  a.H2 = out.H; a.W2 = out.W; a.out_pitch = out.pitch; a.C2 = c1.Cout2; a.act2 = c1.act2;
+  LP_CHECK(a.H2 == (a.H1 + 1) / 2 && a.W2 == (a.W1 + 1) / 2 && out.C >= c1.Cout2, LP_ERR_STATE, "stem block: output view mismatch");
+  dim3 grid(N, ceil_div(a.W2, SB_TW), ceil_div(a.H2, SB_TH));
+  hipLaunchKernelGGL(stem_block_kernel, grid, dim3(256), 0, st, a);
+  LP_HIP(hipGetLastError());
 }
 
 void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& out, hipStream_t st) const {

@@ -660,6 +660,22 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     }
   }
 
+  // ---- stem block: stem + the stride-2 conv that is its only consumer (+ that conv's fused 1x1 tail) in one launch;
+  //      the 320x320 stem map is never stored (StemLayer::launch_block; LITEPI_NO_STEMBLOCK=1: off)
+  if (!getenv("LITEPI_NO_STEMBLOCK") && ops_.size() >= 2 && ops_[0].kind == DetOp::STEM && ops_[1].kind == DetOp::CONV &&
+      ops_[1].in == ops_[0].out && ops_[1].res < 0 && S_ % 4 == 0 &&
+      canon_consumers[tensors_[ops_[0].out].name].size() == 1 && stem_.block_supported(*convs_[ops_[1].conv])) {
+    const Tensor& TI = tensors_[ops_[0].in >= 0 ? ops_[0].in : input_tensor];
+    const Tensor& TO = tensors_[ops_[1].out];
+    ops_[0].kind = DetOp::STEMBLOCK;
+    ops_[0].conv = ops_[1].conv;
+    ops_[0].out = ops_[1].out;
+    ops_[0].layer += "+" + ops_[1].layer;
+    ops_[0].flops += ops_[1].flops;
+    ops_[0].bytes = 3.0 * TI.H * TI.W + (double)TO.C * TO.H * TO.W * esd;
+    ops_.erase(ops_.begin() + 1);
+  }
+
   // ---- Detect tail ---------------------------------------------------------------------------
   reg_max_ = 0;
   std::vector<float> dfl;
@@ -721,6 +737,10 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
       case DetOp::STEM:
         stem_.launch(imgs, B, S_, S_, view(op.out), st);
         kname = std::string("stem_conv") + sfx;
+        break;
+      case DetOp::STEMBLOCK:
+        stem_.launch_block(imgs, B, S_, S_, *convs_[op.conv], view(op.out), st);
+        kname = std::string("stem_block") + sfx;
         break;
       case DetOp::CONV: {
         const ConvLayer& c = *convs_[op.conv];

@@ -35,7 +35,7 @@ struct Tensor {
 struct Buffer { int Cp = 0, H = 0, W = 0; DevBuf mem; };
 
 struct DetOp {
-  enum Kind { STEM, CONV, BNECK, UPSAMPLE, SPPF, ADD, COPY } kind = CONV;
+  enum Kind { STEM, STEMBLOCK, CONV, BNECK, UPSAMPLE, SPPF, ADD, COPY } kind = CONV;
   int conv = -1;                 // index into convs (CONV) / bnecks (BNECK)
   int in = -1, in2 = -1, res = -1, out = -1, out2 = -1, out3 = -1;
   std::string layer;
