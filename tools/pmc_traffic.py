@@ -29,7 +29,7 @@ def family(name):
         return "conv1x1_mfma" + f16
     if "stem_mfma_kernel" in name or "stem_conv" in name:
         return "stem_conv_f16" if "stem_mfma" in name else "stem_conv" + f16
-    for key, fam in (("roi_resize_kernel", "roi_resize_pil"), ("shuffle_stage_kernel", "shuffle_stage_fused_f16"),
+    for key, fam in (("stem_block_kernel", "stem_block_f16"), ("roi_resize_kernel", "roi_resize_pil"), ("shuffle_stage_kernel", "shuffle_stage_fused_f16"),
                      ("cls_head_kernel", "cls_head_fused_f16"), ("nms_kernel", "nms"), ("roi_index_kernel", "roi_index")):
         if key in name:
             return fam
