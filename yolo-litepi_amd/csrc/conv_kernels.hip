@@ -13,6 +13,7 @@
 // those are 4 (x tiles) consecutive physical channels of one pixel -> vector stores.
 #include "common.h"
 #include "conv.h"
+#include <type_traits>
 
 namespace lp {
 
@@ -590,25 +591,35 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+  // (interior workgroups -- the conv_a region lies inside the map -- skip the per-pixel inside-the-image arithmetic:
+  //  a block-uniform branch around two copies of the loop)
+  auto write_mid = [&](auto interior_tag) {
+    constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
-  for (int i = 0; i < P1; ++i) {
-    const int p = (wave + 4 * i) * 16 + col;
-    if (wave + 4 * i < n1 && p < R1) {
-      const int py = pk1[i] >> 16, px = pk1[i] & 0xffff;
-      const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
-      const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      T* dst = reinterpret_cast<T*>(tile2 + (py * LW + px) * PS) + g * 4 * NT;
+    for (int i = 0; i < P1; ++i) {
+      const int p = (wave + 4 * i) * 16 + col;
+      if (wave + 4 * i < n1 && p < R1) {
+        const int py = pk1[i] >> 16, px = pk1[i] & 0xffff;
+        bool inside = true;
+        if constexpr (!INTERIOR) {
+          const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
+          inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        }
+        T* dst = reinterpret_cast<T*>(tile2 + (py * LW + px) * PS) + g * 4 * NT;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (g * 4 * NT + t * 4 < a.C) {
-          typename Tr<T>::quad q;
+        for (int t = 0; t < NT; ++t) {
+          if (g * 4 * NT + t * 4 < a.C) {
+            typename Tr<T>::quad q;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) q[r] = inside ? (T)activate_ct<T, ACT_SILU>(acc[t][i][r] + bias1[t][r]) : (T)0.f;
-          *reinterpret_cast<typename Tr<T>::quad*>(dst + t * 4) = q;
+            for (int r = 0; r < 4; ++r) q[r] = inside ? (T)activate_ct<T, ACT_SILU>(acc[t][i][r] + bias1[t][r]) : (T)0.f;
+            *reinterpret_cast<typename Tr<T>::quad*>(dst + t * 4) = q;
+          }
         }
       }
     }
-  }
+  };
+  if (oy0 >= 1 && ox0 >= 1 && oy0 + TH + 1 <= a.H && ox0 + TW + 1 <= a.W) write_mid(std::true_type{});
+  else write_mid(std::false_type{});
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -1213,12 +1224,18 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
   const int row_words = a.Win * 3 / 4;
   const int w0 = (12 * ox0 - 9) >> 2;
   const uint32_t* im = reinterpret_cast<const uint32_t*>(a.img + (long)n * a.Hin * a.Win * 3);
-  for (int i = tid; i < SB_IR * SB_ROWW; i += 256) {
-    const int r = i / SB_ROWW, c = i - r * SB_ROWW;
-    const int iy = 4 * oy0 - 3 + r, wi = w0 + c;
-    uint32_t v = 0u;
-    if (iy >= 0 && iy < a.Hin && wi >= 0 && wi < row_words) v = im[(long)iy * row_words + wi];
-    in_tile[i] = v;
+  {  // a thread keeps its dword column and strides over rows: no per-element division, the column test is hoisted
+    const int c = tid & 127, r0 = tid >> 7;
+    const int wi = w0 + c;
+    const bool colok = c < SB_ROWW && wi >= 0 && wi < row_words;
+    if (c < SB_ROWW) {
+      for (int r = r0; r < SB_IR; r += 2) {
+        const int iy = 4 * oy0 - 3 + r;
+        uint32_t v = 0u;
+        if (colok && iy >= 0 && iy < a.Hin) v = im[(long)iy * row_words + wi];
+        in_tile[r * SB_ROWW + c] = v;
+      }
+    }
   }
   const half8 af0 = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.afrag)[lane]);
   const half8 af1 = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.afrag)[64 + lane]);
@@ -1228,6 +1245,8 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
   // ---- 2. stem on the matrix cores, two pixels per column (see stem_mfma_kernel); 17 x 33 pairs, 16 per MFMA tile
   const half2v k1024 = {(half_t)1024.f, (half_t)1024.f};
   constexpr int NPAIR = SB_SH * SB_PAIRS, NTILE = (NPAIR + 15) / 16;
+  // block-uniform: every stem pixel of this tile lies inside the stem map (then no per-pixel test)
+  const bool sb_interior = oy0 >= 1 && ox0 >= 1 && 2 * oy0 - 1 + SB_SH <= a.H1 && 2 * ox0 - 1 + SB_SW <= a.W1;
   for (int t = wave; t < NTILE; t += 4) {
     int pi = t * 16 + col;
     pi = pi < NPAIR ? pi : NPAIR - 1;
@@ -1258,7 +1277,7 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
     const int c = 2 * pp + (g >> 1);
     if (t * 16 + col < NPAIR && c < SB_SW) {
       const int sy = 2 * oy0 - 1 + r, sx = 2 * ox0 - 1 + c;
-      const bool inside = sy >= 0 && sy < a.H1 && sx >= 0 && sx < a.W1;
+      const bool inside = sb_interior || (sy >= 0 && sy < a.H1 && sx >= 0 && sx < a.W1);
       half4 q4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) q4[j] = inside ? (half_t)Tr<half_t>::silu(acc[j] + sb4[j]) : (half_t)0.f;
