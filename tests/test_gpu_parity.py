@@ -552,6 +552,43 @@ def test_empty_and_error_behaviour(synth_models, tmp_path):
         PyTorchClassifier("x", "resnet18")
 
 
+# ---------------------------------------------------------------------------- other graphs of the family (optional)
+@pytest.mark.parametrize("fam", ["yolo8"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_reference_baseline_graphs(tmp_path, fam, prec):
+    """the reference's YOLOv8n comparison detector uses the same NCNN op set (YOLOv5nu needs a
+    6x6 stem convolution and YOLO11n attention ops: not built); its exported graph file (staged by __graft_entry__.build() under oracle/_ref/, no weights exist) must plan and run
+    unchanged.  Seeded weights (litepi.ncnn_export.seeded_bin_for_param); fp32: north_star tolerance against the CPU
+    oracle, fp16: the documented fp16 bounds."""
+    import os
+    from litepi import Engine, ncnn_export
+    param = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", f"{fam}_tt100k.param")
+    if not os.path.exists(param):
+        pytest.skip("reference graph files not staged (run __graft_entry__.build() where /root/reference exists)")
+    binf = str(tmp_path / "m.bin")
+    ncnn_export.seeded_bin_for_param(param, binf, seed=5)
+    rng = np.random.default_rng(9)
+    imgs = rng.integers(0, 256, (2, 640, 640, 3), dtype=np.uint8)
+    ref, _ = _oracle_out0(param, binf, imgs)
+    e = Engine(precision=prec, max_batch=2)
+    try:
+        e.load_detector(param, binf)
+        got = e.detect_raw(imgs)
+    finally:
+        e.close()
+    assert got.shape == ref.shape
+    err_b = np.abs(got[:, :4] - ref[:, :4])
+    err_s = np.abs(got[:, 4:] - ref[:, 4:])
+    print(f"{fam} {prec}: score err max {err_s.max():.5f}; box err max {err_b.max():.4f}")
+    if prec == "fp32":
+        assert (err_b <= 1e-3 + 1e-3 * np.abs(ref[:, :4])).all()
+        assert err_s.max() <= 1e-3
+    else:
+        stride = np.concatenate([np.full(6400, 8.0), np.full(1600, 16.0), np.full(400, 32.0)]).astype(np.float32)
+        assert err_s.max() <= 0.02
+        assert (err_b <= 0.35 * stride + 0.02 * np.abs(ref[:, :4])).all()
+
+
 # ---------------------------------------------------------------------------- real weights (optional)
 _REF_STAGE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
 _REAL = (os.path.join(_REF_STAGE, "yolo_plus_v1.param"), os.path.join(_REF_STAGE, "yolo_plus_v1.bin"))

@@ -339,3 +339,47 @@ def shift_cls_bias(param_path: str, bin_path: str, delta: float, nc: int = 1) ->
             off += 4 * n
     with open(bin_path, "wb") as f:
         f.write(bytes(blob))
+
+
+def seeded_bin_for_param(param_path: str, bin_path: str, seed: int = 1234, gain: float = 1.6, size: int = 640,
+                         cls_bias: float = -2.0) -> None:
+    """Write a seeded random fp32 ``.bin`` that matches an existing NCNN ``.param`` of the YOLOv8 family
+    (same file layout as a real export: per Convolution a zero flag word, weights, optional bias; MemoryData
+    payloads).  Used to exercise graphs whose weights are not available (the reference ships the YOLOv8n /
+    YOLOv5nu graphs of its baseline comparison without weights).  He-style init scaled by ``gain``; the Detect
+    tail's DFL conv (no bias, one output channel) gets arange(reg_max); MemoryData blobs get the anchor grid /
+    strides of ``size``; convs that feed a Sigmoid through at most a Concat/Slice get ``cls_bias``."""
+    from .ncnn_io import read_param_layers
+    layers = read_param_layers(param_path)
+    rng = np.random.default_rng(seed)
+    anchors, strides = make_anchors(size)
+    # class count: the Detect tail slices [4*reg_max, nc] off the head concat; reg_max = K of the bias-free 1-channel conv
+    reg_max = next((int(L["params"][6]) for L in layers if L["type"] == "Convolution" and int(L["params"][0]) == 1 and
+                    int(L["params"].get(5, 0)) == 0), 16)
+    nc = next((int(L["params"][-23300][1]) for L in layers if L["type"] == "Slice" and -23300 in L["params"] and
+               len(L["params"][-23300]) == 2 and int(L["params"][-23300][0]) == 4 * reg_max), 1)
+    with open(bin_path, "wb") as f:
+        for L in layers:
+            p = L["params"]
+            if L["type"] == "Convolution":
+                out_ch, kw, wcount = int(p[0]), int(p.get(1, 1)), int(p[6])
+                kh = int(p.get(11, kw))
+                in_ch = wcount // (out_ch * kw * kh)
+                has_bias = int(p.get(5, 0)) != 0
+                if out_ch == 1 and not has_bias and kw == 1:
+                    w = np.arange(in_ch, dtype=np.float32).reshape(1, in_ch, 1, 1)  # DFL expectation
+                else:
+                    w = rng.standard_normal((out_ch, in_ch, kh, kw)).astype(np.float32) * np.float32(gain / np.sqrt(in_ch * kh * kw))
+                f.write(struct.pack("<I", 0))
+                f.write(np.ascontiguousarray(w, "<f4").tobytes())
+                if has_bias:
+                    b = (rng.standard_normal(out_ch) * 0.1).astype(np.float32)
+                    if kw == 1 and out_ch == nc:
+                        b[:] = cls_bias  # class projections: keeps the scores away from 0.5 on random weights
+                    f.write(np.ascontiguousarray(b, "<f4").tobytes())
+            elif L["type"] == "MemoryData":
+                w, h = int(p.get(0, 0)), int(p.get(1, 0))
+                data = strides if h == 0 else anchors
+                if data.size != max(w, 1) * max(h, 1):
+                    raise ValueError(f"MemoryData {L['name']}: {w}x{h} does not match the {size}x{size} anchor grid")
+                f.write(np.ascontiguousarray(data, "<f4").tobytes())
