@@ -78,10 +78,12 @@ struct BottleneckPair {
 // First layer: 3x3 stride-2 conv reading the uint8 BGR image directly.
 struct StemLayer {
   int prec = LP_FP16, CO = 8, act = ACT_SILU;
+  int k = 3, stride = 2, pad = 1;  // YOLOv8 family: 3x3/s2/p1 (fast kernels); anything else runs the generic kernel
   DevBuf d_w, d_bias;
   DevBuf d_afrag;  // fp16, 8 channels: MFMA A fragments (stem_mfma_kernel)
-  // w_bgr: fp32 [27][CO], row = (ky*3+kx)*3 + c with c in BGR order
-  void build(int prec, int cout_phys, int act, const std::vector<float>& w_bgr, const std::vector<float>& bias);
+  // w_bgr: fp32 [k*k*3][CO], row = (ky*k+kx)*3 + c with c in BGR order
+  void build(int prec, int cout_phys, int act, const std::vector<float>& w_bgr, const std::vector<float>& bias, int k = 3, int stride = 2,
+             int pad = 1);
   void launch(const uint8_t* img, int N, int Hin, int Win, const View& out, hipStream_t st) const;
   // stem + the following stride-2 3x3 conv (+ its fused 1x1 tail) in one launch (stem_block_kernel); out = the tail's output
   bool block_supported(const ConvLayer& c1) const;

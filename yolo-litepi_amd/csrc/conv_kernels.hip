@@ -1014,13 +1014,15 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const ConvArgs a, int k
 // Stem: 3x3 stride-2 pad-1 conv straight from the uint8 BGR image (the reference's
 // BGR->RGB + x*(1/255) + HWC->CHW preprocessing, e2e.py:222-238, is folded in: the weight
 // table is stored in BGR order and the scale is applied to the pixel before the FMA).
-// One thread = one output pixel x all CO channels.  w: fp32 [27][CO], k = (ky*3+kx)*3 + c_bgr.
+// One thread = one output pixel x all CO channels.  w: fp32 [k*k*3][CO], row = (ky*k+kx)*3 + c_bgr.  Generic in kernel
+// size / stride / padding (YOLOv5's 6x6/s2/p2 stem runs here); the 3x3/s2/p1 stems of the YOLOv8 family take the
+// LDS / MFMA kernels below.
 // ------------------------------------------------------------------------------------
 template <typename T, int CO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restrict__ img, T* __restrict__ out,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         int N, int Hin, int Win, int Hout, int Wout, int out_pitch,
-                                                        int act) {
+                                                        int act, int k, int stride, int pad) {
   const long pix = (long)blockIdx.x * 256 + threadIdx.x;
   if (pix >= (long)N * Hout * Wout) return;
   const int ox = (int)(pix % Wout);
@@ -1030,17 +1032,17 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restric
 #pragma unroll
   for (int c = 0; c < CO; ++c) acc[c] = 0.f;
   const float inv255 = 1.f / 255.f;
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = oy * 2 - 1 + ky;
+  for (int ky = 0; ky < k; ++ky) {
+    const int iy = oy * stride - pad + ky;
     if (iy < 0 || iy >= Hin) continue;
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ox * 2 - 1 + kx;
+    for (int kx = 0; kx < k; ++kx) {
+      const int ix = ox * stride - pad + kx;
       if (ix < 0 || ix >= Win) continue;
       const uint8_t* px = img + ((long)(n * Hin + iy) * Win + ix) * 3;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float v = (float)px[c] * inv255;
-        const float* wr = w + ((ky * 3 + kx) * 3 + c) * CO;
+        const float* wr = w + ((ky * k + kx) * 3 + c) * CO;
 #pragma unroll
         for (int co = 0; co < CO; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
       }
@@ -1922,8 +1924,9 @@ void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t 
   LP_HIP(hipGetLastError());
 }
 
-void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<float>& w_bgr, const std::vector<float>& bias) {
-  prec = prec_; CO = cout_phys; act = act_;
+void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<float>& w_bgr, const std::vector<float>& bias, int k_, int stride_, int pad_) {
+  prec = prec_; CO = cout_phys; act = act_; k = k_; stride = stride_; pad = pad_;
+  LP_CHECK((int)w_bgr.size() == k * k * 3 * CO, LP_ERR_GRAPH, "stem weights do not match a %dx%d kernel", k, k);
   LP_CHECK(CO == 8 || CO == 16 || CO == 32, LP_ERR_GRAPH, "stem with %d output channels unsupported", CO);
   d_w.alloc(w_bgr.size() * 4);
   LP_HIP(hipMemcpy(d_w.p, w_bgr.data(), w_bgr.size() * 4, hipMemcpyHostToDevice));
@@ -1931,7 +1934,7 @@ void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<floa
   for (size_t i = 0; i < bias.size() && i < (size_t)CO; ++i) b[i] = bias[i];
   d_bias.alloc(CO * 4);
   LP_HIP(hipMemcpy(d_bias.p, b.data(), CO * 4, hipMemcpyHostToDevice));
-  if (prec == LP_FP16 && CO == 8 && act == ACT_SILU) {
+  if (prec == LP_FP16 && CO == 8 && act == ACT_SILU && k == 3 && stride == 2 && pad == 1) {
     // stem_mfma_kernel A fragments [2 steps][64 lanes][8]: row m = (pixel parity, channel); K group q = 4s+g ->
     // (ky = q/2, byte half h = q%2) of the 15-byte union of the two windows; the even pixel uses union bytes 0..8,
     // the odd one 6..14.  1/255 folded in.
@@ -1974,7 +1977,8 @@ void StemLayer::launch_block(const uint8_t* img, int N, int Hin, int Win, const 
 }
 
 void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& out, hipStream_t st) const {
-  const bool aligned = Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 && out.H == (Hin + 1) / 2 && out.W == (Win + 1) / 2;
+  const bool aligned = k == 3 && stride == 2 && pad == 1 && Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 &&
+                       out.H == (Hin + 1) / 2 && out.W == (Win + 1) / 2;
   static const bool no_mfma_stem = getenv("LITEPI_NO_MFMA_STEM") != nullptr;
   if (aligned && d_afrag.p && !no_mfma_stem) {
     dim3 g3(N, ceil_div(out.W, STEMM_TW), ceil_div(out.H, STEMM_TH));
@@ -2001,7 +2005,7 @@ void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& 
   dim3 grid((unsigned)((total + 255) / 256));
 #define LP_ST(TT, C)                                                                                     \
   hipLaunchKernelGGL((stem_conv_kernel<TT, C>), grid, dim3(256), 0, st, img, reinterpret_cast<TT*>(out.base), \
-                     d_w.as<float>(), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch, act)
+                     d_w.as<float>(), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch, act, k, stride, pad)
   if (prec == LP_FP16) {
     if (CO == 8) LP_ST(half_t, 8); else if (CO == 16) LP_ST(half_t, 16); else LP_ST(half_t, 32);
   } else {

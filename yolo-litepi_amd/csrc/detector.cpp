@@ -208,7 +208,8 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     } else if (l.type == "Convolution") {
       const int tin = get(l.inputs[0]);
       const int k = l.ipar(1, 1), s = l.ipar(3, 1), pad = l.ipar(4, 0), dil = l.ipar(2, 1);
-      LP_CHECK(l.ipar(11, k) == k && l.ipar(13, s) == s && l.ipar(14, pad) == pad && dil == 1 && pad == k / 2, LP_ERR_GRAPH,
+      // pad k/2 everywhere; the image conv may also be YOLOv5's 6x6/s2/p2 stem (any k, s, p: generic stem kernel)
+      LP_CHECK(l.ipar(11, k) == k && l.ipar(13, s) == s && l.ipar(14, pad) == pad && dil == 1 && (pad == k / 2 || tin == input_tensor), LP_ERR_GRAPH,
                "Convolution %s: only square k with pad k/2, dilation 1 supported", l.name.c_str());
       LP_CHECK(l.in_ch == tensors_[tin].C, LP_ERR_GRAPH, "Convolution %s: weight expects %d input channels, blob has %d",
                l.name.c_str(), l.in_ch, tensors_[tin].C);
@@ -541,19 +542,19 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
       op.bytes = ((double)TI.C * TI.H * TI.W + (double)TO.C * TO.H * TO.W * (res >= 0 ? 2 : 1)) * esd + (double)l.weight.size() * esd;
       op.in = tin; op.out = tout; op.res = res;
       if (tin == input_tensor) {
-        LP_CHECK(k == 3 && s == 2 && Cin == 3, LP_ERR_GRAPH, "first convolution must be 3x3 stride 2 on 3 channels");
-        // weights in BGR order, [27][CO]
+        LP_CHECK(Cin == 3 && k >= 1 && k <= 7, LP_ERR_GRAPH, "first convolution must read the 3-channel image with k <= 7");
+        // weights in BGR order, [k*k*3][CO]
         const int CO = TO.Cp;
-        std::vector<float> w((size_t)27 * CO, 0.f), b(CO, 0.f);
+        std::vector<float> w((size_t)k * k * 3 * CO, 0.f), b(CO, 0.f);
         for (int co = 0; co < Cout; ++co) {
           const int pc = TO.phys(co);
           for (int c = 0; c < 3; ++c)
-            for (int ky = 0; ky < 3; ++ky)
-              for (int kx = 0; kx < 3; ++kx)
-                w[(size_t)((ky * 3 + kx) * 3 + (2 - c)) * CO + pc] = l.weight[(((size_t)co * 3 + c) * 3 + ky) * 3 + kx];
+            for (int ky = 0; ky < k; ++ky)
+              for (int kx = 0; kx < k; ++kx)
+                w[(size_t)((ky * k + kx) * 3 + (2 - c)) * CO + pc] = l.weight[(((size_t)co * 3 + c) * k + ky) * k + kx];
           if (!l.bias.empty()) b[pc] = l.bias[co];
         }
-        stem_.build(prec_, CO, fused_act[i], w, b);
+        stem_.build(prec_, CO, fused_act[i], w, b, k, s, l.ipar(4, 0));
         op.kind = DetOp::STEM;
         op.bytes = (double)3 * TI.H * TI.W + (double)TO.C * TO.H * TO.W * esd;
       } else {
