@@ -633,6 +633,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
           const int tsrc = get(l.inputs[0]);
           if (c2.size() == 1 && L[c2[0]].type == "Convolution" && L[c2[0]].ipar(1, 1) == 1 && L[c2[0]].ipar(3, 1) == 1 &&
               !is_tail(c2[0]) && tensors_[get(l.outputs[0])].off == 0 && tensors_[tsrc].Cp % 8 == 0 &&
+              tensors_[get(l.outputs[0])].buf >= 0 && tensors_[get(l.outputs[0])].buf == tensors_[get(L[c1[0]].outputs[0])].buf &&  // zero-copy segment 0
               tensors_[tsrc].Cp == tensors_[get(l.outputs[0])].Cp) {
             fuse_up[c2[0]] = tsrc;
             continue;
