@@ -808,6 +808,8 @@ void Detector::fetch_blob(const std::string& name, int B, std::vector<float>& ou
   auto it = blob2tensor_.find(name);
   LP_CHECK(it != blob2tensor_.end(), LP_ERR_ARG, "unknown blob %s", name.c_str());
   const Tensor& T = tensors_[it->second];
+  // a blob that a fused kernel keeps in registers / LDS has storage reserved (e.g. its concat slot) but is never written
+  LP_CHECK(T.materialised || T.parent >= 0 || T.segs.size() > 1, LP_ERR_ARG, "blob %s is fused away (never stored)", name.c_str());
   const View v = view(it->second);
   C = T.C; H = T.H; W = T.W;
   const size_t es = prec_ == LP_FP16 ? 2 : 4;
