@@ -1200,6 +1200,67 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restric
 }
 
 
+// 16-channel variant (v2 widths): one pixel per MFMA column, rows = the 16 output channels, K = 27 window bytes in one
+// 16x16x32 step: K group g < 3 = bytes 0..7 of window row g, group 3 = byte 8 of the three rows (+ 5 zero slots).
+__global__ __launch_bounds__(256) void stem_mfma16_kernel(const uint8_t* __restrict__ img, half_t* __restrict__ out,
+                                                          const u32x4* __restrict__ afrag, const float* __restrict__ bias,
+                                                          int N, int Hin, int Win, int Hout, int Wout, int out_pitch) {
+  __shared__ uint32_t tile[(2 * STEMM_TH + 1) * STEMM_ROWW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int n = blockIdx.x, oy0 = blockIdx.z * STEMM_TH, ox0 = blockIdx.y * STEMM_TW;
+  const int row_words = Win * 3 / 4;
+  const int w0 = (6 * ox0 - 3) >> 2;
+  const uint32_t* im = reinterpret_cast<const uint32_t*>(img + (long)n * Hin * Win * 3);
+  for (int i = tid; i < (2 * STEMM_TH + 1) * STEMM_ROWW; i += 256) {
+    const int r = i / STEMM_ROWW, c = i - r * STEMM_ROWW;
+    const int iy = 2 * oy0 - 1 + r, wi = w0 + c;
+    uint32_t v = 0u;
+    if (iy >= 0 && iy < Hin && wi >= 0 && wi < row_words) v = im[(long)iy * row_words + wi];
+    tile[i] = v;
+  }
+  const half8 af = __builtin_bit_cast(half8, afrag[lane]);
+  const floatx4 b4 = *reinterpret_cast<const floatx4*>(bias + 4 * g);
+  __syncthreads();
+  const half2v k1024 = {(half_t)1024.f, (half_t)1024.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int mt = wave * 8 + i;
+    const int r = mt >> 2, tx = (mt & 3) * 16 + col;
+    const int bo = 1 + 6 * tx;  // first window byte of this pixel inside a staged row
+    uint32_t wa, wb;
+    if (g < 3) {
+      const uint32_t* rw = tile + (2 * r + g) * STEMM_ROWW + (bo >> 2);
+      const int sh = bo & 3;
+      const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
+      wa = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      wb = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    } else {
+      const int b8 = bo + 8;
+      const uint8_t* t8 = reinterpret_cast<const uint8_t*>(tile);
+      wa = (uint32_t)t8[(2 * r + 0) * STEMM_ROWW * 4 + b8] | ((uint32_t)t8[(2 * r + 1) * STEMM_ROWW * 4 + b8] << 8) |
+           ((uint32_t)t8[(2 * r + 2) * STEMM_ROWW * 4 + b8] << 16);
+      wb = 0u;
+    }
+    const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04010400u);
+    const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04030402u);
+    const uint32_t p2 = __builtin_amdgcn_perm(0x64646464u, wb, 0x04010400u);
+    const uint32_t p3 = __builtin_amdgcn_perm(0x64646464u, wb, 0x04030402u);
+    const half2v h0 = __builtin_bit_cast(half2v, p0) - k1024, h1 = __builtin_bit_cast(half2v, p1) - k1024;
+    const half2v h2 = __builtin_bit_cast(half2v, p2) - k1024, h3 = __builtin_bit_cast(half2v, p3) - k1024;
+    const half8 bf = half8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc, 0, 0, 0);
+    const int oy = oy0 + r, ox = ox0 + tx;
+    if (oy < Hout && ox < Wout) {
+      half4 q4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q4[j] = (half_t)Tr<half_t>::silu(acc[j] + b4[j]);
+      *reinterpret_cast<half4*>(out + ((long)(n * Hout + oy) * Wout + ox) * out_pitch + 4 * g) = q4;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // Network head in one launch (fp16, v1 widths): stem 3x3/s2 (uint8 BGR -> 8 ch, SiLU) -> 3x3/s2 conv (8 -> <=16 ch,
 // SiLU) -> its 1x1 tail (C2f.cv1).  The 320x320x8 stem map is the largest activation of the network and was written
@@ -1518,15 +1579,15 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
 }
 
 bool ConvLayer::tail_supported(int k, int stride, int cmid_phys, int cout2_phys) {
-  if (k != 3 || cmid_phys % 16 != 0) return false;
-  const int nt = cmid_phys / 16, t2 = ceil_div(cout2_phys, 16);
+  if (k != 3 || cmid_phys % 8 != 0) return false;
+  const int nt = ceil_div(cmid_phys, 16), t2 = ceil_div(cout2_phys, 16);  // a half-filled last tile has zero weights and bias
   if (stride == 1) return (nt == 4 && t2 == 4) || (nt == 2 && t2 == 1);
   if (stride == 2) return (nt == 1 && t2 == 1) || (nt == 2 && t2 == 2) || (nt == 4 && t2 == 4);
   return false;
 }
 
 void ConvLayer::attach_tail(int cout2_phys, int act2_, const std::vector<float>& w2_phys, const std::vector<float>& bias2_phys) {
-  LP_CHECK(impl == IMPL_MFMA && nsplits == 1 && NT * 16 == Cout && tail_supported(k, stride, Cout, cout2_phys), LP_ERR_STATE,
+  LP_CHECK(impl == IMPL_MFMA && nsplits == 1 && NT == ceil_div(Cout, 16) && tail_supported(k, stride, Cout, cout2_phys), LP_ERR_STATE,
            "conv %s: fused 1x1 tail not supported for this shape", name.c_str());
   T2 = ceil_div(cout2_phys, 16);
   Cout2 = cout2_phys;
@@ -1543,6 +1604,7 @@ void ConvLayer::attach_tail(int cout2_phys, int act2_, const std::vector<float>&
         for (int j = 0; j < G; ++j) {
           if (G * s2 + j >= 4 * NT) continue;       // half-filled last K step (odd NT, fp16)
           const int mid = g * 4 * NT + G * s2 + j;  // the intermediate channel this lane's accumulators hold at (s2, j)
+          if (mid >= Cout) continue;                // padding rows of a half-filled last channel tile
           put_elem(buf, ((size_t)(t * S2 + s2) * 64 + lane) * G + j, prec, w2_phys[(size_t)oc * Cout + mid]);
         }
       }
@@ -1954,6 +2016,23 @@ void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<floa
     d_afrag.alloc(buf.size());
     LP_HIP(hipMemcpy(d_afrag.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
   }
+  if (prec == LP_FP16 && CO == 16 && act == ACT_SILU && k == 3 && stride == 2 && pad == 1) {
+    // stem_mfma16_kernel A fragment [64 lanes][8]: row m = channel; K group g < 3 = window row g bytes 0..7, group 3 =
+    // byte 8 of rows 0..2.  1/255 folded in.
+    std::vector<uint8_t> buf((size_t)64 * 16, 0);
+    for (int lane = 0; lane < 64; ++lane) {
+      const int g = lane >> 4, ch = lane & 15;
+      for (int j = 0; j < 8; ++j) {
+        int row;
+        if (g < 3) row = g * 9 + j;
+        else if (j < 3) row = j * 9 + 8;
+        else continue;
+        put_elem(buf, (size_t)lane * 8 + j, LP_FP16, w_bgr[(size_t)row * CO + ch] / 255.f);
+      }
+    }
+    d_afrag.alloc(buf.size());
+    LP_HIP(hipMemcpy(d_afrag.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+  }
 }
 
 
@@ -1980,6 +2059,13 @@ void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& 
   const bool aligned = k == 3 && stride == 2 && pad == 1 && Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0 &&
                        out.H == (Hin + 1) / 2 && out.W == (Win + 1) / 2;
   static const bool no_mfma_stem = getenv("LITEPI_NO_MFMA_STEM") != nullptr;
+  if (aligned && d_afrag.p && !no_mfma_stem && CO == 16) {
+    dim3 g3(N, ceil_div(out.W, STEMM_TW), ceil_div(out.H, STEMM_TH));
+    hipLaunchKernelGGL(stem_mfma16_kernel, g3, dim3(256), 0, st, img, reinterpret_cast<half_t*>(out.base),
+                       reinterpret_cast<const u32x4*>(d_afrag.p), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch);
+    LP_HIP(hipGetLastError());
+    return;
+  }
   if (aligned && d_afrag.p && !no_mfma_stem) {
     dim3 g3(N, ceil_div(out.W, STEMM_TW), ceil_div(out.H, STEMM_TH));
     hipLaunchKernelGGL(stem_mfma_kernel, g3, dim3(256), 0, st, img, reinterpret_cast<half_t*>(out.base),
