@@ -24,3 +24,13 @@ for conf in (0.25, 0.05, 0.001):
         for _ in range(10): e.run_batch_device(imgs.data_ptr(), B, 640, 640, conf, 0.45, 50, dets.data_ptr(), counts.data_ptr())
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
     print(f"conf {conf}: {dt*1e3:.2f} ms/step, kept {int(counts[:B].sum())} rois, pre-filter {int(counts[B:].sum())}")
+
+# per-launch profile of one stressed step (HIP events), top entries
+with torch.cuda.stream(st):
+    e.profile_next(True)
+    e.run_batch_device(imgs.data_ptr(), B, 640, 640, 0.25, 0.45, 50, dets.data_ptr(), counts.data_ptr())
+    torch.cuda.synchronize()
+    prof = sorted(e.profile_read(), key=lambda k: -k["ms"])
+    print("profiled step %.2f ms" % sum(k["ms"] for k in prof))
+    for k in prof[:14]:
+        print("  %-28s %-26s %8.1f us" % (k["name"], k["layer"], k["ms"] * 1e3))

@@ -225,6 +225,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   const float thr = a.iou;
   for (int i = 0; i < cnt; ++i) {
     if (removed[i]) continue;  // uniform: written before the last barrier only
+    // the records leave in this (class, score) order and only the first max_det of them: once that many are kept the
+    // rest of the sweep cannot change the result (the reference has no such bound; tests that compare whole sets run
+    // with max_det = number of anchors).  Bounds the serial part at max_det barrier rounds under stress.
+    if (nkeep >= a.max_det) break;
     if (tid == 0) keep[nkeep] = i;
     ++nkeep;
     const Cand bi = sorted[i];
