@@ -83,7 +83,7 @@ def load_bin(layers: List[Layer], path: str) -> None:
         blob = f.read()
     off = 0
     for L in layers:
-        if L.type == "Convolution":
+        if L.type in ("Convolution", "ConvolutionDepthWise"):
             out_ch = int(L.params[0])
             kw = int(L.params.get(1, 1))
             kh = int(L.params.get(11, kw))
@@ -92,7 +92,7 @@ def load_bin(layers: List[Layer], path: str) -> None:
             off += 4
             if flag != 0:
                 raise ValueError(f"{L.name}: unsupported weight storage flag {flag:#x}")
-            in_ch = wcount // (out_ch * kw * kh)
+            in_ch = wcount // (out_ch * kw * kh)  # per group for ConvolutionDepthWise (1 for a depthwise conv)
             L.weight = np.frombuffer(blob, "<f4", wcount, off).reshape(out_ch, in_ch, kh, kw).copy()
             off += 4 * wcount
             if int(L.params.get(5, 0)):
@@ -141,7 +141,7 @@ def run_graph(layers: List[Layer], x: torch.Tensor, keep: Optional[List[str]] = 
         elif t == "MemoryData":
             blobs[L.outputs[0]] = torch.from_numpy(L.data)
             batched[L.outputs[0]] = False
-        elif t == "Convolution":
+        elif t in ("Convolution", "ConvolutionDepthWise"):
             a = blobs[L.inputs[0]]
             squeeze = False
             if a.dim() == 3:  # [B,h,w] never happens here; keep conv strictly 4-D
@@ -149,9 +149,12 @@ def run_graph(layers: List[Layer], x: torch.Tensor, keep: Optional[List[str]] = 
             stride = (int(p.get(13, p.get(3, 1))), int(p.get(3, 1)))
             pad = (int(p.get(14, p.get(4, 0))), int(p.get(4, 0)))
             dil = (int(p.get(12, p.get(2, 1))), int(p.get(2, 1)))
+            squeeze = a.dim() == 3  # a blob that went through 3-D Reshape/MatMul (YOLO11 attention) has no batch dim
+            if squeeze:
+                raise ValueError("Convolution on non-3D blob")
             y = F.conv2d(a, torch.from_numpy(L.weight),
                          torch.from_numpy(L.bias) if L.bias is not None else None,
-                         stride=stride, padding=pad, dilation=dil)
+                         stride=stride, padding=pad, dilation=dil, groups=int(p.get(7, 1)) if t == "ConvolutionDepthWise" else 1)
             blobs[L.outputs[0]] = y
             batched[L.outputs[0]] = True
         elif t == "Swish":
@@ -222,12 +225,20 @@ def run_graph(layers: List[Layer], x: torch.Tensor, keep: Optional[List[str]] = 
             b = batched[L.inputs[0]]
             order = int(p.get(0, 0))
             nd = a.dim() - (1 if b else 0)
-            if nd != 3 or order != 2:
-                raise ValueError("only 3-D Permute order_type 2 (w,c,h) is used by these graphs")
-            # new (w,h,c) = old (w,c,h): [c,h,w] -> [h,c,w]
+            if nd != 3 or order not in (1, 2):
+                raise ValueError("only 3-D Permute order_type 1 (h,w,c) / 2 (w,c,h) is used by these graphs")
             o = 1 if b else 0
-            blobs[L.outputs[0]] = a.transpose(o, o + 1).contiguous()
+            if order == 2:   # new (w,h,c) = old (w,c,h): [c,h,w] -> [h,c,w]
+                blobs[L.outputs[0]] = a.transpose(o, o + 1).contiguous()
+            else:            # new (w,h,c) = old (h,w,c): [c,h,w] -> [c,w,h]   (YOLO11 attention: q^T)
+                blobs[L.outputs[0]] = a.transpose(o + 1, o + 2).contiguous()
             batched[L.outputs[0]] = b
+        elif t == "MatMul":
+            a, bb = blobs[L.inputs[0]], blobs[L.inputs[1]]
+            if int(p.get(0, 0)):
+                bb = bb.transpose(-1, -2)
+            blobs[L.outputs[0]] = torch.matmul(a, bb)
+            batched[L.outputs[0]] = batched[L.inputs[0]] or batched[L.inputs[1]]
         elif t == "Softmax":
             a = blobs[L.inputs[0]]
             b = batched[L.inputs[0]]

@@ -553,11 +553,12 @@ def test_empty_and_error_behaviour(synth_models, tmp_path):
 
 
 # ---------------------------------------------------------------------------- other graphs of the family (optional)
-@pytest.mark.parametrize("fam", ["yolo8", "yolo5"])
+@pytest.mark.parametrize("fam", ["yolo8", "yolo5", "yolo11"])
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 def test_reference_baseline_graphs(tmp_path, fam, prec):
     """the reference's YOLOv8n / YOLOv5nu comparison detectors use the same NCNN op set (YOLOv5nu with
-    a 6x6/s2/p2 stem: generic stem kernel; YOLO11n needs depthwise + attention ops: not built); their exported graph files (staged by __graft_entry__.build() under oracle/_ref/, no weights exist) must plan and run
+    a 6x6/s2/p2 stem: generic stem kernel; YOLO11n adds ConvolutionDepthWise and the C2PSA attention block, matched as one
+    fused op); their exported graph files (staged by __graft_entry__.build() under oracle/_ref/, no weights exist) must plan and run
     unchanged.  Seeded weights (litepi.ncnn_export.seeded_bin_for_param); fp32: north_star tolerance against the CPU
     oracle, fp16: the documented fp16 bounds."""
     import os

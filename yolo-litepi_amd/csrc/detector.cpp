@@ -96,6 +96,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   const size_t es = prec_ == LP_FP16 ? 2 : 4;
 
   tensors_.clear(); blob2tensor_.clear(); buffers_.clear(); convs_.clear(); ops_.clear(); levels_.clear();
+  bnecks_.clear(); dws_.clear(); attns_.clear();
   loaded_ = false;
 
   std::map<std::string, int> producer;
@@ -127,6 +128,37 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   std::set<int> head_cat_set(head_cats.begin(), head_cats.end());
   auto is_tail = [&](int i) { return i >= first_tail || head_cat_set.count(i) || L[i].type == "MemoryData"; };
 
+  // ---- YOLO11 C2PSA attention blocks: a fixed 12-layer sequence becomes one ATTN op (launch_psa_attention) --------
+  struct AttnBlock { int heads, dk, dv, hw; float scale; int dw; std::string in_blob, out_blob; };
+  std::map<int, AttnBlock> attn_at;
+  std::vector<char> in_attn(n, 0);
+  {
+    const char* seq[12] = {"Reshape", "Slice", "Split", "Permute", "MatMul", "BinaryOp", "Softmax", "MatMul", "Reshape", "Reshape",
+                           "ConvolutionDepthWise", "BinaryOp"};
+    for (int i = 0; i + 12 <= n; ++i) {
+      if (is_tail(i) || L[i].type != "Reshape" || L[i].ipar(2, 0) <= 0 || prod_type(L[i].inputs[0]) != "Convolution") continue;
+      bool ok = true;
+      for (int q = 0; q < 12 && ok; ++q) ok = L[i + q].type == seq[q];
+      if (!ok) continue;
+      AttnBlock a;
+      a.heads = L[i].ipar(2); a.hw = L[i].ipar(0);
+      auto it = L[i + 1].arrays.find(0);
+      ok = it != L[i + 1].arrays.end() && it->second.size() == 3 && L[i + 1].ipar(1, 0) == 1 && it->second[0] == it->second[1];
+      if (ok) { a.dk = (int)it->second[0]; a.dv = (int)it->second[2]; }
+      ok = ok && L[i].ipar(1) == 2 * a.dk + a.dv && L[i + 3].ipar(0, 0) == 1 && L[i + 5].ipar(0, 0) == 2 && L[i + 5].ipar(1, 0) == 1 &&
+           L[i + 7].ipar(0, 0) == 1 && L[i + 10].ipar(1, 1) == 3 && L[i + 10].ipar(3, 1) == 1 && L[i + 10].ipar(4, 0) == 1 &&
+           L[i + 10].ipar(7, 1) == a.heads * a.dv && L[i + 10].ipar(0) == a.heads * a.dv && L[i + 11].ipar(0, 0) == 0 &&
+           L[i + 11].inputs.size() == 2;
+      LP_CHECK(ok, LP_ERR_GRAPH, "attention block at %s has an unexpected shape", L[i].name.c_str());
+      a.scale = (float)L[i + 5].fpar(2, 1.0);
+      a.dw = i + 10;
+      a.in_blob = L[i].inputs[0];
+      a.out_blob = L[i + 11].outputs[0];
+      attn_at[i] = a;
+      for (int q = 0; q < 12; ++q) in_attn[i + q] = 1;
+    }
+  }
+
   // ---- aliases (Split) and Swish fusion -----------------------------------------------------
   std::map<std::string, std::string> alias;
   std::function<std::string(const std::string&)> canon = [&](const std::string& b) {
@@ -138,10 +170,10 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   std::vector<std::string> conv_out(n);
   std::vector<char> skip(n, 0);
   for (int i = 0; i < n; ++i) {
-    if (is_tail(i)) continue;
+    if (is_tail(i) || in_attn[i]) continue;
     if (L[i].type == "Split")
       for (auto& o : L[i].outputs) alias[o] = L[i].inputs[0];
-    if (L[i].type == "Convolution") {
+    if (L[i].type == "Convolution" || L[i].type == "ConvolutionDepthWise") {
       const std::string& x = L[i].outputs[0];
       conv_out[i] = x;
       auto& cs = consumers[x];
@@ -155,12 +187,16 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   std::map<std::string, std::vector<int>> canon_consumers;
   for (int i = 0; i < n; ++i) {
     if (L[i].type == "Split" || skip[i]) continue;
+    if (in_attn[i]) {  // the block as a whole consumes its input blob
+      if (attn_at.count(i)) canon_consumers[canon(attn_at[i].in_blob)].push_back(i);
+      continue;
+    }
     for (auto& in : L[i].inputs) canon_consumers[canon(in)].push_back(i);
   }
   // Slice sizes keyed by the canonical input blob (needed before the parent's layout is fixed)
   std::map<std::string, std::vector<int>> slice_sizes;
   for (int i = 0; i < n; ++i) {
-    if (is_tail(i) || L[i].type != "Slice") continue;
+    if (is_tail(i) || in_attn[i] || L[i].type != "Slice") continue;
     LP_CHECK(L[i].ipar(1, 0) == 0, LP_ERR_GRAPH, "Slice %s: only channel slices supported", L[i].name.c_str());
     auto it = L[i].arrays.find(0);
     LP_CHECK(it != L[i].arrays.end() && it->second.size() == L[i].outputs.size(), LP_ERR_GRAPH, "Slice %s: bad size list", L[i].name.c_str());
@@ -203,6 +239,24 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     if (i >= first_tail) continue;  // DFL conv etc.
     const NcnnLayer& l = L[i];
     if (skip[i]) continue;
+    if (in_attn[i]) {
+      if (attn_at.count(i)) {
+        const AttnBlock& a = attn_at[i];
+        const Tensor tin = tensors_[get(a.in_blob)];
+        LP_CHECK(tin.C == a.heads * (2 * a.dk + a.dv) && tin.H * tin.W == a.hw && tin.segs.size() == 1, LP_ERR_GRAPH,
+                 "attention block at %s: qkv blob is %dx%dx%d", l.name.c_str(), tin.C, tin.H, tin.W);
+        new_tensor(a.out_blob, a.heads * a.dv, tin.H, tin.W);
+      }
+      continue;
+    }
+    if (l.type == "ConvolutionDepthWise") {
+      const int tin = get(l.inputs[0]);
+      LP_CHECK(l.ipar(1, 1) == 3 && l.ipar(3, 1) == 1 && l.ipar(4, 0) == 1 && l.ipar(2, 1) == 1 && l.ipar(7, 1) == l.ipar(0) &&
+                   l.ipar(0) == tensors_[tin].C, LP_ERR_GRAPH, "ConvolutionDepthWise %s: only depthwise 3x3/s1/p1 supported", l.name.c_str());
+      cinfo[i].tin = tin;
+      cinfo[i].tout = new_tensor(conv_out[i], l.ipar(0), tensors_[tin].H, tensors_[tin].W);
+      continue;
+    }
     if (l.type == "Input") {
       input_tensor = new_tensor(l.outputs[0], 3, S_, S_);
     } else if (l.type == "Convolution") {
@@ -328,6 +382,58 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   for (int i = 0; i < first_tail; ++i) {
     if ((is_tail(i) && L[i].type != "Convolution") || skip[i] || done[i]) continue;
     const NcnnLayer& l = L[i];
+    if (in_attn[i]) {
+      if (!attn_at.count(i)) continue;
+      const AttnBlock& a = attn_at[i];
+      const int tin = get(a.in_blob), tout = get(a.out_blob);
+      ensure_buffer(tout);
+      const NcnnLayer& dw = L[a.dw];
+      const int Cv = a.heads * a.dv;
+      attns_.emplace_back();
+      AttnLayer& A = attns_.back();
+      A.heads = a.heads; A.dk = a.dk; A.dv = a.dv; A.scale = a.scale;
+      std::vector<float> w((size_t)9 * Cv, 0.f), b(Cv, 0.f);
+      for (int c = 0; c < Cv; ++c) {
+        for (int t = 0; t < 9; ++t) w[(size_t)t * Cv + c] = dw.weight[(size_t)c * 9 + t];
+        if (!dw.bias.empty()) b[c] = dw.bias[c];
+      }
+      A.pe_w.alloc(w.size() * 4); A.pe_b.alloc(b.size() * 4);
+      LP_HIP(hipMemcpy(A.pe_w.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+      LP_HIP(hipMemcpy(A.pe_b.p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+      const Tensor& TI = tensors_[tin];
+      DetOp op;
+      op.kind = DetOp::ATTN; op.layer = l.name; op.conv = (int)attns_.size() - 1; op.in = tin; op.out = tout;
+      op.flops = 2.0 * a.heads * (double)a.hw * a.hw * (a.dk + a.dv);
+      op.bytes = ((double)TI.C + Cv) * TI.H * TI.W * esd;
+      ops_.push_back(op);
+      continue;
+    }
+    if (l.type == "ConvolutionDepthWise") {
+      const int tin = cinfo[i].tin, tout = cinfo[i].tout;
+      const Tensor& TI = tensors_[tin];
+      LP_CHECK(TI.segs.size() == 1 && tensors_[tout].segs.size() == 1 && TI.Cp == tensors_[tout].Cp, LP_ERR_GRAPH,
+               "ConvolutionDepthWise %s: input and output must be plain tensors", l.name.c_str());
+      ensure_buffer(tout);
+      const int C = l.ipar(0), Cp = TI.Cp;
+      dws_.emplace_back();
+      DwLayer& D = dws_.back();
+      D.act = fused_act[i];
+      std::vector<float> w((size_t)9 * Cp, 0.f), b(Cp, 0.f);
+      for (int c = 0; c < C; ++c) {
+        for (int t = 0; t < 9; ++t) w[(size_t)t * Cp + TI.phys(c)] = l.weight[(size_t)c * 9 + t];
+        if (!l.bias.empty()) b[TI.phys(c)] = l.bias[c];
+      }
+      D.w.alloc(w.size() * 4); D.b.alloc(b.size() * 4);
+      LP_HIP(hipMemcpy(D.w.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+      LP_HIP(hipMemcpy(D.b.p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+      DetOp op;
+      op.kind = DetOp::DWCONV; op.layer = l.name; op.conv = (int)dws_.size() - 1; op.in = tin; op.out = tout;
+      op.flops = 2.0 * 9.0 * C * TI.H * TI.W;
+      op.bytes = 2.0 * C * TI.H * TI.W * esd;
+      macs_ += 9.0 * C * TI.H * TI.W;
+      ops_.push_back(op);
+      continue;
+    }
     if (l.type == "Convolution") {
       const int tin = cinfo[i].tin;
       int tout = cinfo[i].tout, res = -1;
@@ -767,6 +873,16 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         }
         kname = std::string("bottleneck3x3x2") + sfx;
         break;
+      case DetOp::DWCONV:
+        launch_dwconv3x3_act(prec_, view(op.in), view(op.out), dws_[op.conv].w.as<float>(), dws_[op.conv].b.as<float>(), dws_[op.conv].act, B, st);
+        kname = std::string("dwconv3x3_det") + sfx;
+        break;
+      case DetOp::ATTN: {
+        const AttnLayer& A = attns_[op.conv];
+        launch_psa_attention(prec_, view(op.in), view(op.out), A.pe_w.as<float>(), A.pe_b.as<float>(), A.heads, A.dk, A.dv, A.scale, B, st);
+        kname = std::string("psa_attention") + sfx;
+        break;
+      }
       case DetOp::UPSAMPLE:
         launch_upsample2x(prec_, view(op.in), view(op.out), B, st);
         kname = std::string("upsample2x") + sfx;

@@ -25,6 +25,11 @@ void launch_sppf_pool(int prec, const View& in, const View& o1, const View& o2, 
 // fallbacks for graphs whose concat/add could not be fused
 void launch_add(int prec, const View& a, const View& b, const View& out, int N, hipStream_t st);
 void launch_copy(int prec, const View& in, const View& out, int N, hipStream_t st);
+// YOLO11: ConvolutionDepthWise 3x3/s1/p1 (+bias, optional SiLU), w fp32 [9][C] over physical channels
+void launch_dwconv3x3_act(int prec, const View& in, const View& out, const float* w, const float* bias, int act, int N, hipStream_t st);
+// YOLO11 C2PSA attention block (Reshape .. MatMul .. Softmax .. MatMul .. + depthwise positional encoding), see misc_kernels.hip
+void launch_psa_attention(int prec, const View& qkv, const View& out, const float* pe_w, const float* pe_b, int heads, int dk, int dv,
+                          float scale, int N, hipStream_t st);
 
 // ---- post_kernels.hip -----------------------------------------------------------------
 struct Cand {  // one candidate / kept box, 32 bytes

@@ -274,4 +274,149 @@ void launch_copy(int prec, const View& in, const View& out, int N, hipStream_t s
   LP_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------
+// Depthwise 3x3 / stride 1 / pad 1 (+bias, optional SiLU) on a detector activation (NHWC).  YOLO11's DWConv layers
+// (Detect class branch) -- ConvolutionDepthWise in the NCNN export.  w: fp32 [9][C] over physical channels.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_act_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            long npix, int H, int W, int C, int in_pitch, int out_pitch, int act) {
+  typedef typename VecT<T>::type vec;
+  constexpr int G = VecT<T>::G;
+  const int CG = C / G;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npix * CG) return;
+  const int cg = (int)(idx % CG);
+  const long pix = idx / CG;
+  const int ox = (int)(pix % W), oy = (int)((pix / W) % H);
+  float acc[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) acc[i] = bias[cg * G + i];
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy - 1 + ky;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox - 1 + kx;
+      if (ix < 0 || ix >= W) continue;
+      const vec v = *reinterpret_cast<const vec*>(in + (pix + (long)(ky - 1) * W + (kx - 1)) * in_pitch + cg * G);
+      const float* wr = w + (ky * 3 + kx) * C + cg * G;
+#pragma unroll
+      for (int i = 0; i < G; ++i) acc[i] = fmaf((float)v[i], wr[i], acc[i]);
+    }
+  }
+  vec o;
+#pragma unroll
+  for (int i = 0; i < G; ++i) o[i] = (T)(act == ACT_SILU ? acc[i] * __builtin_amdgcn_rcpf(1.f + __expf(-acc[i])) : acc[i]);
+  *reinterpret_cast<vec*>(out + pix * out_pitch + cg * G) = o;
+}
+
+void launch_dwconv3x3_act(int prec, const View& in, const View& out, const float* w, const float* bias, int act, int N, hipStream_t st) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  LP_CHECK(in.C == out.C && in.C % G == 0 && in.H == out.H && in.W == out.W, LP_ERR_STATE, "dwconv3x3: view mismatch");
+  const long npix = (long)N * in.H * in.W;
+  dim3 grid((unsigned)((npix * (in.C / G) + 255) / 256));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(dwconv3x3_act_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, w, bias, npix,
+                       in.H, in.W, in.C, in.pitch, out.pitch, act);
+  else
+    hipLaunchKernelGGL(dwconv3x3_act_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, w, bias, npix,
+                       in.H, in.W, in.C, in.pitch, out.pitch, act);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
+// YOLO11 C2PSA attention (model.ncnn.param of the reference's yolo11 export, layers reshape_166 .. add_7): the qkv
+// tensor [N, HW, heads*(2*dk+dv)] holds per head dk query, dk key and dv value channels.  Per head:
+//     P = softmax_m(scale * q_n . k_m),   o_n = sum_m P[n][m] v_m,   out = o + dwconv3x3(v) + pe_bias
+// One workgroup = 16 queries of one (image, head); scores in LDS (fp32), K / V read through L2 (a head's K and V are
+// ~75 KB).  fp32 arithmetic whatever the storage type.
+// ------------------------------------------------------------------------------------
+#define ATT_QB 16
+template <typename T>
+__global__ __launch_bounds__(256) void psa_attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, const float* __restrict__ pe_w,
+                                                            const float* __restrict__ pe_b, int H, int W, int heads, int dk, int dv,
+                                                            float scale, int in_pitch, int out_pitch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = H * W;
+  float* sq = reinterpret_cast<float*>(smem);         // [ATT_QB][dk]
+  float* ss = sq + ATT_QB * dk;                        // [ATT_QB][HW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x, h = blockIdx.y, n0 = blockIdx.z * ATT_QB;
+  const int hc = h * (2 * dk + dv);
+  const T* base = qkv + (long)n * HW * in_pitch + hc;
+  for (int i = tid; i < ATT_QB * dk; i += 256) {
+    const int qi = i / dk, j = i - qi * dk;
+    sq[i] = n0 + qi < HW ? (float)base[(long)(n0 + qi) * in_pitch + j] : 0.f;
+  }
+  __syncthreads();
+  for (int m = tid; m < HW; m += 256) {
+    float acc[ATT_QB];
+#pragma unroll
+    for (int qi = 0; qi < ATT_QB; ++qi) acc[qi] = 0.f;
+    const T* kp = base + (long)m * in_pitch + dk;
+    for (int j = 0; j < dk; ++j) {
+      const float kv = (float)kp[j];
+#pragma unroll
+      for (int qi = 0; qi < ATT_QB; ++qi) acc[qi] = fmaf(sq[qi * dk + j], kv, acc[qi]);
+    }
+#pragma unroll
+    for (int qi = 0; qi < ATT_QB; ++qi) ss[qi * HW + m] = acc[qi] * scale;
+  }
+  __syncthreads();
+  for (int qi = wave; qi < ATT_QB; qi += 4) {  // softmax over the keys, one wave per query row
+    float mx = -3.0e38f;
+    for (int m = lane; m < HW; m += 64) mx = fmaxf(mx, ss[qi * HW + m]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int m = lane; m < HW; m += 64) { const float e = expf(ss[qi * HW + m] - mx); ss[qi * HW + m] = e; sum += e; }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+    for (int m = lane; m < HW; m += 64) ss[qi * HW + m] *= inv;
+  }
+  __syncthreads();
+  for (int i = tid; i < ATT_QB * dv; i += 256) {
+    const int qi = i / dv, d = i - qi * dv;
+    const int q = n0 + qi;
+    if (q >= HW) continue;
+    const T* vp = base + 2 * dk + d;
+    float acc = 0.f;
+    for (int m = 0; m < HW; ++m) acc = fmaf(ss[qi * HW + m], (float)vp[(long)m * in_pitch], acc);
+    // positional encoding: depthwise 3x3 over the value map of this channel
+    const int c = h * dv + d, oy = q / W, ox = q - oy * W;
+    float pe = pe_b[c];
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        pe = fmaf((float)vp[(long)(iy * W + ix) * in_pitch], pe_w[(ky * 3 + kx) * heads * dv + c], pe);
+      }
+    }
+    out[((long)n * HW + q) * out_pitch + c] = (T)(acc + pe);
+  }
+}
+
+void launch_psa_attention(int prec, const View& qkv, const View& out, const float* pe_w, const float* pe_b, int heads, int dk, int dv,
+                          float scale, int N, hipStream_t st) {
+  const int HW = qkv.H * qkv.W;
+  LP_CHECK(qkv.C >= heads * (2 * dk + dv) && out.C >= heads * dv && out.H == qkv.H && out.W == qkv.W, LP_ERR_STATE, "attention: view mismatch");
+  const size_t lds = (size_t)ATT_QB * (dk + HW) * 4;
+  LP_CHECK(lds <= 150 * 1024, LP_ERR_GRAPH, "attention over %d positions does not fit LDS", HW);
+  dim3 grid(N, heads, (HW + ATT_QB - 1) / ATT_QB);
+  if (prec == LP_FP16) {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(psa_attention_kernel<half_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL(psa_attention_kernel<half_t>, grid, dim3(256), lds, st, (const half_t*)qkv.base, (half_t*)out.base, pe_w, pe_b, qkv.H,
+                       qkv.W, heads, dk, dv, scale, qkv.pitch, out.pitch);
+  } else {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(psa_attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL(psa_attention_kernel<float>, grid, dim3(256), lds, st, (const float*)qkv.base, (float*)out.base, pe_w, pe_b, qkv.H,
+                       qkv.W, heads, dk, dv, scale, qkv.pitch, out.pitch);
+  }
+  LP_HIP(hipGetLastError());
+}
+
 }  // namespace lp

@@ -82,7 +82,7 @@ void NcnnGraph::load(const std::string& param_path, const std::string& bin_path)
     off += 4 * n;
   };
   for (auto& L : layers) {
-    if (L.type == "Convolution") {
+    if (L.type == "Convolution" || L.type == "ConvolutionDepthWise") {  // depthwise: weights [C][1][kh][kw], in_ch = 1
       const int out_ch = L.ipar(0), kw = L.ipar(1, 1), kh = L.ipar(11, kw), wcount = L.ipar(6);
       LP_CHECK(out_ch > 0 && kw > 0 && wcount > 0 && wcount % (out_ch * kw * kh) == 0, LP_ERR_GRAPH,
                "layer %s: inconsistent convolution parameters", L.name.c_str());

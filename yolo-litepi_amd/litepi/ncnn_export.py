@@ -361,12 +361,12 @@ def seeded_bin_for_param(param_path: str, bin_path: str, seed: int = 1234, gain:
     with open(bin_path, "wb") as f:
         for L in layers:
             p = L["params"]
-            if L["type"] == "Convolution":
+            if L["type"] in ("Convolution", "ConvolutionDepthWise"):
                 out_ch, kw, wcount = int(p[0]), int(p.get(1, 1)), int(p[6])
                 kh = int(p.get(11, kw))
-                in_ch = wcount // (out_ch * kw * kh)
+                in_ch = wcount // (out_ch * kw * kh)  # per group for ConvolutionDepthWise
                 has_bias = int(p.get(5, 0)) != 0
-                if out_ch == 1 and not has_bias and kw == 1:
+                if out_ch == 1 and not has_bias and kw == 1 and L["type"] == "Convolution":
                     w = np.arange(in_ch, dtype=np.float32).reshape(1, in_ch, 1, 1)  # DFL expectation
                 else:
                     w = rng.standard_normal((out_ch, in_ch, kh, kw)).astype(np.float32) * np.float32(gain / np.sqrt(in_ch * kh * kw))
