@@ -158,3 +158,32 @@ def test_shufflenet_oracle_shapes_and_param_count():
     with torch.no_grad():
         y = m(torch.randn(2, 3, 64, 64))
     assert y.shape == (2, 91)
+
+
+def test_oracle_runs_reference_baseline_graphs(tmp_path):
+    """The interpreter covers the op set of the reference's other exported detectors (YOLOv8n, YOLOv5nu with a 6x6 stem,
+    YOLO11n with ConvolutionDepthWise / MatMul / Permute / a second Softmax).  The graph files are staged by
+    __graft_entry__.build() where /root/reference exists; weights are seeded (none ship with the reference)."""
+    import os
+    import sys
+    import numpy as np
+    import pytest
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "yolo-litepi_amd"))
+    from litepi import ncnn_export
+    from oracle import ncnn_ref
+    ran = 0
+    for fam in ("yolo8", "yolo5", "yolo11"):
+        param = os.path.join(root, "oracle", "_ref", f"{fam}_tt100k.param")
+        if not os.path.exists(param):
+            continue
+        binf = str(tmp_path / f"{fam}.bin")
+        ncnn_export.seeded_bin_for_param(param, binf, seed=5)
+        layers = ncnn_ref.load_model(param, binf)
+        out = ncnn_ref.run_graph(layers, torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(0)))["out0"].numpy()
+        assert out.shape == (1, 5, 8400) and np.isfinite(out).all()
+        assert (out[0, 4] > 0).all() and (out[0, 4] < 1).all()
+        ran += 1
+    if ran == 0:
+        pytest.skip("reference graph files not staged")
