@@ -127,7 +127,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from litepi import Engine
-    from litepi.distributed import alloc_result_buffers, gather_detections, records_to_numpy
+    from litepi.distributed import Gatherer, alloc_result_buffers
 
     B = args.batch
     rng = np.random.default_rng(1 + rank)
@@ -155,6 +155,7 @@ def main():
         e.set_stream(st.cuda_stream)
         engs.append(e); streams.append(st); outs.append(alloc_result_buffers(B, args.max_det, dev))
     eng, (dets, counts) = engs[0], outs[0]
+    gatherers = [Gatherer(o, dst=0) for o in outs]   # receive slots allocated once (rank 0), nothing per step
     torch.cuda.synchronize()
     step_no = [0]
 
@@ -165,7 +166,7 @@ def main():
         with torch.cuda.stream(streams[i]):
             engs[i].run_batch_device(imgs.data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
             if world > 1:
-                return gather_detections(d, c, dst=0)
+                return gatherers[i].gather(outs[i])
         return d, c.view(1, -1)
 
     for _ in range(args.warmup):
@@ -189,7 +190,7 @@ def main():
 
     # ---- workload facts (untimed) --------------------------------------------------------------
     kept = counts[:B].sum().item()
-    prefilter = counts[B:].sum().item()
+    prefilter = counts[B:2 * B].sum().item()
 
     # ---- roofline of the dominant kernel family: profiled passes of the same step ---------------
     roofline, families = None, {}

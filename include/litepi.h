@@ -42,11 +42,15 @@ typedef struct lp_config {
   int device;        /* HIP device ordinal */
   int precision;     /* lp_precision: storage/MFMA input type; accumulation is always fp32 */
   int max_batch;     /* images per call (capacity of every activation buffer) */
-  int max_det;       /* detections kept per image after NMS (score order); the reference keeps all */
+  int max_det;       /* detections kept per image after NMS; the reference keeps all (e2e.py:280-296): when more
+                        survive, the max_det highest scores over all classes stay, emitted class-ascending then
+                        score-descending like the reference; set it to the anchor count for keep-all semantics */
   int num_classes;   /* classifier classes (e2e.py:353 default 58) */
   int det_input;     /* detector input size (e2e.py:1040 --det_input_size, 640) */
   int cls_input;     /* classifier input size (e2e.py:1041 --cls_input_size, 64) */
-  int max_rois;      /* ROIs classified per call; 0 = max_batch * min(max_det, 64) */
+  int max_rois;      /* ROIs classified per call; 0 = max_batch * max_det = every kept box, as the reference
+                        (e2e.py:493-497).  A smaller value that a batch exceeds makes lp_run_batch fail with
+                        LP_ERR_STATE instead of leaving detections unclassified silently */
   int conv_impl;     /* 0 = MFMA kernels (product), 1 = naive direct kernels (GPU debug aid) */
   int reserved[7];
 } lp_config;
@@ -108,14 +112,15 @@ int lp_detect(lp_handle* h, const uint8_t* const* imgs, const int* heights, cons
  * (e2e.py:465-473) -> PIL-bilinear 64x64 + normalize (e2e.py:385-389) -> ShuffleNetV2 ->
  * softmax/argmax.  dets [B*max_det]: only boxes that survive the min_area filter;
  * counts [B] their number; num_det [B] (may be NULL) the pre-filter count
- * (PipelineMetrics.num_detections, e2e.py:454). */
+ * (PipelineMetrics.num_detections, e2e.py:454); det_conf_avg [B] (may be NULL) the mean
+ * detector score over the pre-filter boxes (PipelineMetrics.det_confidence_avg, e2e.py:456-457). */
 int lp_run_batch(lp_handle* h, const uint8_t* const* imgs, const int* heights, const int* widths,
                  int B, float conf, float iou, int min_area,
-                 lp_det* dets, int* counts, int* num_det, lp_timing* timing);
+                 lp_det* dets, int* counts, int* num_det, float* det_conf_avg, lp_timing* timing);
 
 /* Same pipeline on B equally sized images already resident in HBM (dev_imgs: uint8 BGR
- * [B,H,W,3]); results stay on the device: dev_dets [B*max_det] lp_det, dev_counts [2*B] int32
- * (kept counts, then pre-filter counts).  Asynchronous on the handle's stream; this is what
+ * [B,H,W,3]); results stay on the device: dev_dets [B*max_det] lp_det, dev_counts [3*B] int32
+ * (kept counts, then pre-filter counts, then the float bits of the mean pre-filter score).  Asynchronous on the handle's stream; this is what
  * bench.py times and what the multi-GPU gather consumes. */
 int lp_run_batch_device(lp_handle* h, const void* dev_imgs, int B, int H, int W,
                         float conf, float iou, int min_area, void* dev_dets, void* dev_counts);
@@ -152,11 +157,18 @@ int lp_debug_blob(lp_handle* h, const char* blob, float* out, int64_t cap, int* 
 int lp_test_conv(lp_handle* h, int impl, const float* x, int N, int Cin, int H, int W,
                  const float* w, const float* bias, int Cout, int k, int stride, int act,
                  const float* res, float* y);
-/* Decode+NMS on a host out0 tensor (tests of the post-processing kernels in isolation):
- * out0 fp32 [4+nc, A], geometry of the original image -> dets/count as lp_detect. */
+/* Decode+NMS(+ROI filter) on a host out0 tensor (tests of the post-processing kernels in isolation):
+ * out0 fp32 [4+nc, A], geometry of the original image -> dets/count as lp_detect.  min_area < 0: no ROI
+ * filter; >= 0: the ROI clip + area filter of e2e.py:465-473, rects [count*4] (may be NULL) receives the int
+ * crop rectangles and num_det (may be NULL) the pre-filter count.  max_det <= 0: keep every survivor. */
 int lp_test_postprocess(lp_handle* h, const float* out0, int nc, int A, int orig_h, int orig_w,
-                        float ratio, float pad_w, float pad_h, float conf, float iou,
-                        lp_det* dets, int* count);
+                        float ratio, float pad_w, float pad_h, float conf, float iou, int min_area, int max_det,
+                        lp_det* dets, int* rects, int* count, int* num_det);
+/* NMS + ROI clip/area filter on host boxes (xyxy, original-image pixels) given directly, bypassing the decode filter:
+ * replays the reference's HybridPipeline.run ROI fixtures (e2e.py:460-485) through the device kernel. */
+int lp_test_nms_boxes(lp_handle* h, const float* boxes, const float* scores, const int* classes, int n,
+                      int orig_h, int orig_w, float iou, int min_area, int max_det,
+                      lp_det* dets, int* rects, int* count, int* num_det);
 /* PIL-exact ROI resize alone: host BGR crops -> uint8 RGB [R,S,S,3]. */
 int lp_test_roi_resize(lp_handle* h, const uint8_t* const* rois, const int* heights,
                        const int* widths, int R, uint8_t* out_rgb);

@@ -175,6 +175,56 @@ def test_postprocess_ties_follow_documented_rule(eng32):
     _check_post(eng32, out0, (640, 640), 1.0, (0.0, 0.0), 0.25, 0.45, eb, es, ec)
 
 
+def test_roi_goldens_through_hip(eng32, golden_dir):
+    """a6: the REFERENCE's own HybridPipeline.run ROI fixtures (tools/make_goldens.py ran e2e.py:460-531 with a fake
+    detector: border clipping, x2 <= x1, areas just under min_area) through nms_kernel's ROI clip / area filter.
+    IoU threshold 1.0 keeps every box (nothing has IoU > 1), so the kernel sees exactly the fixture's 40 boxes; it emits
+    them score-descending, the reference in detector order -> compare after sorting the fixture by score (scores are
+    distinct).  Bit-equal: valid set, int crop rectangles (shapes held by the fixture), bbox truncation, num_detections."""
+    from oracle import postprocess_ref as P
+    g = np.load(os.path.join(golden_dir, "ref_pipeline.npz"))
+    for i in range(4):
+        h, w, ma = (int(v) for v in g[f"c{i}_hw_minarea"])
+        boxes, scores = g[f"c{i}_boxes"], g[f"c{i}_scores"]
+        d, rects, num = eng32.test_nms_boxes(boxes, scores, None, (h, w), 1.0, ma)
+        assert num == int(g[f"c{i}_num_detections"]) == len(boxes)          # counted before the area filter (e2e.py:454)
+        order = np.argsort(-g[f"c{i}_res_det_conf"], kind="stable")
+        assert len(d) == len(order), f"case {i}: {len(d)} valid ROIs vs reference {len(order)}"
+        assert np.array_equal(d["det_conf"].astype(np.float64), g[f"c{i}_res_det_conf"][order])
+        got_bbox = np.stack([d["x1"], d["y1"], d["x2"], d["y2"]], 1).astype(int)      # result-dict bbox (e2e.py:522)
+        assert np.array_equal(got_bbox, g[f"c{i}_res_bbox"][order])
+        shp = g[f"c{i}_roi_shapes"][order]                                              # crops the classifier received
+        assert np.array_equal(rects[:, 3] - rects[:, 1], shp[:, 0]) and np.array_equal(rects[:, 2] - rects[:, 0], shp[:, 1])
+        # the rectangles themselves: the oracle's roi_rects, pinned to the same fixture in the CPU suite
+        er, valid = P.roi_rects(boxes, h, w, ma)
+        eo = np.argsort(-scores[valid], kind="stable")
+        assert np.array_equal(rects.astype(np.int64), er[eo])
+
+
+@pytest.mark.parametrize("nc", [1, 4])
+def test_max_det_overflow_keeps_global_top_scores(eng32, nc):
+    """More NMS survivors than max_det (the reference has no cap, e2e.py:280-296): the max_det best scores over ALL
+    classes stay, in the reference's class-ascending / score-descending order -- not the head of the class-major list."""
+    from oracle import postprocess_ref as P
+    rng = np.random.default_rng(11 + nc)
+    A = 3000
+    out0 = np.zeros((4 + nc, A), np.float32)
+    out0[0] = rng.uniform(20, 2028, A); out0[1] = rng.uniform(20, 2028, A)
+    out0[2] = rng.uniform(6, 30, A); out0[3] = rng.uniform(6, 30, A)
+    sc = rng.permutation(np.linspace(0.05, 0.95, nc * A)).astype(np.float32).reshape(nc, A)   # distinct scores
+    out0[4:] = sc
+    geom = ((2048, 2048), 1.0, (0.0, 0.0))
+    eb, es, ec = P.postprocess(out0, geom[0], geom[1], geom[2], 0.3, 0.45)
+    assert len(eb) > 400
+    for max_det in (100, 257):
+        top = np.sort(np.argsort(-es, kind="stable")[:max_det])       # global top-max_det, kept in the reference's output order
+        d = eng32.test_postprocess(out0, geom[0], geom[1], geom[2], 0.3, 0.45, max_det=max_det)
+        assert len(d) == max_det
+        assert np.array_equal(np.stack([d["x1"], d["y1"], d["x2"], d["y2"]], 1), eb[top].astype(np.float32))
+        assert np.array_equal(d["det_conf"], es[top].astype(np.float32))
+        assert np.array_equal(d["det_class"], ec[top].astype(np.int32))
+
+
 # ---------------------------------------------------------------------------- ROI resize / letterbox
 def test_roi_resize_bit_exact_vs_pillow(eng16):
     from PIL import Image
@@ -437,33 +487,234 @@ def test_pipeline_fp32_matches_oracle(tmp_path):
     assert [r["bbox"] for r in single[0]] == [r["bbox"] for r in outs[0][0]]
 
 
+def _oracle_out0_chunked(layers, imgs_bgr, chunk=8):
+    from oracle import ncnn_ref
+    outs = []
+    for i in range(0, len(imgs_bgr), chunk):
+        x = torch.from_numpy(imgs_bgr[i:i + chunk][..., ::-1].astype(np.float32) * np.float32(1 / 255.0)).permute(0, 3, 1, 2).contiguous()
+        outs.append(ncnn_ref.run_graph(layers, x)["out0"].numpy())
+    return np.concatenate(outs)
+
+
+def _calibrate(param, binf, imgs, per_image):
+    """shift the class-projection biases so that ~per_image anchors per image pass conf 0.25 (threshold placed midway, in
+    logit space, between two neighbouring scores: no anchor sits on it)"""
+    from litepi import ncnn_export
+    from oracle import ncnn_ref
+    ref = _oracle_out0_chunked(ncnn_ref.load_model(param, binf), imgs)
+    s = np.sort(ref[:, 4:].max(axis=1).astype(np.float64).ravel())[::-1]
+    k = per_image * len(imgs)
+    logit = 0.5 * (np.log(s[k - 1] / (1 - s[k - 1])) + np.log(s[k] / (1 - s[k])))
+    ncnn_export.shift_cls_bias(param, binf, float(np.log(0.25 / 0.75) - logit))
+
+
+def _box_match(b, e, slack_px=4.0):
+    return np.abs(np.asarray(b, np.float64) - np.asarray(e, np.float64)).max() <= slack_px + 0.02 * np.abs(np.asarray(e, np.float64)).max()
+
+
+def _stable_oracle_boxes(out0, hw, conf, iou, min_area, rng, trials=12, band=0.02):
+    """Oracle post-NMS boxes (score > conf + band, area filter passed) whose presence does not hinge on a near-tie: the
+    box must survive `trials` re-runs of the oracle's postprocess on out0 perturbed by the documented fp16 error scale
+    (scores +-0.015, box centres / sizes +-2 px).  What is left is what an fp16 detector has no excuse to miss; a box
+    that an NMS order swap or an IoU within a hair of the threshold can remove is excluded -- that, and the +-band around
+    the conf threshold, is the documented exclusion zone of the fp16 comparison."""
+    from oracle import postprocess_ref as P
+    eb, es, _ = P.postprocess(out0, hw, 1.0, (0.0, 0.0), conf, iou)
+    if len(eb) == 0:
+        return []
+    _, valid = P.roi_rects(eb, hw[0], hw[1], min_area)
+    keep = [i for i in valid if es[i] > conf + band]
+    alive = {i: True for i in keep}
+    for _ in range(trials):
+        o = out0.copy()
+        o[4:] = np.clip(o[4:] + rng.uniform(-0.015, 0.015, o[4:].shape).astype(np.float32), 0, 1)
+        o[:4] += rng.uniform(-2.0, 2.0, o[:4].shape).astype(np.float32)
+        pb, _, _ = P.postprocess(o, hw, 1.0, (0.0, 0.0), conf, iou)
+        for i in keep:
+            if alive[i] and not any(_box_match(q, eb[i], 6.0) for q in pb):
+                alive[i] = False
+    return [(eb[i], float(es[i])) for i in keep if alive[i]]
+
+
+def _check_fp16_against_oracle(pipe, layers, cls_model, imgs, conf=0.25, iou=0.45, min_area=50):
+    """Shared body of the fp16 end-to-end checks (configs[2] numerics).  For every image:
+      1. out0 within the documented fp16 bound of the fp32 oracle;
+      2. decisions are EXACT given the device's own out0: the oracle's postprocess + ROI filter on it reproduce the
+         device's records bit for bit (boxes, scores, order, counts);
+      3. classifier parity on identical pixels: the oracle's ShuffleNetV2 on the crop the device took;
+      4. zero misses: every stable oracle (fp32) box with score > conf + 0.02 is found; nothing is invented.
+    Returns a dict of achieved maxima for printing."""
+    from oracle import postprocess_ref as P, shufflenet_ref as S
+    B = len(imgs)
+    ref0 = _oracle_out0_chunked(layers, imgs)
+    got0 = pipe.engine.detect_raw(imgs)
+    stride = np.concatenate([np.full(6400, 8.0), np.full(1600, 16.0), np.full(400, 32.0)]).astype(np.float32)
+    err_s = np.abs(got0[:, 4] - ref0[:, 4])
+    err_b = np.abs(got0[:, :4] - ref0[:, :4])
+    assert err_s.max() <= 0.02, f"score row: {err_s.max()}"
+    assert (err_b <= 0.35 * stride + 0.02 * np.abs(ref0[:, :4])).all(), f"box rows: {err_b.max()}"
+    assert err_b.mean() <= 0.5
+    outs = pipe.run_batch(list(imgs), conf, iou, min_area)
+    rng = np.random.default_rng(99)
+    stat = dict(score_err=float(err_s.max()), box_err=float(err_b.max()), box_err_mean=float(err_b.mean()), boxes=0, stable=0, missed=0,
+                cls_checked=0, cls_flips_in_margin=0, prob_err=0.0)
+    for i in range(B):
+        res, met = outs[i]
+        hw = imgs[i].shape[:2]
+        # 2. exact decisions on the device's own out0
+        eb, es, ec = P.postprocess(got0[i], hw, 1.0, (0.0, 0.0), conf, iou)
+        assert met.num_detections == len(eb), f"image {i}: num_detections {met.num_detections} vs {len(eb)}"
+        rects, valid = P.roi_rects(eb, hw[0], hw[1], min_area)
+        assert len(res) == len(valid), f"image {i}: {len(res)} results vs {len(valid)}"
+        for r, k in zip(res, valid):
+            assert r["bbox"] == tuple(eb[k].astype(int)) and r["det_conf"] == float(es[k]) and r["det_class"] == int(ec[k])
+        if len(eb):
+            assert abs(met.det_confidence_avg - float(np.mean(es))) <= 1e-6
+        stat["boxes"] += len(res)
+        # 3. classifier on the very crop the device classified
+        if len(valid):
+            crops = [imgs[i][y1:y2, x1:x2] for x1, y1, x2, y2 in rects]
+            ids, probs = S.predict_batch(cls_model, crops)
+            for r, cid, pr in zip(res, ids, probs):
+                top2 = np.sort(pr)[-2:]
+                stat["cls_checked"] += 1
+                stat["prob_err"] = max(stat["prob_err"], abs(r["cls_conf"] - float(pr[r["cls_class"]])))
+                assert r["cls_class"] >= 0
+                assert abs(r["cls_conf"] - float(pr[r["cls_class"]])) <= 3e-2
+                if r["cls_class"] != int(cid):
+                    assert top2[1] - top2[0] < 6e-2, f"image {i}: argmax {r['cls_class']} vs {cid}, margin {top2[1] - top2[0]}"
+                    stat["cls_flips_in_margin"] += 1
+        # 4. fp32 oracle boxes that an fp16 detector must find
+        stable = _stable_oracle_boxes(ref0[i], hw, conf, iou, min_area, rng)
+        stat["stable"] += len(stable)
+        fboxes = [np.array([d for d in r["bbox"]], np.float64) for r in res]
+        for box, sc in stable:
+            hit = any(_box_match(fb, box.astype(int)) and abs(r["det_conf"] - sc) <= 0.02 for fb, r in zip(fboxes, res))
+            stat["missed"] += 0 if hit else 1
+        # nothing invented: a confident device box sits on an oracle candidate (pre-NMS, score > conf - band)
+        cb, cs, _ = P.postprocess(ref0[i], hw, 1.0, (0.0, 0.0), conf - 0.02, 1.0)   # iou 1.0: every candidate survives
+        for fb, r in zip(fboxes, res):
+            if r["det_conf"] > conf + 0.02:
+                assert any(_box_match(fb, q.astype(int)) for q in cb), f"image {i}: device box {r['bbox']} has no oracle candidate"
+    assert stat["missed"] == 0, f"{stat['missed']} of {stat['stable']} stable oracle boxes missed"
+    return stat
+
+
 def test_pipeline_fp16_close_to_oracle(tmp_path):
-    """configs[2] numerics: fp16 path.  Post-NMS sets must match the CPU fp32 path except for
-    candidates whose score is within 0.02 of the conf threshold (documented exclusion band)."""
-    from litepi import HybridPipeline
-    from oracle import ncnn_ref, pipeline_ref, shufflenet_ref as S
-    p, b, imgs = _calibrated_model(tmp_path)
+    """configs[2] numerics at a small capacity: 16 images, ZERO misses (see _check_fp16_against_oracle for the four
+    checks and the documented exclusion zone: +-0.02 around conf and boxes that a near-tie can flip)."""
+    from litepi import HybridPipeline, ncnn_export
+    from oracle import ncnn_ref, shufflenet_ref as S
+    p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    ncnn_export.export_detector(p, b, "v1", seed=77, cls_bias=0.0)
+    imgs = np.random.default_rng(123).integers(0, 256, (16, 640, 640, 3), dtype=np.uint8)
+    _calibrate(p, b, imgs[:8], 8)
     sd = S.seeded_state_dict(91)
     cls_path = str(tmp_path / "cls.pth")
     torch.save(sd, cls_path)
-    cpu = pipeline_ref.CpuPipeline(ncnn_ref.load_model(p, b), S.build(91, sd))
+    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=16, max_det=300)
+    try:
+        st = _check_fp16_against_oracle(pipe, ncnn_ref.load_model(p, b), S.build(91, sd), imgs)
+    finally:
+        pipe.engine.close()
+    print(f"fp16 B=16: {st}")
+    assert st["stable"] >= 16
+
+
+@pytest.mark.parametrize("preset", ["v1", "v2"])
+def test_bench_configuration_fp16_capacity64(tmp_path, preset):
+    """The EXACT configuration bench.py times (BASELINE.json configs[2]): Engine(precision='fp16', max_batch=64,
+    max_det=300, num_classes=91), 64 distinct images in one call -- the tile / split / fusion plan depends on the
+    capacity, so these are the kernel instantiations of the benchmark (bottleneck_mfma f16, stem_block, conv3x3_mfma f16
+    NT variants, the fused classifier).  Every image is checked against the oracle: out0 bounds, exact decisions,
+    classifier on identical crops, zero missed stable boxes."""
+    from litepi import HybridPipeline, ncnn_export
+    from oracle import ncnn_ref, shufflenet_ref as S
+    p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    ncnn_export.export_detector(p, b, preset, seed=1234, cls_bias=0.0)
+    imgs = np.random.default_rng(1).integers(0, 256, (64, 640, 640, 3), dtype=np.uint8)
+    _calibrate(p, b, imgs[:8], 8)
+    sd = S.seeded_state_dict(91)
+    cls_path = str(tmp_path / "cls.pth")
+    torch.save(sd, cls_path)
+    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=64, max_det=300)
+    try:
+        st = _check_fp16_against_oracle(pipe, ncnn_ref.load_model(p, b), S.build(91, sd), imgs)
+    finally:
+        pipe.engine.close()
+    print(f"bench config {preset} fp16 capacity 64: {st}")
+    assert st["boxes"] >= 64 and st["stable"] >= 32
+
+
+def test_every_roi_is_classified_beyond_64_per_image(tmp_path):
+    """The reference classifies EVERY kept box (e2e.py:493-497).  Two images with far more than 64 ROIs each through one
+    B = 2 call: no cls_class == -1, counts agree with the oracle on the device's out0, and a max_rois that is too small
+    is an error, not a silent -1."""
+    from litepi import HybridPipeline, _ffi, ncnn_export
+    from oracle import postprocess_ref as P, shufflenet_ref as S
+    p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    ncnn_export.export_detector(p, b, "v1", seed=77, cls_bias=0.0)
+    imgs = np.random.default_rng(321).integers(0, 256, (2, 640, 640, 3), dtype=np.uint8)
+    _calibrate(p, b, imgs, 700)
+    sd = S.seeded_state_dict(91)
+    cls_path = str(tmp_path / "cls.pth")
+    torch.save(sd, cls_path)
     pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=2, max_det=300)
     try:
-        outs = pipe.run_batch([imgs[0], imgs[1]], 0.25, 0.45, 50)
+        got0 = pipe.engine.detect_raw(imgs)
+        outs = pipe.run_batch(list(imgs), 0.25, 0.45, 50)
     finally:
         pipe.engine.close()
     for i in range(2):
-        exp, _ = cpu.run(imgs[i], 0.25, 0.45, 50)
-        res = outs[i][0]
-        strong_exp = [x for x in exp if x["det_conf"] > 0.27]
-        matched = 0
-        for x in strong_exp:
-            for r in res:
-                if np.abs(np.array(r["bbox"]) - np.array(x["bbox"])).max() <= 4 and abs(r["det_conf"] - x["det_conf"]) < 0.02:
-                    matched += 1
-                    break
-        assert matched >= len(strong_exp) - 1, f"image {i}: matched {matched} of {len(strong_exp)} confident oracle boxes"
-        assert len([r for r in res if r["det_conf"] > 0.27]) <= len(exp) + 1
+        res, met = outs[i]
+        eb, es, _ = P.postprocess(got0[i], (640, 640), 1.0, (0.0, 0.0), 0.25, 0.45)
+        top = np.sort(np.argsort(-es, kind="stable")[:300])
+        _, valid = P.roi_rects(eb[top], 640, 640, 50)
+        assert len(res) == len(valid) and len(res) > 64, f"image {i}: {len(res)} ROIs (oracle {len(valid)})"
+        assert all(r["cls_class"] >= 0 and r["cls_conf"] > 0 for r in res)
+    small = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=2, max_det=300, max_rois=64)
+    try:
+        with pytest.raises(_ffi.LitepiError) as ei:
+            small.run_batch(list(imgs), 0.25, 0.45, 50)
+        assert ei.value.code == _ffi.LP_ERR_STATE and "max_rois" in str(ei.value)
+    finally:
+        small.engine.close()
+
+
+def test_head_projection_logits_fp32(synth_models):
+    """north_star words the fp32 tolerance as '1e-3 on logits': the six Detect-head projection outputs (class logits
+    and DFL box logits of the three levels, before sigmoid / softmax) against the oracle, abs + rel 1e-3."""
+    from litepi import Engine
+    from litepi.ncnn_io import read_param_layers
+    from oracle import ncnn_ref
+    for preset in ("v1", "v2"):
+        param, binf = synth_models[preset]
+        layers = read_param_layers(param)
+        heads = []
+        prod = {l["outputs"][0]: l for l in layers}
+        for l in layers:
+            if l["type"] == "Concat" and len(l["inputs"]) == 2 and all(prod.get(x, {}).get("type") == "Convolution" for x in l["inputs"]):
+                nxt = [m for m in layers if l["outputs"][0] in m["inputs"]]
+                if nxt and nxt[0]["type"] == "Reshape":
+                    heads += l["inputs"]
+        assert len(heads) == 6
+        imgs = np.random.default_rng(4).integers(0, 256, (1, 640, 640, 3), dtype=np.uint8)
+        ol = ncnn_ref.load_model(param, binf)
+        x = torch.from_numpy(imgs[..., ::-1].astype(np.float32) * np.float32(1 / 255.0)).permute(0, 3, 1, 2).contiguous()
+        ref = ncnn_ref.run_graph(ol, x, keep=heads)
+        e = Engine(precision="fp32", max_batch=1)
+        try:
+            e.load_detector(param, binf)
+            e.detect_raw(imgs)
+            worst = 0.0
+            for n in heads:
+                got, want = e.debug_blob(n), ref[n].numpy()
+                err = np.abs(got - want)
+                worst = max(worst, float(err.max()))
+                assert (err <= 1e-3 + 1e-3 * np.abs(want)).all(), f"{preset} blob {n}: max logit err {err.max()}"
+        finally:
+            e.close()
+        print(f"{preset} fp32 head logits: max abs err {worst:.2e}")
 
 
 def test_config4_large_images_map_vs_cpu(tmp_path):
@@ -537,6 +788,11 @@ def test_empty_and_error_behaviour(synth_models, tmp_path):
         img = np.zeros((480, 640, 3), np.uint8)
         boxes, scores, cls = det.detect(img, 0.999, 0.45)
         assert boxes.shape == (0, 4) and boxes.dtype == np.float64 and scores.shape == (0,) and cls.shape == (0,)
+        # misuse is an error, not "no detections": only an engine (HIP) failure maps to the reference's empty result
+        from litepi import _ffi
+        with pytest.raises(_ffi.LitepiError) as ei:
+            det.detect_batch([img, img], 0.25, 0.45)          # capacity is max_batch = 1
+        assert ei.value.code == _ffi.LP_ERR_ARG
     finally:
         det.engine.close()
     clf = PyTorchClassifier(str(tmp_path / "none.pth"), "shufflenetv2", num_classes=49)

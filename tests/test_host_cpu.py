@@ -86,50 +86,76 @@ def _free_port():
 
 
 def _gather_worker(rank, world, port, q):
+    """One rank of the N>1 path on CPU (gloo): uneven image shards (shard_range), one fixed-capacity payload per rank,
+    a Gatherer allocated once and used for several steps, max_det overflow (a shard whose images all saturate)."""
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "yolo-litepi_amd"))
-    from litepi.distributed import alloc_result_buffers, gather_detections, records_to_numpy
+    from litepi.distributed import COUNT_WORDS, Gatherer, alloc_result_buffers, records_to_numpy, shard_range
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    B, max_det = 3, 5
-    dets, counts = alloc_result_buffers(B, max_det, "cpu")
-    rec = records_to_numpy(dets)            # a copy; fill a structured array and write it back
-    rec = np.zeros((B, max_det), dtype=rec.dtype)
-    for b in range(B):
-        n = (rank + b) % (max_det + 1)
-        counts[b] = n
-        counts[B + b] = n + 1
-        for k in range(n):
-            rec[b, k] = (rank, b, k, 0.5, 0.9 - 0.1 * k, 0, rank * 10 + k, 0.75)
-    dets.copy_(torch.from_numpy(rec.view(np.uint8).reshape(B, max_det, 32)))
-    out = gather_detections(dets, counts, dst=0)
-    if rank == 0:
+    total_images, max_det = 4 * world + 3, 5           # not a multiple of world: shards differ by one image
+    cap = -(-total_images // world)                    # every rank sends the same fixed-capacity message
+    lo, hi = shard_range(total_images, rank, world)
+
+    def fill(buf, step):
+        rec = np.zeros((cap, max_det), dtype=records_to_numpy(buf.dets).dtype)
+        buf.payload.zero_()
+        for b in range(hi - lo):
+            g = lo + b                                  # global image id
+            n = max_det if g % 4 == 0 else (g + step) % (max_det + 1)   # every 4th image saturates max_det (overflow case)
+            buf.counts[b] = n
+            buf.counts[cap + b] = min(n + 1, max_det)
+            buf.counts[2 * cap + b] = int(np.float32(0.5 + 0.01 * g).view(np.int32))
+            for k in range(n):
+                rec[b, k] = (g, step, k, 0.5, 0.9 - 0.1 * k, 0, g * 10 + k, 0.75)
+        buf.dets.copy_(torch.from_numpy(rec.view(np.uint8).reshape(cap, max_det, 32)))
+
+    buf = alloc_result_buffers(cap, max_det, "cpu")
+    gat = Gatherer(buf, dst=0)
+    ok = True
+    recv_ptr = None
+    for step in range(3):
+        fill(buf, step)
+        out = gat.gather(buf)
+        if rank != 0:
+            ok = ok and out is None
+            continue
         all_dets, all_counts = out
+        ok = ok and tuple(all_dets.shape) == (world, cap, max_det, 32) and tuple(all_counts.shape) == (world, COUNT_WORDS * cap)
+        ok = ok and all_dets.data_ptr() == gat.recv.data_ptr()      # views of the receive buffer: nothing allocated per step
+        recv_ptr = recv_ptr or gat.recv.data_ptr()
+        ok = ok and recv_ptr == gat.recv.data_ptr()
         r = records_to_numpy(all_dets)
-        ok = all_dets.shape == (world * B, max_det, 32) and all_counts.shape == (world, 2 * B)
+        seen = 0
         for src in range(world):
-            for b in range(B):
-                n = (src + b) % (max_det + 1)
-                ok = ok and int(all_counts[src, b]) == n and int(all_counts[src, B + b]) == n + 1
+            slo, shi = shard_range(total_images, src, world)
+            for b in range(shi - slo):
+                g = slo + b
+                n = max_det if g % 4 == 0 else (g + step) % (max_det + 1)
+                ok = ok and int(all_counts[src, b]) == n and int(all_counts[src, cap + b]) == min(n + 1, max_det)
+                ok = ok and np.int32(int(all_counts[src, 2 * cap + b])).view(np.float32) == np.float32(0.5 + 0.01 * g)
                 for k in range(n):
-                    e = r[src * B + b, k]
-                    ok = ok and e["x1"] == src and e["y1"] == b and e["x2"] == k and e["cls_class"] == src * 10 + k
-        q.put(ok)
-    else:
-        q.put(out is None)
+                    e = r[src, b, k]
+                    ok = ok and e["x1"] == g and e["y1"] == step and e["x2"] == k and e["cls_class"] == g * 10 + k
+                seen += 1
+            for b in range(shi - slo, cap):              # padding slots of a short shard stay empty
+                ok = ok and int(all_counts[src, b]) == 0
+        ok = ok and seen == total_images
+    q.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_of_detection_records_gloo():
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_gather_of_detection_records_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -138,9 +164,12 @@ def test_two_rank_gather_of_detection_records_gloo():
 
 def test_single_process_gather_is_identity():
     from litepi.distributed import alloc_result_buffers, gather_detections
-    dets, counts = alloc_result_buffers(2, 4, "cpu")
+    buf = alloc_result_buffers(2, 4, "cpu")
+    d, c = gather_detections(buf)
+    assert d.data_ptr() == buf.dets.data_ptr() and d.shape == (1, 2, 4, 32) and c.shape == (1, 6)
+    dets, counts = buf
     d, c = gather_detections(dets, counts)
-    assert d is dets and c.shape == (1, 4)
+    assert d.data_ptr() == dets.data_ptr() and c.shape == (1, 6)
 
 
 def test_random_shufflenet_state_matches_torchvision_layout():

@@ -23,7 +23,7 @@ for conf in (0.25, 0.05, 0.001):
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(10): e.run_batch_device(imgs.data_ptr(), B, 640, 640, conf, 0.45, 50, dets.data_ptr(), counts.data_ptr())
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
-    print(f"conf {conf}: {dt*1e3:.2f} ms/step, kept {int(counts[:B].sum())} rois, pre-filter {int(counts[B:].sum())}")
+    print(f"conf {conf}: {dt*1e3:.2f} ms/step, kept {int(counts[:B].sum())} rois, pre-filter {int(counts[B:2 * B].sum())}")
 
 # per-launch profile of one stressed step (HIP events), top entries
 with torch.cuda.stream(st):

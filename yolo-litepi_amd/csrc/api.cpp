@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 
 #include "classifier.h"
 #include "common.h"
@@ -68,6 +70,19 @@ float f16_to_f32(uint16_t h) {
   return f;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device attribute: set it once per (device, kernel) and
+// check the result (a kernel that needs more than 64 KB of LDS fails to launch without it)
+void set_max_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  LP_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({dev, fn})) return;
+  LP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, fn});
+}
+
 // letterbox geometry exactly as the reference computes it in Python doubles (e2e.py:72-83);
 // Python's round() is round-half-to-even == nearbyint in the default rounding mode.
 static ImgGeom make_geom(int h, int w, int S, long src_off) {
@@ -104,7 +119,7 @@ struct lp_handle {
 
   RoiTable roi_table() {
     RoiTable t;
-    t.base = d_roi_base.as<int>(); t.total = d_roi_total.as<int>();
+    t.base = d_roi_base.as<int>(); t.total = d_roi_total.as<int>(); t.work = d_roi_total.as<int>() + 4;
     t.img = d_roi_img.as<int>(); t.slot = d_roi_slot.as<int>();
     return t;
   }
@@ -117,7 +132,7 @@ struct lp_handle {
     d_sorted.alloc((size_t)B * A * sizeof(Cand), false);
     d_cand_count.alloc((size_t)B * 4);
     d_dets.alloc((size_t)B * cfg.max_det * sizeof(lp_det));
-    d_counts.alloc((size_t)2 * B * 4);
+    d_counts.alloc((size_t)3 * B * 4);
     d_rects.alloc((size_t)B * cfg.max_det * 16);
     d_out0.alloc((size_t)B * (4 + nc) * A * 4, false);
   }
@@ -169,7 +184,8 @@ int lp_create(const lp_config* cfg, lp_handle** out) {
     throw Error(LP_ERR_NODEVICE, fmt("device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName));
   std::unique_ptr<lp_handle> h(new lp_handle());
   h->cfg = *cfg;
-  h->max_rois = cfg->max_rois > 0 ? cfg->max_rois : cfg->max_batch * std::min(cfg->max_det, 64);
+  // every kept box is a ROI (the reference classifies all of them, e2e.py:493-497): the default capacity can not overflow
+  h->max_rois = cfg->max_rois > 0 ? cfg->max_rois : cfg->max_batch * cfg->max_det;
   LP_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   for (auto& e : h->ev) LP_HIP(hipEventCreate(&e));
@@ -177,7 +193,7 @@ int lp_create(const lp_config* cfg, lp_handle** out) {
   const int S = cfg->det_input;
   h->d_lb.alloc((size_t)cfg->max_batch * S * S * 3, false);
   h->d_roi_base.alloc((size_t)(cfg->max_batch + 1) * 4);
-  h->d_roi_total.alloc(16);
+  h->d_roi_total.alloc(32);  // total, unclamped total | accumulator, ticket (kernels.h RoiTable)
   h->d_roi_img.alloc((size_t)h->max_rois * 4);
   h->d_roi_slot.alloc((size_t)h->max_rois * 4);
   const int cs = cfg->cls_input;
@@ -310,30 +326,28 @@ void enqueue_detect(lp_handle* h, const uint8_t* src, const std::vector<ImgGeom>
   h->det->forward(img, B, h->d_geom.as<ImgGeom>(), conf, out0, h->d_cand.as<Cand>(), h->d_cand_count.as<int>(), h->stream, prof);
 }
 
-void enqueue_nms(lp_handle* h, int B, float iou, int min_area, lp_det* dets, int* counts, Profiler* prof) {
+// NMS + ROI rectangles; with_rois: also the batch-wide ROI list the classifier stage consumes
+void enqueue_nms(lp_handle* h, int B, float iou, int min_area, lp_det* dets, int* counts, bool with_rois, Profiler* prof) {
   NmsArgs a;
+  memset(&a, 0, sizeof(a));
   a.cand = h->d_cand.as<Cand>(); a.cand_count = h->d_cand_count.as<int>(); a.sorted = h->d_sorted.as<Cand>();
   a.dets = dets; a.counts = counts; a.rects = h->d_rects.as<int>(); a.geom = h->d_geom.as<ImgGeom>();
-  a.A = h->det->num_anchors(); a.max_det = h->cfg.max_det; a.iou = iou; a.min_area = min_area;
+  a.A = h->det->num_anchors(); a.max_det = h->cfg.max_det; a.nc = h->det->num_classes(); a.iou = iou; a.min_area = min_area;
+  if (with_rois) a.tab = h->roi_table();
+  a.max_rois = h->max_rois;
   if (prof) prof->begin(h->stream);
   launch_nms(a, B, h->stream);
   if (prof) prof->end(h->stream, "nms", "nms", 0.0, 0.0);
 }
 
-// ROI table + PIL resize + ShuffleNetV2 + softmax; scatters (cls, conf) into dets when given
-void enqueue_classify(lp_handle* h, const uint8_t* src, int B, const int* counts, lp_det* dets, float* probs, int* ids,
-                      float* conf, Profiler* prof) {
+// PIL resize + ShuffleNetV2 + softmax over the ROI list; scatters (cls, conf) into dets when given
+void enqueue_classify(lp_handle* h, const uint8_t* src, int B, lp_det* dets, float* probs, int* ids, float* conf, Profiler* prof) {
   RoiTable tab = h->roi_table();
-  if (counts) {
-    if (prof) prof->begin(h->stream);
-    launch_roi_index(counts, tab, B, h->cfg.max_det, h->max_rois, h->stream);
-    if (prof) prof->end(h->stream, "roi_index", "roi_index", 0.0, 0.0);
-  }
   RoiResizeArgs r;
   r.src = src; r.geom = h->d_geom.as<ImgGeom>(); r.rects = h->d_rects.as<int>(); r.tab = tab;
   r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = h->cfg.max_det; r.S = h->cfg.cls_input;
   if (prof) prof->begin(h->stream);
-  launch_roi_resize(r, h->stream);
+  launch_roi_resize(r, std::min(h->max_rois, B * h->cfg.max_det), h->stream);
   if (prof) prof->end(h->stream, "roi_resize_pil", "roi_resize", 0.0, (double)r.S * r.S * 3 * 2, true);
   Classifier::Post post;
   post.probs = probs; post.ids = ids; post.dets = dets; post.max_det = h->cfg.max_det; post.roi_img = tab.img; post.roi_slot = tab.slot;
@@ -400,7 +414,7 @@ int lp_detect(lp_handle* h, const uint8_t* const* imgs, const int* hs, const int
   h->upload_geom(g);
   Profiler* prof = begin_profile(h);
   enqueue_detect(h, h->d_src.as<uint8_t>(), g, B, conf, nullptr, prof);
-  enqueue_nms(h, B, iou, -1, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), prof);
+  enqueue_nms(h, B, iou, -1, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), false, prof);
   LP_HIP(hipMemcpyAsync(dets, h->d_dets.p, (size_t)B * h->cfg.max_det * sizeof(lp_det), hipMemcpyDeviceToHost, h->stream));
   LP_HIP(hipMemcpyAsync(counts, h->d_counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
   LP_HIP(hipStreamSynchronize(h->stream));
@@ -409,7 +423,7 @@ int lp_detect(lp_handle* h, const uint8_t* const* imgs, const int* hs, const int
 }
 
 int lp_run_batch(lp_handle* h, const uint8_t* const* imgs, const int* hs, const int* ws, int B, float conf, float iou,
-                 int min_area, lp_det* dets, int* counts, int* num_det, lp_timing* timing) {
+                 int min_area, lp_det* dets, int* counts, int* num_det, float* det_conf_avg, lp_timing* timing) {
   LP_API_BEGIN
   LP_CHECK(h && imgs && hs && ws && dets && counts, LP_ERR_ARG, "null argument");
   LP_CHECK(h->det && h->det->loaded(), LP_ERR_STATE, "detector not loaded");
@@ -423,30 +437,35 @@ int lp_run_batch(lp_handle* h, const uint8_t* const* imgs, const int* hs, const 
   LP_HIP(hipEventRecord(h->ev[0], h->stream));
   enqueue_detect(h, h->d_src.as<uint8_t>(), g, B, conf, nullptr, prof);
   LP_HIP(hipEventRecord(h->ev[1], h->stream));
-  enqueue_nms(h, B, iou, min_area, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), prof);
+  enqueue_nms(h, B, iou, min_area, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), true, prof);
   LP_HIP(hipEventRecord(h->ev[2], h->stream));
-  enqueue_classify(h, h->d_src.as<uint8_t>(), B, h->d_counts.as<int>(), h->d_dets.as<lp_det>(), nullptr, nullptr, nullptr, prof);
+  enqueue_classify(h, h->d_src.as<uint8_t>(), B, h->d_dets.as<lp_det>(), nullptr, nullptr, nullptr, prof);
   LP_HIP(hipEventRecord(h->ev[3], h->stream));
   LP_HIP(hipMemcpyAsync(dets, h->d_dets.p, (size_t)B * h->cfg.max_det * sizeof(lp_det), hipMemcpyDeviceToHost, h->stream));
-  std::vector<int> cnt(2 * B);
-  LP_HIP(hipMemcpyAsync(cnt.data(), h->d_counts.p, (size_t)2 * B * 4, hipMemcpyDeviceToHost, h->stream));
-  int R = 0;
-  LP_HIP(hipMemcpyAsync(&R, h->d_roi_total.p, 4, hipMemcpyDeviceToHost, h->stream));
+  std::vector<int> cnt(3 * B);
+  LP_HIP(hipMemcpyAsync(cnt.data(), h->d_counts.p, (size_t)3 * B * 4, hipMemcpyDeviceToHost, h->stream));
+  int R[2] = {0, 0};
+  LP_HIP(hipMemcpyAsync(R, h->d_roi_total.p, 8, hipMemcpyDeviceToHost, h->stream));
   LP_HIP(hipStreamSynchronize(h->stream));
   for (int i = 0; i < B; ++i) {
     counts[i] = cnt[i];
     if (num_det) num_det[i] = cnt[B + i];
+    if (det_conf_avg) memcpy(&det_conf_avg[i], &cnt[2 * B + i], 4);
   }
-  h->last_roi_count = R;
+  h->last_roi_count = R[0];
   if (timing) {
-    // NMS + ROI rectangle are one kernel here; the reference books NMS under detection and the
-    // ROI loop under t_roi_extract (e2e.py:452-475)
+    // the detector's decode + NMS are booked under detection like the reference's detect() (e2e.py:452-453); the ROI
+    // rectangles come out of the NMS kernel, the crop + PIL resize is the device's share of the ROI loop (e2e.py:460-475)
     (void)hipEventElapsedTime(&timing->t_detection, h->ev[0], h->ev[2]);
     timing->t_roi_extract = 0.f;
     (void)hipEventElapsedTime(&timing->t_classification, h->ev[2], h->ev[3]);
     (void)hipEventElapsedTime(&timing->t_total, h->ev[0], h->ev[3]);
   }
-  if (prof) { prof->collect(R); prof->enabled = false; }
+  if (prof) { prof->collect(R[0]); prof->enabled = false; }
+  // every kept ROI must have been classified (the reference classifies all of them): a user-set max_rois that was too
+  // small is an error, not a silent cls_class = -1
+  LP_CHECK(R[1] <= h->max_rois, LP_ERR_STATE, "%d ROIs in this batch exceed max_rois = %d: %d detections were left unclassified", R[1],
+           h->max_rois, R[1] - h->max_rois);
   LP_API_END
 }
 
@@ -464,9 +483,8 @@ int lp_run_batch_device(lp_handle* h, const void* dev_imgs, int B, int H, int W,
   const uint8_t* src = static_cast<const uint8_t*>(dev_imgs);
   enqueue_detect(h, src, g, B, conf, nullptr, prof);
   const bool classify = h->cls && h->cls->loaded();
-  enqueue_nms(h, B, iou, classify ? min_area : -1, static_cast<lp_det*>(dev_dets), static_cast<int*>(dev_counts), prof);
-  if (classify)
-    enqueue_classify(h, src, B, static_cast<int*>(dev_counts), static_cast<lp_det*>(dev_dets), nullptr, nullptr, nullptr, prof);
+  enqueue_nms(h, B, iou, classify ? min_area : -1, static_cast<lp_det*>(dev_dets), static_cast<int*>(dev_counts), classify, prof);
+  if (classify) enqueue_classify(h, src, B, static_cast<lp_det*>(dev_dets), nullptr, nullptr, nullptr, prof);
   if (prof) prof->enabled = false;  // records are collected by lp_profile_read after the caller synchronises
   LP_API_END
 }
@@ -512,7 +530,7 @@ int lp_classify(lp_handle* h, const uint8_t* const* rois, const int* hs, const i
   RoiResizeArgs r;
   r.src = h->d_src.as<uint8_t>(); r.geom = h->d_geom.as<ImgGeom>(); r.rects = d_rects_tmp.as<int>(); r.tab = tab;
   r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = 1; r.S = h->cfg.cls_input;
-  launch_roi_resize(r, h->stream);
+  launch_roi_resize(r, R, h->stream);
   Classifier::Post post;
   post.probs = h->d_probs.as<float>(); post.ids = h->d_ids.as<int>();
   h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof, &post);
@@ -616,7 +634,8 @@ int lp_test_conv(lp_handle* h, int impl, const float* x, int N, int Cin, int H, 
 }
 
 int lp_test_postprocess(lp_handle* h, const float* out0, int nc, int A, int orig_h, int orig_w, float ratio, float pad_w,
-                        float pad_h, float conf, float iou, lp_det* dets, int* count) {
+                        float pad_h, float conf, float iou, int min_area, int max_det, lp_det* dets, int* rects, int* count,
+                        int* num_det) {
   LP_API_BEGIN
   LP_CHECK(h && out0 && dets && count && nc >= 1 && A >= 1 && A <= 16384, LP_ERR_ARG, "bad argument");
   LP_HIP(hipSetDevice(h->cfg.device));
@@ -629,17 +648,64 @@ int lp_test_postprocess(lp_handle* h, const float* out0, int nc, int A, int orig
   d_geom.alloc(sizeof(g));
   LP_HIP(hipMemcpy(d_geom.p, &g, sizeof(g), hipMemcpyHostToDevice));
   d_cand.alloc((size_t)A * sizeof(Cand)); d_sorted.alloc((size_t)A * sizeof(Cand)); d_cnt.alloc(16);
-  const int max_det = A;
+  if (max_det <= 0 || max_det > A) max_det = A;  // the reference keeps every survivor
   d_dets.alloc((size_t)max_det * sizeof(lp_det)); d_counts.alloc(16); d_rects.alloc((size_t)max_det * 16);
   launch_filter_out0(d_out0.as<float>(), nc, A, d_geom.as<ImgGeom>(), d_cand.as<Cand>(), d_cnt.as<int>(), conf, 1, h->stream);
   NmsArgs a;
+  memset(&a, 0, sizeof(a));
   a.cand = d_cand.as<Cand>(); a.cand_count = d_cnt.as<int>(); a.sorted = d_sorted.as<Cand>(); a.dets = d_dets.as<lp_det>();
-  a.counts = d_counts.as<int>(); a.rects = d_rects.as<int>(); a.geom = d_geom.as<ImgGeom>(); a.A = A; a.max_det = max_det;
-  a.iou = iou; a.min_area = -1;
+  a.counts = d_counts.as<int>(); a.rects = d_rects.as<int>(); a.geom = d_geom.as<ImgGeom>(); a.A = A; a.max_det = max_det; a.nc = nc;
+  a.iou = iou; a.min_area = min_area;
   launch_nms(a, 1, h->stream);
   LP_HIP(hipStreamSynchronize(h->stream));
-  LP_HIP(hipMemcpy(count, d_counts.p, 4, hipMemcpyDeviceToHost));
+  int cnt[3];
+  LP_HIP(hipMemcpy(cnt, d_counts.p, 12, hipMemcpyDeviceToHost));
+  *count = cnt[0];
+  if (num_det) *num_det = cnt[1];
   LP_HIP(hipMemcpy(dets, d_dets.p, (size_t)(*count) * sizeof(lp_det), hipMemcpyDeviceToHost));
+  if (rects) LP_HIP(hipMemcpy(rects, d_rects.p, (size_t)(*count) * 16, hipMemcpyDeviceToHost));
+  LP_API_END
+}
+
+int lp_test_nms_boxes(lp_handle* h, const float* boxes, const float* scores, const int* classes, int n, int orig_h, int orig_w,
+                      float iou, int min_area, int max_det, lp_det* dets, int* rects, int* count, int* num_det) {
+  LP_API_BEGIN
+  LP_CHECK(h && boxes && scores && dets && count && n >= 0 && n <= 16384, LP_ERR_ARG, "bad argument");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  const int A = n > 0 ? n : 1;
+  ImgGeom g;
+  memset(&g, 0, sizeof(g));
+  g.h = orig_h; g.w = orig_w; g.ratio = 1.f;
+  std::vector<Cand> cand(A);
+  int nc = 1;
+  for (int i = 0; i < n; ++i) {
+    Cand c;
+    c.x1 = boxes[4 * i]; c.y1 = boxes[4 * i + 1]; c.x2 = boxes[4 * i + 2]; c.y2 = boxes[4 * i + 3];
+    c.score = scores[i]; c.cls = classes ? classes[i] : 0; c.anchor = i; c.pad = 0;
+    nc = std::max(nc, c.cls + 1);
+    cand[i] = c;
+  }
+  DevBuf d_geom, d_cand, d_sorted, d_cnt, d_dets, d_counts, d_rects;
+  d_geom.alloc(sizeof(g));
+  LP_HIP(hipMemcpy(d_geom.p, &g, sizeof(g), hipMemcpyHostToDevice));
+  d_cand.alloc((size_t)A * sizeof(Cand)); d_sorted.alloc((size_t)A * sizeof(Cand)); d_cnt.alloc(16);
+  LP_HIP(hipMemcpy(d_cand.p, cand.data(), (size_t)A * sizeof(Cand), hipMemcpyHostToDevice));
+  LP_HIP(hipMemcpy(d_cnt.p, &n, 4, hipMemcpyHostToDevice));
+  if (max_det <= 0 || max_det > A) max_det = A;
+  d_dets.alloc((size_t)max_det * sizeof(lp_det)); d_counts.alloc(16); d_rects.alloc((size_t)max_det * 16);
+  NmsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.cand = d_cand.as<Cand>(); a.cand_count = d_cnt.as<int>(); a.sorted = d_sorted.as<Cand>(); a.dets = d_dets.as<lp_det>();
+  a.counts = d_counts.as<int>(); a.rects = d_rects.as<int>(); a.geom = d_geom.as<ImgGeom>(); a.A = A; a.max_det = max_det; a.nc = nc;
+  a.iou = iou; a.min_area = min_area;
+  launch_nms(a, 1, h->stream);
+  LP_HIP(hipStreamSynchronize(h->stream));
+  int cnt[3];
+  LP_HIP(hipMemcpy(cnt, d_counts.p, 12, hipMemcpyDeviceToHost));
+  *count = cnt[0];
+  if (num_det) *num_det = cnt[1];
+  LP_HIP(hipMemcpy(dets, d_dets.p, (size_t)(*count) * sizeof(lp_det), hipMemcpyDeviceToHost));
+  if (rects) LP_HIP(hipMemcpy(rects, d_rects.p, (size_t)(*count) * 16, hipMemcpyDeviceToHost));
   LP_API_END
 }
 
@@ -674,7 +740,7 @@ int lp_test_roi_resize(lp_handle* h, const uint8_t* const* rois, const int* hs, 
   r.src = d_src.as<uint8_t>(); r.geom = d_geom.as<ImgGeom>(); r.rects = d_rects.as<int>();
   r.tab.base = d_base.as<int>(); r.tab.total = d_total.as<int>(); r.tab.img = d_img.as<int>(); r.tab.slot = d_slot.as<int>();
   r.out = d_out.as<uint8_t>(); r.max_det = 1; r.S = S;
-  launch_roi_resize(r, h->stream);
+  launch_roi_resize(r, R, h->stream);
   LP_HIP(hipStreamSynchronize(h->stream));
   LP_HIP(hipMemcpy(out_rgb, d_out.p, (size_t)R * S * S * 3, hipMemcpyDeviceToHost));
   LP_API_END

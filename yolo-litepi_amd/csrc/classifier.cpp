@@ -128,7 +128,8 @@ void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
   // stride-1 blocks of a stage run as one fused launch (cls_fused.hip) in the fp16 MFMA configuration;
   // fp32 and the naive debug path keep one kernel per layer
   use_fused_ = prec_ == LP_FP16 && impl_ == IMPL_MFMA && S_ == 64;
-  LP_CHECK(S_ % 32 == 0 && S_ >= 32 && S_ <= 64, LP_ERR_ARG, "classifier input size must be 32 or 64");
+  // the reference resizes every ROI to 64x64 whatever --cls_input_size says (transforms.Resize((64, 64)), e2e.py:367)
+  LP_CHECK(S_ == 64, LP_ERR_ARG, "classifier input size must be 64 (the reference's transform is fixed at 64x64)");
 
   // conv1 + BN -> fp32 [27][24], RGB order
   {

@@ -191,9 +191,7 @@ void launch_fused_stage(const FusedStageArgs& a, int max_items, hipStream_t st) 
   if (groups < 1) groups = 1;
 #define LP_FS(NW, SM)                                                                                          \
   {                                                                                                            \
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(shuffle_stage_kernel<NW, SM>), \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true); \
-    (void)once;                                                                                                \
+    set_max_dynamic_lds(reinterpret_cast<const void*>(shuffle_stage_kernel<NW, SM>), 160 * 1024);                                                                                                \
     hipLaunchKernelGGL((shuffle_stage_kernel<NW, SM>), dim3(groups), dim3(NW * 64), lds, st, a);                 \
   }
   if (Tt <= 4 && S <= 2) LP_FS(4, 2) else if (Tt <= 8 && S <= 4) LP_FS(8, 4) else if (Tt <= 16 && S <= 8) LP_FS(16, 8) else
@@ -342,9 +340,7 @@ void launch_fused_head(const FusedHeadArgs& a, int max_items, hipStream_t st) {
   const size_t lds = fused_head_lds_bytes(a.cin_p, a.nc_p);
   LP_CHECK(lds <= 160 * 1024 && a.nc_p % 16 == 0 && a.nc_p <= 256 && a.cin_p % 8 == 0, LP_ERR_STATE,
            "fused classifier head: unsupported geometry (cin %d, classes %d)", a.cin_p, a.nc);
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(cls_head_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-  (void)once;
+  set_max_dynamic_lds(reinterpret_cast<const void*>(cls_head_kernel), 160 * 1024);
   int groups = (max_items + FH_ROIS - 1) / FH_ROIS;
   if (groups > 512) groups = 512;
   hipLaunchKernelGGL(cls_head_kernel, dim3(groups), dim3(1024), lds, st, a);

@@ -24,6 +24,8 @@ struct Error : std::runtime_error {
 
 std::string fmt(const char* f, ...) __attribute__((format(printf, 1, 2)));
 void set_last_error(const std::string& s);
+// raise a kernel's dynamic-LDS limit once per (device, kernel); throws when the runtime refuses
+void set_max_dynamic_lds(const void* fn, int bytes);
 
 #define LP_HIP(expr)                                                                       \
   do {                                                                                     \

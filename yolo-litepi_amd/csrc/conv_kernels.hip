@@ -1619,23 +1619,17 @@ void ConvLayer::attach_tail(int cout2_phys, int act2_, const std::vector<float>&
 template <typename T, int NT>
 static void launch3x3(const ConvArgs& a, int stride, dim3 grid, int threads, size_t lds, hipStream_t st) {
   if (stride == 1) {
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<T, NT, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_mfma_kernel<T, NT, 1>), 160 * 1024);
     hipLaunchKernelGGL((conv3x3_mfma_kernel<T, NT, 1>), grid, dim3(threads), lds, st, a);
   } else {
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<T, NT, 2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_mfma_kernel<T, NT, 2>), 160 * 1024);
     hipLaunchKernelGGL((conv3x3_mfma_kernel<T, NT, 2>), grid, dim3(threads), lds, st, a);
   }
 }
 
 template <typename T, int NT, int U>
 static void launch_s2_u(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<T, NT, 4, 0, U>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-  (void)once;
+  set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<T, NT, 4, 0, U>), 160 * 1024);
   hipLaunchKernelGGL((conv3x3s2_direct_kernel<T, NT, 4, 0, U>), grid, dim3(256), lds, st, a);
 }
 template <typename T, int NT>
@@ -1646,18 +1640,14 @@ static void launch_s2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) 
 
 template <typename T, int NT, int NP, int EPI>
 static void launch1x1_(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_mfma_kernel<T, NT, NP, EPI>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-  (void)once;
+  set_max_dynamic_lds(reinterpret_cast<const void*>(conv1x1_mfma_kernel<T, NT, NP, EPI>), 160 * 1024);
   hipLaunchKernelGGL((conv1x1_mfma_kernel<T, NT, NP, EPI>), grid, dim3(256), lds, st, a);
 }
 
 template <typename T, int NT>
 static void launch1x1(const ConvArgs& a, bool shuffle, dim3 grid, size_t lds, hipStream_t st) {
   if (a.up) {
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_mfma_kernel<T, NT, 4, EPI_PLAIN, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv1x1_mfma_kernel<T, NT, 4, EPI_PLAIN, true>), 160 * 1024);
     hipLaunchKernelGGL((conv1x1_mfma_kernel<T, NT, 4, EPI_PLAIN, true>), grid, dim3(256), lds, st, a);
   } else if (shuffle)
     launch1x1_<T, NT, 4, EPI_SHUFFLE>(a, grid, lds, st);
@@ -1716,9 +1706,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
       LP_CHECK(!io.res.base, LP_ERR_STATE, "fused tail with residual unsupported");
 #define LP_LDT_(TT, N_, T_, U_)                                                                                              \
   {                                                                                                                          \
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<TT, N_, 4, T_, U_>),  \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);            \
-    (void)once;                                                                                                              \
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<TT, N_, 4, T_, U_>), 160 * 1024);                                                                                                              \
     hipLaunchKernelGGL((conv3x3s2_direct_kernel<TT, N_, 4, T_, U_>), grid, dim3(256), lds_bytes, st, a);                      \
   }
 #define LP_LDT(TT, N_, T_)                               \
@@ -1762,9 +1750,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
       LP_CHECK(!io.res.base && stride == 1, LP_ERR_STATE, "fused tail with residual unsupported");
 #define LP_L3T(TT, N_, T_)                                                                                              \
   {                                                                                                                     \
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<TT, N_, 1, T_>),     \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);       \
-    (void)once;                                                                                                         \
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_mfma_kernel<TT, N_, 1, T_>), 160 * 1024);                                                                                                         \
     hipLaunchKernelGGL((conv3x3_mfma_kernel<TT, N_, 1, T_>), grid, dim3(threads), lds_bytes, st, a);                      \
   }
       if (NT == 4 && T2 == 4) { if (f16) LP_L3T(half_t, 4, 4) else LP_L3T(float, 4, 4) }
@@ -1918,9 +1904,7 @@ void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, 
 template <typename T, int NT, int P1, int P2, int T2>
 static void launch_bneck_(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   constexpr bool SEP = NT == 1;
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-  (void)once;
+  set_max_dynamic_lds(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2>), 160 * 1024);
   hipLaunchKernelGGL((bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2>), grid, dim3(256), lds, st, a);
 }
 

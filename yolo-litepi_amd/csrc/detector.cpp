@@ -252,7 +252,8 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     if (l.type == "ConvolutionDepthWise") {
       const int tin = get(l.inputs[0]);
       LP_CHECK(l.ipar(1, 1) == 3 && l.ipar(3, 1) == 1 && l.ipar(4, 0) == 1 && l.ipar(2, 1) == 1 && l.ipar(7, 1) == l.ipar(0) &&
-                   l.ipar(0) == tensors_[tin].C, LP_ERR_GRAPH, "ConvolutionDepthWise %s: only depthwise 3x3/s1/p1 supported", l.name.c_str());
+                   l.ipar(0) == tensors_[tin].C && l.ipar(9, 0) == 0 && l.ipar(8, 0) == 0, LP_ERR_GRAPH,
+               "ConvolutionDepthWise %s: only depthwise 3x3/s1/p1 without fused activation supported", l.name.c_str());
       cinfo[i].tin = tin;
       cinfo[i].tout = new_tensor(conv_out[i], l.ipar(0), tensors_[tin].H, tensors_[tin].W);
       continue;
@@ -267,6 +268,10 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
                "Convolution %s: only square k with pad k/2, dilation 1 supported", l.name.c_str());
       LP_CHECK(l.in_ch == tensors_[tin].C, LP_ERR_GRAPH, "Convolution %s: weight expects %d input channels, blob has %d",
                l.name.c_str(), l.in_ch, tensors_[tin].C);
+      // fused activation (9 != 0, e.g. after ncnnoptimize), int8 weights (8), asymmetric / valued padding (15, 16, 18): the
+      // kernels implement none of them, and ignoring the parameter would silently compute a different network
+      LP_CHECK(l.ipar(9, 0) == 0 && l.ipar(8, 0) == 0 && l.ipar(15, pad) == pad && l.ipar(16, pad) == pad && l.fpar(18, 0.0) == 0.0,
+               LP_ERR_GRAPH, "Convolution %s: fused activation_type / int8 / asymmetric padding parameters are unsupported", l.name.c_str());
       const int Ho = (tensors_[tin].H + 2 * pad - k) / s + 1, Wo = (tensors_[tin].W + 2 * pad - k) / s + 1;
       cinfo[i].tin = tin;
       cinfo[i].tout = new_tensor(conv_out[i], l.ipar(0), Ho, Wo);

@@ -62,30 +62,33 @@ void launch_decode(int prec, const DecodeArgs& a, int N, hipStream_t st);
 void launch_filter_out0(const float* out0, int nc, int A, const ImgGeom* geom, Cand* cand, int* cand_count,
                         float conf, int N, hipStream_t st);
 
+// ROI bookkeeping across the batch: every image's NMS block appends its kept ROIs to one list
+struct RoiTable {
+  int* base;      // [N+1] (unused by the fused path; kept for the host-filled table of lp_classify)
+  int* total;     // [2]  min(sum, max_rois), then the unclamped sum
+  int* img;       // [max_rois] image index of ROI r
+  int* slot;      // [max_rois] detection slot of ROI r within its image
+  int* work;      // [2] accumulator + ticket of the NMS blocks (zero between calls)
+};
+
 struct NmsArgs {
   const Cand* cand;       // [N][A]
   int* cand_count;        // [N]   (reset to 0 by the kernel for the next call)
   Cand* sorted;           // [N][A] scratch
   lp_det* dets;           // [N][max_det]
-  int* counts;            // [2N]: kept-after-filter, kept-before-filter
+  int* counts;            // [3N]: kept-after-filter, kept-before-filter, float bits of the mean score before the filter
   int* rects;             // [N][max_det][4] int ROI rectangles of the kept boxes
   const ImgGeom* geom;
-  int A, max_det;
+  int A, max_det, nc;
   float iou;
   int min_area;           // < 0: no ROI filter (lp_detect semantics)
+  RoiTable tab;           // tab.total == nullptr: no ROI list
+  int max_rois;
 };
-// per-class greedy NMS (e2e.py:89-119,280-296) + ROI clip / area filter (e2e.py:465-473)
+// per-class greedy NMS (e2e.py:89-119,280-296) + ROI clip / area filter (e2e.py:465-473) + the batch's ROI list
 void launch_nms(const NmsArgs& a, int N, hipStream_t st);
 size_t nms_lds_bytes(int A);
 
-// ROI bookkeeping across the batch: exclusive scan of counts -> roi table
-struct RoiTable {
-  int* base;      // [N+1]
-  int* total;     // [1]  min(sum, max_rois)
-  int* img;       // [max_rois] image index of ROI r
-  int* slot;      // [max_rois] detection slot of ROI r within its image
-};
-void launch_roi_index(const int* counts, const RoiTable& t, int N, int max_det, int max_rois, hipStream_t st);
 
 // PIL Image.resize((S,S), BILINEAR) of every ROI + BGR->RGB (e2e.py:385-389): uint8 RGB [R,S,S,3]
 struct RoiResizeArgs {
@@ -96,7 +99,7 @@ struct RoiResizeArgs {
   uint8_t* out;             // [max_rois,S,S,3]
   int max_det, S;
 };
-void launch_roi_resize(const RoiResizeArgs& a, hipStream_t st);
+void launch_roi_resize(const RoiResizeArgs& a, int max_items, hipStream_t st);
 size_t roi_resize_lds_bytes();
 
 // ---- cls_kernels.hip ------------------------------------------------------------------

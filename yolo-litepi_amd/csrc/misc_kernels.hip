@@ -406,13 +406,11 @@ void launch_psa_attention(int prec, const View& qkv, const View& out, const floa
   LP_CHECK(lds <= 150 * 1024, LP_ERR_GRAPH, "attention over %d positions does not fit LDS", HW);
   dim3 grid(N, heads, (HW + ATT_QB - 1) / ATT_QB);
   if (prec == LP_FP16) {
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(psa_attention_kernel<half_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(psa_attention_kernel<half_t>), 160 * 1024);
     hipLaunchKernelGGL(psa_attention_kernel<half_t>, grid, dim3(256), lds, st, (const half_t*)qkv.base, (half_t*)out.base, pe_w, pe_b, qkv.H,
                        qkv.W, heads, dk, dv, scale, qkv.pitch, out.pitch);
   } else {
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(psa_attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(psa_attention_kernel<float>), 160 * 1024);
     hipLaunchKernelGGL(psa_attention_kernel<float>, grid, dim3(256), lds, st, (const float*)qkv.base, (float*)out.base, pe_w, pe_b, qkv.H,
                        qkv.W, heads, dk, dv, scale, qkv.pitch, out.pitch);
   }

@@ -147,11 +147,19 @@ void launch_filter_out0(const float* out0, int nc, int A, const ImgGeom* geom, C
 //   1. key = (0xFFFF - class, score bits, anchor): a descending bitonic sort in LDS gives
 //      class ascending, score descending, ties -> higher anchor first (the order a stable
 //      ascending argsort reversed gives; e2e.py:96).
-//   2. sequential sweep over the sorted boxes; each surviving box suppresses, in parallel
-//      over the workgroup, every later box of its class with IoU > thr using the reference's
-//      fp32 expression inter / (area_i + area_j - inter + 1e-6) (e2e.py:106-116).
-//   3. ROI rectangle (int truncation, clip) and area filter (e2e.py:465-473) of the kept
-//      boxes, order-preserving compaction into the lp_det records.
+//   2. greedy sweep over the sorted boxes in chunks of 64 (one box per lane of wave 0): inside a
+//      chunk the survivors are found with wave64 ballot masks -- box i, still alive, suppresses
+//      every later lane of its class with IoU > thr, the ballot of those lanes clears them from
+//      the alive mask, no barrier; the chunk's survivors then suppress all later chunks in
+//      parallel over the workgroup (one barrier pair per 64 boxes instead of one per kept box).
+//      IoU is the reference's fp32 expression inter / (area_i + area_j - inter + 1e-6)
+//      (e2e.py:106-116) in its operation order, so the kept set is the NumPy one.
+//   3. max_det: the reference keeps every survivor.  When more than max_det survive, the
+//      max_det highest-scoring ones (over all classes) stay and are emitted in the reference's
+//      class-major order; with a single class that is the head of the list, so the sweep stops early.
+//   4. ROI rectangle (int truncation, clip) and area filter (e2e.py:465-473) of the kept
+//      boxes, order-preserving compaction into the lp_det records, and -- when a ROI table is
+//      given -- the image's slice of the batch-wide ROI list (one atomicAdd per image).
 // ------------------------------------------------------------------------------------
 #define NMS_THREADS 1024
 
@@ -161,10 +169,61 @@ size_t nms_lds_bytes(int A) {
   return (size_t)npad * 8 + (size_t)round_up(A, 16) + 16;
 }
 
+__device__ __forceinline__ unsigned long long nms_key(const Cand& c) {
+  return ((unsigned long long)(0xFFFFu - (unsigned)c.cls) << 46) | ((unsigned long long)__float_as_uint(c.score) << 14) |
+         (unsigned long long)(c.anchor & 0x3FFF);
+}
+// score-major key of a kept box (global top-max_det selection): unique per image
+__device__ __forceinline__ unsigned long long nms_score_key(const Cand& c) {
+  return ((unsigned long long)__float_as_uint(c.score) << 14) | (unsigned long long)(c.anchor & 0x3FFF);
+}
+// true when box j (area aj) is suppressed by kept box i (area ai): NOT (iou <= thr), e2e.py:116
+__device__ __forceinline__ bool nms_suppressed(float ix1, float iy1, float ix2, float iy2, float ai, float jx1, float jy1, float jx2,
+                                               float jy2, float thr) {
+  const float aj = __fmul_rn(__fsub_rn(jx2, jx1), __fsub_rn(jy2, jy1));
+  const float w = fmaxf(0.f, __fsub_rn(fminf(ix2, jx2), fmaxf(ix1, jx1)));
+  const float h = fmaxf(0.f, __fsub_rn(fminf(iy2, jy2), fmaxf(iy1, jy1)));
+  const float inter = __fmul_rn(w, h);
+  const float iou = __fdiv_rn(inter, __fadd_rn(__fsub_rn(__fadd_rn(ai, aj), inter), 1e-6f));
+  return !(iou <= thr);
+}
+
+// exclusive prefix sum of one int per thread over the workgroup (NMS_THREADS = 16 waves); returns the total via *total
+__device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave /*[17]*/, int* total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    int w = lane < NMS_THREADS / 64 ? s_wave[lane] : 0;
+    int winc = w;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int t = __shfl_up(winc, o);
+      if (lane >= o) winc += t;
+    }
+    if (lane < NMS_THREADS / 64) s_wave[lane] = winc - w;
+    if (lane == NMS_THREADS / 64 - 1) s_wave[NMS_THREADS / 64] = winc;
+  }
+  __syncthreads();
+  const int r = s_wave[wave] + inc - v;
+  *total = s_wave[NMS_THREADS / 64];
+  __syncthreads();  // s_wave may be reused
+  return r;
+}
+
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_part[NMS_THREADS];
-  const int n = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_wave[NMS_THREADS / 64 + 1];
+  __shared__ float s_chunk[64 * 6];  // kept boxes of the current chunk: x1, y1, x2, y2, area, class bits
+  __shared__ int s_nk, s_base;
+  __shared__ double s_red[NMS_THREADS / 64];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int cnt = a.cand_count[n];
   cnt = cnt > a.A ? a.A : cnt;
   int npad = 1;
@@ -176,17 +235,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   int nsort = 1;
   while (nsort < cnt) nsort <<= 1;
 
-  for (int i = tid; i < nsort; i += NMS_THREADS) {
-    unsigned long long k = 0ull;
-    if (i < cnt) {
-      const Cand c = cand[i];
-      k = ((unsigned long long)(0xFFFFu - (unsigned)c.cls) << 46) |
-          ((unsigned long long)__float_as_uint(c.score) << 14) | (unsigned long long)(c.anchor & 0x3FFF);
-      // low bits carry the slot in cand[] as well: anchors are unique per image, so the
-      // slot is recovered by a second pass below
-    }
-    keys[i] = k;
-  }
+  for (int i = tid; i < nsort; i += NMS_THREADS) keys[i] = i < cnt ? nms_key(cand[i]) : 0ull;
   __syncthreads();
   for (int k = 2; k <= nsort; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -205,9 +254,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   // is not stored in it, so each candidate finds its own rank by binary search.
   for (int i = tid; i < cnt; i += NMS_THREADS) {
     const Cand c = cand[i];
-    const unsigned long long k = ((unsigned long long)(0xFFFFu - (unsigned)c.cls) << 46) |
-                                 ((unsigned long long)__float_as_uint(c.score) << 14) |
-                                 (unsigned long long)(c.anchor & 0x3FFF);
+    const unsigned long long k = nms_key(c);
     int lo = 0, hi = cnt - 1;
     while (lo < hi) {  // descending order
       const int mid = (lo + hi) >> 1;
@@ -219,43 +266,94 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   __syncthreads();
   __threadfence_block();
 
-  // greedy sweep
+  // ---- greedy sweep, 64 boxes per step
   int* keep = reinterpret_cast<int*>(keys);  // keys are dead from here on
   int nkeep = 0;
   const float thr = a.iou;
-  for (int i = 0; i < cnt; ++i) {
-    if (removed[i]) continue;  // uniform: written before the last barrier only
-    // the records leave in this (class, score) order and only the first max_det of them: once that many are kept the
-    // rest of the sweep cannot change the result (the reference has no such bound; tests that compare whole sets run
-    // with max_det = number of anchors).  Bounds the serial part at max_det barrier rounds under stress.
-    if (nkeep >= a.max_det) break;
-    if (tid == 0) keep[nkeep] = i;
-    ++nkeep;
-    const Cand bi = sorted[i];
-    const float ai = __fmul_rn(__fsub_rn(bi.x2, bi.x1), __fsub_rn(bi.y2, bi.y1));
-    for (int j = i + 1 + tid; j < cnt; j += NMS_THREADS) {
+  const bool single_class = a.nc <= 1;
+  for (int c0 = 0; c0 < cnt; c0 += 64) {
+    if (wave == 0) {
+      const int j = c0 + lane;
+      const bool valid = j < cnt;
+      Cand bj;
+      bj.x1 = bj.y1 = bj.x2 = bj.y2 = 0.f; bj.cls = -1;
+      if (valid) bj = sorted[j];
+      const float aj = __fmul_rn(__fsub_rn(bj.x2, bj.x1), __fsub_rn(bj.y2, bj.y1));
+      unsigned long long alive = __ballot(valid && !removed[valid ? j : 0]);
+      unsigned long long todo = alive, kept = 0ull;
+      int room = single_class ? a.max_det - nkeep : 0x7fffffff;
+      while (todo && room > 0) {  // wave-uniform
+        const int i = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        kept |= 1ull << i;
+        --room;
+        const float ix1 = __shfl(bj.x1, i), iy1 = __shfl(bj.y1, i), ix2 = __shfl(bj.x2, i), iy2 = __shfl(bj.y2, i);
+        const float ai = __shfl(aj, i);
+        const int ic = __shfl(bj.cls, i);
+        const bool sup = lane > i && ((alive >> lane) & 1ull) && bj.cls == ic &&
+                         nms_suppressed(ix1, iy1, ix2, iy2, ai, bj.x1, bj.y1, bj.x2, bj.y2, thr);
+        const unsigned long long m = __ballot(sup);
+        alive &= ~m;
+        todo &= ~m;
+      }
+      if ((kept >> lane) & 1ull) {
+        const int idx = __popcll(kept & ((1ull << lane) - 1ull));
+        keep[nkeep + idx] = j;
+        float* cb = s_chunk + idx * 6;
+        cb[0] = bj.x1; cb[1] = bj.y1; cb[2] = bj.x2; cb[3] = bj.y2; cb[4] = aj; cb[5] = __int_as_float(bj.cls);
+      }
+      if (lane == 0) s_nk = __popcll(kept);
+    }
+    __syncthreads();
+    const int nk = s_nk;
+    nkeep += nk;
+    // single class: (class, score) order is score order, so the first max_det kept boxes are the answer
+    if (single_class && nkeep >= a.max_det) break;
+    for (int j = c0 + 64 + tid; j < cnt; j += NMS_THREADS) {
       if (removed[j]) continue;
       const Cand bj = sorted[j];
-      if (bj.cls != bi.cls) continue;
-      const float aj = __fmul_rn(__fsub_rn(bj.x2, bj.x1), __fsub_rn(bj.y2, bj.y1));
-      const float w = fmaxf(0.f, __fsub_rn(fminf(bi.x2, bj.x2), fmaxf(bi.x1, bj.x1)));
-      const float h = fmaxf(0.f, __fsub_rn(fminf(bi.y2, bj.y2), fmaxf(bi.y1, bj.y1)));
-      const float inter = __fmul_rn(w, h);
-      const float iou = __fdiv_rn(inter, __fadd_rn(__fsub_rn(__fadd_rn(ai, aj), inter), 1e-6f));
-      if (!(iou <= thr)) removed[j] = 1;
+      for (int k = 0; k < nk; ++k) {
+        const float* cb = s_chunk + k * 6;
+        if (__float_as_int(cb[5]) != bj.cls) continue;
+        if (nms_suppressed(cb[0], cb[1], cb[2], cb[3], cb[4], bj.x1, bj.y1, bj.x2, bj.y2, thr)) { removed[j] = 1; break; }
+      }
     }
     __syncthreads();
   }
   __syncthreads();
-  if (nkeep > a.max_det) nkeep = a.max_det;  // score order: the top max_det stay
 
-  // ROI rectangle + area filter, order-preserving compaction
+  // ---- more survivors than max_det (several classes): the max_det best scores stay.  The (score, anchor) key is
+  //      unique inside an image, so the threshold key T with exactly max_det keys >= T exists; found bit by bit.
+  unsigned long long T = 0ull;
+  int nsel = nkeep;
+  if (nkeep > a.max_det) {
+    if (single_class) {
+      nsel = a.max_det;  // head of the list
+    } else {
+      for (int bit = 45; bit >= 0; --bit) {
+        const unsigned long long candT = T | (1ull << bit);
+        int c = 0;
+        for (int k = tid; k < nkeep; k += NMS_THREADS) c += nms_score_key(sorted[keep[k]]) >= candT ? 1 : 0;
+        int tot;
+        (void)block_exclusive_scan(c, s_wave, &tot);
+        if (tot >= a.max_det) T = candT;
+      }
+      nsel = a.max_det;
+    }
+  }
+  const bool by_key = nkeep > a.max_det && !single_class;
+  const int nlist = by_key ? nkeep : nsel;
+
+  // ---- ROI rectangle + area filter, order-preserving compaction
   const ImgGeom gm = a.geom[n];
-  const int per = (nkeep + NMS_THREADS - 1) / NMS_THREADS;
-  const int k0 = tid * per, k1 = (k0 + per < nkeep) ? k0 + per : nkeep;
+  const int per = (nlist + NMS_THREADS - 1) / NMS_THREADS;
+  const int k0 = tid * per, k1 = (k0 + per < nlist) ? k0 + per : nlist;
   int nvalid = 0;
+  double ssum = 0.0;
   for (int k = k0; k < k1; ++k) {
     const Cand c = sorted[keep[k]];
+    if (by_key && nms_score_key(c) < T) continue;
+    ssum += (double)c.score;
     bool ok = true;
     if (a.min_area >= 0) {
       int x1 = (int)c.x1, y1 = (int)c.y1, x2 = (int)c.x2, y2 = (int)c.y2;
@@ -265,21 +363,44 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     }
     nvalid += ok ? 1 : 0;
   }
-  s_part[tid] = nvalid;
+  int run;
+  int o = block_exclusive_scan(nvalid, s_wave, &run);
+  // mean detector confidence over ALL kept boxes, before the area filter (PipelineMetrics.det_confidence_avg, e2e.py:456-457)
+  for (int off = 32; off > 0; off >>= 1) ssum += __shfl_xor(ssum, off);
+  if (lane == 0) s_red[wave] = ssum;
   __syncthreads();
   if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < NMS_THREADS; ++t) { const int v = s_part[t]; s_part[t] = run; run += v; }
+    double tot = 0.0;
+    for (int w = 0; w < NMS_THREADS / 64; ++w) tot += s_red[w];
     a.counts[n] = run;
-    a.counts[gridDim.x + n] = nkeep;
+    a.counts[gridDim.x + n] = nsel;
+    reinterpret_cast<float*>(a.counts)[2 * gridDim.x + n] = nsel > 0 ? (float)(tot / (double)nsel) : 0.f;
     a.cand_count[n] = 0;  // ready for the next call
+    // the image's slice of the batch-wide ROI list: work[0] accumulates, the block that draws the last ticket
+    // (work[1]) publishes the clamped total for the classifier kernels and re-arms both words for the next call.
+    // The ticket is issued only after the slice's add has RETURNED, so the last ticket implies every add is done.
+    int base = 0;
+    if (a.tab.total) {
+      base = atomicAdd(a.tab.work, run);
+      int one = 1;
+      asm volatile("" : "+v"(one) : "v"(base));
+      const int ticket = atomicAdd(a.tab.work + 1, one);
+      if (ticket == (int)gridDim.x - 1) {
+        const int raw = atomicExch(a.tab.work, 0);
+        atomicExch(a.tab.work + 1, 0);
+        a.tab.total[0] = raw < a.max_rois ? raw : a.max_rois;
+        a.tab.total[1] = raw;  // unclamped: the host checks it against the capacity
+      }
+    }
+    s_base = base;
   }
   __syncthreads();
-  int o = s_part[tid];
+  const int base = s_base;
   lp_det* dets = a.dets + (long)n * a.max_det;
   int* rects = a.rects + (long)n * a.max_det * 4;
   for (int k = k0; k < k1; ++k) {
     const Cand c = sorted[keep[k]];
+    if (by_key && nms_score_key(c) < T) continue;
     int x1 = (int)c.x1, y1 = (int)c.y1, x2 = (int)c.x2, y2 = (int)c.y2;
     x1 = min(max(x1, 0), gm.w - 1); y1 = min(max(y1, 0), gm.h - 1);
     x2 = min(max(x2, x1 + 1), gm.w); y2 = min(max(y2, y1 + 1), gm.h);
@@ -290,43 +411,17 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     d.cls_class = -1; d.cls_conf = 0.f;
     dets[o] = d;
     rects[o * 4 + 0] = x1; rects[o * 4 + 1] = y1; rects[o * 4 + 2] = x2; rects[o * 4 + 3] = y2;
+    if (a.tab.total && base + o < a.max_rois) { a.tab.img[base + o] = n; a.tab.slot[base + o] = o; }
     ++o;
   }
 }
 
 void launch_nms(const NmsArgs& a, int N, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), true);
-  (void)once;
+  set_max_dynamic_lds(reinterpret_cast<const void*>(nms_kernel), 150 * 1024);
   const size_t lds = nms_lds_bytes(a.A);
   LP_CHECK(lds <= 150 * 1024, LP_ERR_STATE, "NMS: %d anchors exceed the LDS sort capacity", a.A);
   LP_CHECK(a.A <= 16384, LP_ERR_STATE, "NMS: anchor index needs more than 14 key bits");
   hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(NMS_THREADS), lds, st, a);
-  LP_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void roi_index_kernel(const int* __restrict__ counts, RoiTable t, int N, int max_det,
-                                                        int max_rois) {
-  __shared__ int s_base[1025];
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int i = 0; i < N; ++i) { s_base[i] = run; run += counts[i]; }
-    s_base[N] = run;
-    t.total[0] = run < max_rois ? run : max_rois;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i <= N; i += 256) t.base[i] = s_base[i];
-  for (int i = 0; i < N; ++i) {
-    const int b = s_base[i], c = s_base[i + 1] - b;
-    for (int k = threadIdx.x; k < c; k += 256)
-      if (b + k < max_rois) { t.img[b + k] = i; t.slot[b + k] = k; }
-  }
-}
-
-void launch_roi_index(const int* counts, const RoiTable& t, int N, int max_det, int max_rois, hipStream_t st) {
-  LP_CHECK(N <= 1024, LP_ERR_ARG, "batch larger than 1024");
-  hipLaunchKernelGGL(roi_index_kernel, dim3(1), dim3(256), 0, st, counts, t, N, max_det, max_rois);
   LP_HIP(hipGetLastError());
 }
 
@@ -396,9 +491,9 @@ __device__ __forceinline__ uint8_t clip8(int v) {
   return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// one ROI per call, whole workgroup; MODE picks the staging strategy (block-uniform)
 template <int MAXK, int MODE>
-__global__ __launch_bounds__(RR_THREADS) void roi_resize_kernel(const RoiResizeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void roi_resize_one(const RoiResizeArgs& a, int r, char* smem) {
   const int S = a.S;
   int* kx = reinterpret_cast<int*>(smem);
   int* ky = kx + 64 * MAXK;
@@ -406,20 +501,18 @@ __global__ __launch_bounds__(RR_THREADS) void roi_resize_kernel(const RoiResizeA
   int* by = bx + 2 * 64;
   uint8_t* tmp = reinterpret_cast<uint8_t*>(by + 2 * 64);  // [rows][S][3]
   const int tid = threadIdx.x;
-  const int R = a.tab.total[0];
   const int half = 1 << (RR_PRECISION_BITS - 1);
-  for (int r = blockIdx.x; r < R; r += gridDim.x) {
+  {
     const int img = a.tab.img[r], slot = a.tab.slot[r];
     const ImgGeom gm = a.geom[img];
     const int* rc = a.rects + ((long)img * a.max_det + slot) * 4;
     const int rx = rc[0], ry = rc[1];
     const int in_w = rc[2] - rx, in_h = rc[3] - ry;
-    if (rr_mode(in_w, in_h) != MODE) continue;  // block-uniform: another variant owns this ROI
     const uint8_t* src = a.src + gm.src_off;
     uint8_t* out = a.out + (long)r * S * S * 3;
     if (in_w > 4096 || in_h > 4096) {  // beyond the tap budget: defined (zero) output instead of garbage
       for (int i = tid; i < S * S * 3; i += RR_THREADS) out[i] = 0;
-      continue;
+      return;
     }
     __syncthreads();
     // one thread per (axis, output index, tap): Pillow's double arithmetic in Pillow's order (the weight sum is
@@ -532,18 +625,30 @@ __global__ __launch_bounds__(RR_THREADS) void roi_resize_kernel(const RoiResizeA
   }
 }
 
-void launch_roi_resize(const RoiResizeArgs& a, hipStream_t st) {
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel<RR_LARGE_K, RR_MODE_LARGE>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel<RR_SMALL_K, RR_MODE_SMALL>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024),
-                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(roi_resize_kernel<RR_SMALL_K, RR_MODE_TINY>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024), true);
-  (void)once;
-  LP_CHECK(a.S <= 64, LP_ERR_ARG, "classifier input larger than 64 unsupported by the resize kernel");
-  hipLaunchKernelGGL((roi_resize_kernel<RR_SMALL_K, RR_MODE_TINY>), dim3(512), dim3(RR_THREADS), roi_resize_banded_lds(RR_TINY_H), st, a);
-  hipLaunchKernelGGL((roi_resize_kernel<RR_SMALL_K, RR_MODE_SMALL>), dim3(256), dim3(RR_THREADS), roi_resize_banded_lds(RR_SMALL_SIDE), st, a);
-  hipLaunchKernelGGL((roi_resize_kernel<RR_LARGE_K, RR_MODE_LARGE>), dim3(128), dim3(RR_THREADS), roi_resize_lds_bytes(), st, a);
+// One launch for every ROI of the batch: a workgroup takes ROIs round-robin and picks the variant by the ROI's size
+// (three launches, two of them usually empty, cost more than the resampling of a typical batch).
+__global__ __launch_bounds__(RR_THREADS) void roi_resize_kernel(const RoiResizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = a.tab.total[0];
+  for (int r = blockIdx.x; r < R; r += gridDim.x) {
+    const int img = a.tab.img[r], slot = a.tab.slot[r];
+    const int* rc = a.rects + ((long)img * a.max_det + slot) * 4;
+    const int mode = rr_mode(rc[2] - rc[0], rc[3] - rc[1]);
+    if (mode == RR_MODE_TINY) roi_resize_one<RR_SMALL_K, RR_MODE_TINY>(a, r, smem);
+    else if (mode == RR_MODE_SMALL) roi_resize_one<RR_SMALL_K, RR_MODE_SMALL>(a, r, smem);
+    else roi_resize_one<RR_LARGE_K, RR_MODE_LARGE>(a, r, smem);
+    __syncthreads();
+  }
+}
+
+void launch_roi_resize(const RoiResizeArgs& a, int max_items, hipStream_t st) {
+  const size_t lds = roi_resize_banded_lds(RR_SMALL_SIDE) > roi_resize_lds_bytes() ? roi_resize_banded_lds(RR_SMALL_SIDE) : roi_resize_lds_bytes();
+  set_max_dynamic_lds(reinterpret_cast<const void*>(roi_resize_kernel), 128 * 1024);
+  LP_CHECK(a.S == 64, LP_ERR_ARG, "the ROI resize kernel's tap tables are sized for a 64x64 classifier input (e2e.py:367 resizes to 64x64 whatever --cls_input_size says)");
+  LP_CHECK(lds <= 128 * 1024, LP_ERR_STATE, "ROI resize LDS budget");
+  int grid = max_items < 512 ? max_items : 512;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(roi_resize_kernel, dim3(grid), dim3(RR_THREADS), lds, st, a);
   LP_HIP(hipGetLastError());
 }
 

@@ -45,7 +45,7 @@ SYMBOLS = [
     "lp_last_error", "lp_version", "lp_default_config", "lp_create", "lp_destroy", "lp_load_detector_ncnn",
     "lp_load_classifier_tensors", "lp_detect_raw", "lp_detect", "lp_run_batch", "lp_run_batch_device", "lp_classify",
     "lp_set_stream", "lp_synchronize", "lp_profile_next", "lp_profile_read", "lp_detector_info", "lp_debug_blob",
-    "lp_test_conv", "lp_test_postprocess", "lp_test_roi_resize", "lp_test_letterbox",
+    "lp_test_conv", "lp_test_postprocess", "lp_test_nms_boxes", "lp_test_roi_resize", "lp_test_letterbox",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -74,7 +74,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.lp_load_classifier_tensors.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(vp), ip]
     lib.lp_detect_raw.argtypes = [vp, vp, C.c_int, vp]
     lib.lp_detect.argtypes = [vp, u8pp, ip, ip, C.c_int, C.c_float, C.c_float, vp, ip]
-    lib.lp_run_batch.argtypes = [vp, u8pp, ip, ip, C.c_int, C.c_float, C.c_float, C.c_int, vp, ip, ip, C.POINTER(LpTiming)]
+    lib.lp_run_batch.argtypes = [vp, u8pp, ip, ip, C.c_int, C.c_float, C.c_float, C.c_int, vp, ip, ip, fp, C.POINTER(LpTiming)]
     lib.lp_run_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp]
     lib.lp_classify.argtypes = [vp, u8pp, ip, ip, C.c_int, ip, fp]
     lib.lp_set_stream.argtypes = [vp, vp]
@@ -86,7 +86,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.lp_test_conv.argtypes = [vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, C.c_int, C.c_int, C.c_int,
                                  C.c_int, fp, fp]
     lib.lp_test_postprocess.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
-                                        C.c_float, C.c_float, vp, ip]
+                                        C.c_float, C.c_float, C.c_int, C.c_int, vp, ip, ip, ip]
+    lib.lp_test_nms_boxes.argtypes = [vp, fp, fp, ip, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip, ip, ip]
     lib.lp_test_roi_resize.argtypes = [vp, u8pp, ip, ip, C.c_int, vp]
     lib.lp_test_letterbox.argtypes = [vp, vp, C.c_int, C.c_int, vp, fp, fp, fp]
     for s in SYMBOLS:

@@ -117,9 +117,11 @@ class Engine:
         B = len(imgs)
         dets = np.zeros((B, self.cfg.max_det), dtype=DET_DTYPE)
         counts, num_det = (C.c_int * B)(), (C.c_int * B)()
+        conf_avg = (C.c_float * B)()
         timing = LpTiming()
         check(self.lib, self.lib.lp_run_batch(self._h, ptrs, hs, ws, B, conf, iou, int(min_area), dets.ctypes.data, counts,
-                                              num_det, C.byref(timing)))
+                                              num_det, conf_avg, C.byref(timing)))
+        self.last_det_conf_avg = np.array(conf_avg[:], dtype=np.float32)
         return dets, np.array(counts[:], dtype=np.int64), np.array(num_det[:], dtype=np.int64), timing
 
     def run_batch_device(self, dev_imgs: int, B: int, H: int, W: int, conf: float, iou: float, min_area: int,
@@ -177,16 +179,38 @@ class Engine:
                                               None if r is None else r.ctypes.data_as(fp), y.ctypes.data_as(fp)))
         return y
 
-    def test_postprocess(self, out0, orig_shape, ratio, pad, conf, iou):
+    def test_postprocess(self, out0, orig_shape, ratio, pad, conf, iou, min_area: int = -1, max_det: int = 0, with_rects: bool = False):
+        """filter + NMS (+ ROI clip / area filter when min_area >= 0) on a host out0 [4+nc, A].  Returns the records, or
+        (records, int rects [n,4], pre-filter count) with ``with_rects``."""
         fp = C.POINTER(C.c_float)
         o = np.ascontiguousarray(out0, np.float32)
         nc, A = o.shape[0] - 4, o.shape[1]
         dets = np.zeros(A, dtype=DET_DTYPE)
-        cnt = C.c_int()
+        rects = np.zeros((A, 4), dtype=np.int32)
+        cnt, num = C.c_int(), C.c_int()
         check(self.lib, self.lib.lp_test_postprocess(self._h, o.ctypes.data_as(fp), nc, A, int(orig_shape[0]), int(orig_shape[1]),
                                                      float(ratio), float(pad[0]), float(pad[1]), float(conf), float(iou),
-                                                     dets.ctypes.data, C.byref(cnt)))
+                                                     int(min_area), int(max_det), dets.ctypes.data,
+                                                     rects.ctypes.data_as(C.POINTER(C.c_int)), C.byref(cnt), C.byref(num)))
+        if with_rects:
+            return dets[:cnt.value], rects[:cnt.value], num.value
         return dets[:cnt.value]
+
+    def test_nms_boxes(self, boxes, scores, classes, orig_shape, iou, min_area: int = -1, max_det: int = 0):
+        """NMS + ROI clip / area filter on host xyxy boxes -> (records, int rects [n,4], pre-filter count)."""
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+        sc = np.ascontiguousarray(scores, np.float32)
+        n = len(b)
+        cl = None if classes is None else np.ascontiguousarray(classes, np.int32)
+        dets = np.zeros(max(n, 1), dtype=DET_DTYPE)
+        rects = np.zeros((max(n, 1), 4), dtype=np.int32)
+        cnt, num = C.c_int(), C.c_int()
+        check(self.lib, self.lib.lp_test_nms_boxes(self._h, b.ctypes.data_as(fp), sc.ctypes.data_as(fp),
+                                                   None if cl is None else cl.ctypes.data_as(ip), n, int(orig_shape[0]),
+                                                   int(orig_shape[1]), float(iou), int(min_area), int(max_det), dets.ctypes.data,
+                                                   rects.ctypes.data_as(ip), C.byref(cnt), C.byref(num)))
+        return dets[:cnt.value], rects[:cnt.value], num.value
 
     def test_roi_resize(self, rois: Sequence[np.ndarray]) -> np.ndarray:
         imgs, ptrs, hs, ws = self._img_args(rois)
@@ -227,6 +251,23 @@ class PipelineMetrics:
     level: str = "HIP(MI355X)"
 
 
+def _system_metrics():
+    """cpu_percent / memory_mb / temperature as the reference samples them after each run (e2e.py:509-516)."""
+    cpu = mem = temp = 0.0
+    try:
+        import psutil
+        cpu = float(psutil.cpu_percent())
+        mem = float(psutil.Process().memory_info().rss) / 1024 / 1024
+    except Exception:  # noqa: BLE001 - psutil missing: fields stay 0 like the reference's temperature fallback
+        pass
+    try:
+        with open("/sys/class/thermal/thermal_zone0/temp") as f:
+            temp = float(f.read()) / 1000.0
+    except Exception:  # noqa: BLE001
+        pass
+    return cpu, mem, temp
+
+
 def _empty_detect():
     # the reference returns float64 empties here (e2e.py:264,292-294)
     return np.empty((0, 4)), np.empty((0,)), np.empty((0,))
@@ -257,8 +298,13 @@ class NCNNDetector:
     def detect_batch(self, images: Sequence[np.ndarray], conf_threshold: float = 0.5, iou_threshold: float = 0.45):
         try:
             dets, counts = self.engine.detect(images, conf_threshold, iou_threshold)
-        except _ffi.LitepiError:
-            return [_empty_detect() for _ in images]  # engine failure -> empty, never raises (e2e.py:309-310)
+        except _ffi.LitepiError as e:
+            # the reference returns empty arrays when the ENGINE call fails (extract != 0, e2e.py:309-310): that is a HIP
+            # runtime failure here.  Misuse (batch over capacity, unsupported shapes, model not loaded) is raised.
+            if e.code != _ffi.LP_ERR_HIP:
+                raise
+            print(f"[HIP Detector] engine failure, returning no detections: {e}")
+            return [_empty_detect() for _ in images]
         out = []
         for i, n in enumerate(counts):
             if n == 0:
@@ -384,8 +430,13 @@ class HybridPipeline:
         t0 = time.perf_counter()
         try:
             dets, counts, num_det, timing = self.engine.run_batch(images, conf_threshold, iou_threshold, min_area)
-        except _ffi.LitepiError:
+        except _ffi.LitepiError as e:
+            if e.code != _ffi.LP_ERR_HIP:  # misuse / capacity errors are raised, only an engine failure yields "nothing found"
+                raise
+            print(f"[HIP Pipeline] engine failure, returning no detections: {e}")
             return [([], PipelineMetrics()) for _ in images]
+        conf_avg = self.engine.last_det_conf_avg
+        sysm = _system_metrics()
         wall_ms = (time.perf_counter() - t0) * 1000.0
         B = len(images)
         out = []
@@ -400,8 +451,10 @@ class HybridPipeline:
             m.num_detections = int(num_det[i])  # counted BEFORE the min-area filter (e2e.py:454)
             n = int(counts[i])
             d = dets[i, :n]
+            # averaged over ALL detector boxes, before the min-area filter (e2e.py:456-457)
+            m.det_confidence_avg = float(conf_avg[i]) if m.num_detections else 0.0
+            m.cpu_percent, m.memory_mb, m.temperature = sysm
             if n:
-                m.det_confidence_avg = float(np.mean(d["det_conf"]))
                 cl = d["cls_conf"][d["cls_class"] >= 0]
                 if len(cl):
                     m.cls_confidence_avg = float(np.mean(cl))
