@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace lp {
 
@@ -143,6 +144,13 @@ void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
     LP_HIP(hipMemcpy(stem_w_.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     stem_b_.alloc(24 * 4);
     LP_HIP(hipMemcpy(stem_b_.p, f.b.data(), 24 * 4, hipMemcpyHostToDevice));
+    if (use_fused_) {
+      std::vector<uint16_t> fr;
+      std::vector<float> bc;
+      pack_cls_stem(f.w, f.b, fr, bc);
+      upload_u16(stem_frag_, fr);
+      upload_f32(stem_bias4_, bc);
+    }
   }
   int H = S_ / 2;
   alloc_act(a_stem_, 24, H, H);
@@ -171,15 +179,18 @@ void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
         LP_CHECK(d.co == inp && d.ci == 1 && d.k == 3, LP_ERR_ARG, "%sbranch1.0 shape", p.c_str());
         expand_dw(d, lin, 0, lin.Cp(), 0, w, b);
         B.b1_dw = add_dw(p + "branch1.0", w, b, lin.Cp(), 2);
+        if (use_fused_) { upload_f32(fused_s2_[s].dw1, w); upload_f32(fused_s2_[s].dw1b, b); }
         Folded q = fold(sd, p + "branch1.2", p + "branch1.3");
         LP_CHECK(q.co == bf && q.ci == inp && q.k == 1, LP_ERR_ARG, "%sbranch1.2 shape", p.c_str());
         expand_pw(q, lin, 0, bfp, w, b, lin.Cp(), 0);
         B.b1_pw = add_pw(p + "branch1.2", w, b, lin.Cp(), bfp, ACT_RELU, Ho);
+        if (use_fused_) { upload_u16(fused_s2_[s].pwb1, pack_fused_pw(w, bfp, lin.Cp())); upload_f32(fused_s2_[s].pwb1b, b); }
         // branch2: pw1 inp->bf + ReLU (full resolution), dw s2, pw2 + ReLU (+shuffle with branch1)
         Folded a1 = fold(sd, p + "branch2.0", p + "branch2.1");
         LP_CHECK(a1.co == bf && a1.ci == inp, LP_ERR_ARG, "%sbranch2.0 shape", p.c_str());
         expand_pw(a1, lin, 0, bfp, w, b, lin.Cp(), 0);
         B.b2_pw1 = add_pw(p + "branch2.0", w, b, lin.Cp(), bfp, ACT_RELU, Hin);
+        if (use_fused_) { upload_u16(fused_s2_[s].pw1, pack_fused_pw(w, bfp, lin.Cp())); upload_f32(fused_s2_[s].pw1b, b); }
         b1dw_elems = std::max(b1dw_elems, (size_t)Ho * Ho * lin.Cp());
         b1_elems = std::max(b1_elems, (size_t)Ho * Ho * bfp);
         t1_elems = std::max(t1_elems, (size_t)Hin * Hin * bfp);
@@ -203,11 +214,13 @@ void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
       expand_dw(d2, lmid, 0, bfp, 0, w, b);
       B.b2_dw = add_dw(p + "branch2.3", w, b, bfp, B.stride);
       if (use_fused_ && B.stride == 1) { upload_f32(fused_[s].back().dw, w); upload_f32(fused_[s].back().dwb, b); }
+      if (use_fused_ && B.stride == 2) { upload_f32(fused_s2_[s].dw2, w); upload_f32(fused_s2_[s].dw2b, b); }
       Folded a2 = fold(sd, p + "branch2.5", p + "branch2.6");
       LP_CHECK(a2.co == bf && a2.ci == bf, LP_ERR_ARG, "%sbranch2.5 shape", p.c_str());
       expand_pw(a2, lmid, 0, bfp, w, b, bfp, 0);
       B.b2_pw2 = add_pw(p + "branch2.5", w, b, bfp, bfp, ACT_RELU, Ho);
       if (use_fused_ && B.stride == 1) { upload_u16(fused_[s].back().w2, pack_fused_pw(w, bfp, bfp)); upload_f32(fused_[s].back().b2, b); }
+      if (use_fused_ && B.stride == 2) { upload_u16(fused_s2_[s].pw2, pack_fused_pw(w, bfp, bfp)); upload_f32(fused_s2_[s].pw2b, b); }
       t2_elems = std::max(t2_elems, (size_t)Ho * Ho * bfp);
       blocks_.push_back(B);
       inp = oup;
@@ -216,6 +229,11 @@ void Classifier::load(const std::map<std::string, NamedTensor>& sd) {
     H = Ho;
     alloc_act(a_stage_[s][0], 2 * bfp, H, H);
     alloc_act(a_stage_[s][1], 2 * bfp, H, H);
+  }
+  if (use_fused_) {
+    LP_CHECK(half_c_[0] == 58 && half_cp_[0] == 64 && half_c_[1] == 116 && half_cp_[1] == 128 && half_c_[2] == 232 && half_cp_[2] == 240,
+             LP_ERR_STATE, "fused classifier kernels are built for ShuffleNetV2 x1.0 widths");
+    a_x3_.alloc((size_t)maxR_ * 16 * 256 * 2);
   }
   const size_t es = prec_ == LP_FP16 ? 2 : 4;
   a_t1_.mem.alloc((size_t)maxR_ * t1_elems * es);
@@ -293,6 +311,51 @@ void Classifier::forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Pro
     P1("dwconv3x3", d.name, 2.0 * 9 * d.C * out.H * out.W, ((double)in.H * in.W + (double)out.H * out.W) * d.C * esd);
   };
 
+  static const bool two_launch = getenv("LITEPI_CLS_LAYERWISE") == nullptr;  // A/B switch: the layer-at-a-time plan of round 1
+  if (use_fused_ && two_launch) {
+    auto s2w = [](const FusedS2& f) {
+      FusedS2W w;
+      w.dw1 = f.dw1.as<float>(); w.dw1b = f.dw1b.as<float>(); w.pwb1 = f.pwb1.as<u32x4_t>(); w.pwb1b = f.pwb1b.as<float>();
+      w.pw1 = f.pw1.as<u32x4_t>(); w.pw1b = f.pw1b.as<float>(); w.dw2 = f.dw2.as<float>(); w.dw2b = f.dw2b.as<float>();
+      w.pw2 = f.pw2.as<u32x4_t>(); w.pw2b = f.pw2b.as<float>();
+      return w;
+    };
+    auto s1w = [](const FusedW& f) {
+      FusedBlockW w;
+      w.w1 = f.w1.as<u32x4_t>(); w.b1 = f.b1.as<float>(); w.dw = f.dw.as<float>(); w.dwb = f.dwb.as<float>();
+      w.w2 = f.w2.as<u32x4_t>(); w.b2 = f.b2.as<float>();
+      return w;
+    };
+    ClsFrontArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.rgb = rgb; fa.m_dyn = d_R; fa.out = a_x3_.p;
+    fa.stem_w = stem_frag_.as<u32x4_t>(); fa.stem_b = stem_bias4_.as<float>();
+    fa.s20 = s2w(fused_s2_[0]);
+    for (int q = 0; q < 3; ++q) fa.s2[q] = s1w(fused_[0][q]);
+    fa.s30 = s2w(fused_s2_[1]);
+    P0();
+    launch_cls_front(fa, maxR_, st);
+    // conv1 0.66 + stage2 2.10 + stage3.0 0.6 MMAC per ROI; bytes: the uint8 crop in, 8 KB out
+    P1("cls_front", "conv1..stage3.0", 2.0 * (0.66e6 + 2.10e6 + 0.60e6), 12288.0 + 8192.0);
+    ClsBackArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    ba.in = a_x3_.p; ba.m_dyn = d_R;
+    for (int q = 0; q < 7; ++q) ba.s3[q] = s1w(fused_[1][q]);
+    ba.s40 = s2w(fused_s2_[2]);
+    for (int q = 0; q < 3; ++q) ba.s4[q] = s1w(fused_[2][q]);
+    ba.w5 = head_w5_.as<u32x4_t>(); ba.b5 = head_b5_.as<float>();
+    ba.wfc = head_wfc_.as<u32x4_t>(); ba.bfc = head_bfc_.as<float>();
+    ba.nc = ncls_; ba.nc_p = head_nc_p_;
+    ba.logits = d_logits_.as<float>(); ba.logits_pitch = lpitch_;
+    if (post) {
+      ba.probs = post->probs; ba.ids = post->ids; ba.dets = post->dets; ba.max_det = post->max_det;
+      ba.roi_img = post->roi_img; ba.roi_slot = post->roi_slot;
+    }
+    P0();
+    launch_cls_back(ba, maxR_, st);
+    P1("cls_back", "stage3.1..softmax", 2.0 * (3.86e6 + 2.63e6 + 1.90e6 + 1024.0 * ncls_), 8192.0 + ncls_ * 4.0);
+    return;
+  }
   P0();
   launch_cls_stem(prec_, rgb, stem_w_.as<float>(), stem_b_.as<float>(), 24, act_view(a_stem_), S_, d_R, maxR_, st);
   P1("cls_stem", "conv1", 2.0 * 27 * 24 * a_stem_.H * a_stem_.W, (double)S_ * S_ * 3 + (double)a_stem_.H * a_stem_.W * 24 * esd);

@@ -5,6 +5,7 @@
 #include "conv.h"
 #include "detector.h"
 #include "cls_fused.h"
+#include "cls_net.h"
 #include "kernels.h"
 
 namespace lp {
@@ -59,6 +60,10 @@ class Classifier {
   // fused stride-1 stage path (fp16 + MFMA only)
   struct FusedW { DevBuf w1, b1, dw, dwb, w2, b2; };
   std::vector<FusedW> fused_[3];
+  // stride-2 blocks + MFMA stem of the two-launch network (cls_net.hip)
+  struct FusedS2 { DevBuf dw1, dw1b, pwb1, pwb1b, pw1, pw1b, dw2, dw2b, pw2, pw2b; };
+  FusedS2 fused_s2_[3];
+  DevBuf stem_frag_, stem_bias4_, a_x3_;
   bool use_fused_ = false;
   DevBuf head_w5_, head_b5_, head_wfc_, head_bfc_;
   int head_cin_p_ = 0, head_nc_p_ = 0;
