@@ -9,18 +9,28 @@ batch 64 per GPU, fp16 storage / fp32 accumulate (BASELINE.json configs[2]; conf
 One "step" = one pass of the whole hot path over one batch of B synthetic uint8 BGR images that
 are already resident in HBM (lp_run_batch_device), plus -- at N>1 -- the single RCCL gather of the
 detection records to rank 0.  Weak scaling: every rank processes its own B images per step.
+Steps rotate over --nbatches distinct input batches and --inflight pipeline handles (own stream,
+own activation buffers), so consecutive steps overlap on the GPU and no step re-reads the inputs
+of the previous one.
 
 Weights: seeded random-init models of the reference's architectures written by
 litepi.ncnn_export (YOLO-LitePi v1 widths by default) and a seeded ShuffleNetV2 x1.0; the
 class-branch bias is calibrated once, untimed, so that ~8 anchors per image pass conf 0.25 and the
 classifier stage has real work.  No dataset/checkpoint is available.
 
-Extra objects on the JSON line:
-  roofline     -- dominant kernel family: algorithmic FLOPs of its launches / their HIP-event
-                  durations (a profiled pass of the same step, same process), vs the dense fp16
-                  MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md)
-  cpu_baseline -- the CPU restatement of the reference path (oracle/, torch-CPU + NumPy) timed
-                  on this host's cores over a bounded sample of the same images (rank 0, N=1)
+The JSON line (rank 0):
+  value / ms_per_step -- the K timed steps between barrier + synchronize pairs (the contract)
+  windows             -- --windows further windows of K steps each: median and p95 of ms/step
+  h2d_inclusive       -- the same loop with the batch starting in PINNED HOST memory: async H2D copy
+                         on the handle's stream, then the pipeline (the reference's t_total starts
+                         from a host image, e2e.py:446-506); never `value`
+  roofline            -- dominant conv kernel family: algorithmic FLOPs of its launches / their
+                         HIP-event durations (profiled passes of the same step, same process) against
+                         the dense fp16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md); the HBM view of the
+                         same family and of the whole step as secondary fields
+  cpu_baseline        -- the CPU restatement of the reference path (oracle/, torch-CPU + NumPy) timed
+                         on this host's cores (all of the GPU's CPU share, and 4 threads = the paper's
+                         Pi 5 setting) over a bounded sample of the same images (rank 0, N=1)
 """
 import argparse
 import json
@@ -43,6 +53,7 @@ PEAK_HBM_GBS = 8000.0
 CONF, IOU, MIN_AREA = 0.25, 0.45, 50
 NUM_CLASSES = 91            # TT100K classifier head
 TARGET_CANDIDATES = 8       # anchors per image above conf after calibration
+PROFILE_ROUND = "r02"
 
 
 def parse_args():
@@ -55,16 +66,19 @@ def parse_args():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--max-det", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=320, help="images in the CPU baseline sample")
+    ap.add_argument("--cpu-images", type=int, default=256, help="images in the CPU baseline sample (all-core run)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent pipeline handles (own stream + activation buffers) the steps rotate over, so "
                          "consecutive steps overlap on the GPU")
+    ap.add_argument("--nbatches", type=int, default=4, help="distinct input batches the steps rotate over")
+    ap.add_argument("--windows", type=int, default=9, help="extra timed windows of --steps steps (median / p95)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (PCIe-inclusive) measurement")
     ap.add_argument("--dump-profile", default="", help="write the per-launch profile of the roofline pass to this JSON file")
     return ap.parse_args()
 
 
-def build_models(args, workdir, engine_factory, imgs_dev):
+def build_models(args, workdir, engine_factory, cal_imgs):
     """Export the synthetic detector, calibrate its class bias with one untimed GPU pass, and
     return (param, bin, classifier_state, spec)."""
     from litepi import ncnn_export
@@ -74,8 +88,8 @@ def build_models(args, workdir, engine_factory, imgs_dev):
     spec = ncnn_export.export_detector(param, binf, args.preset, seed=1234, cls_bias=0.0)
     eng = engine_factory()
     eng.load_detector(param, binf)
-    nb = min(8, imgs_dev.shape[0])
-    out0 = eng.detect_raw(imgs_dev[:nb].cpu().numpy())
+    nb = min(8, cal_imgs.shape[0])
+    out0 = eng.detect_raw(cal_imgs[:nb])
     eng.close()
     s = np.sort(out0[:, 4].astype(np.float64).ravel())[::-1]
     kth = min(max(s[TARGET_CANDIDATES * nb], 1e-6), 1 - 1e-6)
@@ -86,7 +100,8 @@ def build_models(args, workdir, engine_factory, imgs_dev):
 
 
 def cpu_baseline(param, binf, cls_state, imgs_np, n_images):
-    """Reference path restated on CPU (oracle/), timed image by image like e2e.py's loop."""
+    """Reference path restated on CPU (oracle/), timed image by image like e2e.py's loop; once on the GPU's whole CPU
+    share and once on 4 threads (the paper's Raspberry Pi 5 setting)."""
     from oracle import ncnn_ref, pipeline_ref, shufflenet_ref
 
     layers = ncnn_ref.load_model(param, binf)
@@ -96,19 +111,27 @@ def cpu_baseline(param, binf, cls_state, imgs_np, n_images):
     assert not [k for k in missing.missing_keys if "num_batches_tracked" not in k], missing
     model.eval()
     pipe = pipeline_ref.CpuPipeline(layers, model)
+
+    def run(threads, n):
+        torch.set_num_threads(threads)
+        pipe.run(imgs_np[0], CONF, IOU, MIN_AREA)  # warm-up
+        t0 = time.perf_counter()
+        ndet = 0
+        for i in range(n):
+            res, _ = pipe.run(imgs_np[i % len(imgs_np)], CONF, IOU, MIN_AREA)
+            ndet += len(res)
+        dt = time.perf_counter() - t0
+        return n / dt, ndet, dt
+
     # the GPU box gives one GPU a 16-core CPU share; oneDNN at batch 1 does not scale past that
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    cores = torch.get_num_threads()
-    pipe.run(imgs_np[0], CONF, IOU, MIN_AREA)  # warm-up
-    t0 = time.perf_counter()
-    ndet = 0
-    for i in range(n_images):
-        res, _ = pipe.run(imgs_np[i % len(imgs_np)], CONF, IOU, MIN_AREA)
-        ndet += len(res)
-    dt = time.perf_counter() - t0
-    return {"value": n_images / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+    cores = min(16, os.cpu_count() or 1)
+    v, ndet, dt = run(cores, n_images)
+    n4 = max(16, n_images // 4)
+    v4, _, dt4 = run(min(4, cores), n4)
+    return {"value": v, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{n_images} of the bench images, batch 1, fp32 torch-CPU convs + NumPy post-processing "
-                      f"(oracle/pipeline_ref.py), {ndet} classified ROIs, {dt:.1f} s"}
+                      f"(oracle/pipeline_ref.py), {ndet} classified ROIs, {dt:.1f} s",
+            "value_4_threads": v4, "sample_4_threads": f"{n4} images, {dt4:.1f} s, torch.set_num_threads(4)"}
 
 
 def main():
@@ -129,9 +152,9 @@ def main():
     from litepi import Engine
     from litepi.distributed import Gatherer, alloc_result_buffers
 
-    B = args.batch
+    B, NB, K = args.batch, max(1, args.nbatches), args.steps
     rng = np.random.default_rng(1 + rank)
-    imgs_np = rng.integers(0, 256, (B, 640, 640, 3), dtype=np.uint8)
+    imgs_np = rng.integers(0, 256, (NB, B, 640, 640, 3), dtype=np.uint8)
     imgs = torch.from_numpy(imgs_np).to(dev)
 
     def engine_factory():
@@ -140,7 +163,7 @@ def main():
 
     workdir = tempfile.mkdtemp(prefix=f"litepi_bench_r{rank}_")
     # every rank calibrates on rank 0's images so that all replicas are identical
-    cal_imgs = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (8, 640, 640, 3), dtype=np.uint8)).to(dev)
+    cal_imgs = np.random.default_rng(1).integers(0, 256, (8, 640, 640, 3), dtype=np.uint8)
     param, binf, cls_state, spec = build_models(args, workdir, engine_factory, cal_imgs)
 
     # args.inflight pipeline handles, each with its own (non-default torch) stream and buffers:
@@ -154,52 +177,95 @@ def main():
         st = torch.cuda.Stream(device=dev)
         e.set_stream(st.cuda_stream)
         engs.append(e); streams.append(st); outs.append(alloc_result_buffers(B, args.max_det, dev))
+    NH = len(engs)
     eng, (dets, counts) = engs[0], outs[0]
     gatherers = [Gatherer(o, dst=0) for o in outs]   # receive slots allocated once (rank 0), nothing per step
     torch.cuda.synchronize()
     step_no = [0]
 
     def step():
-        i = step_no[0] % len(engs)
+        k = step_no[0]
         step_no[0] += 1
+        i, j = k % NH, k % NB
         d, c = outs[i]
         with torch.cuda.stream(streams[i]):
-            engs[i].run_batch_device(imgs.data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
+            engs[i].run_batch_device(imgs[j].data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
             if world > 1:
                 return gatherers[i].gather(outs[i])
         return d, c.view(1, -1)
 
+    def timed(fn, n):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        enq = time.perf_counter() - t0   # host time to enqueue (no GPU wait unless a queue fills)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, enq
+
+    # set-up, untimed: every (handle, input batch) pair twice -- the library runs a launch sequence eagerly the first time
+    # it sees it and captures it into a hipGraph the second time; from then on a step is one graph launch
+    lcm = NH * NB // int(np.gcd(NH, NB))
+    for _ in range(2 * lcm):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gathered = step()
-    host_enqueue_s = time.perf_counter() - t0   # host time to enqueue all timed steps (no GPU wait unless a queue fills)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, host_enqueue_s = timed(step, K)
+    window_ms = [elapsed / K * 1e3]
+    for _ in range(max(0, args.windows)):
+        el, _ = timed(step, K)
+        window_ms.append(el / K * 1e3)
 
     # ---- workload facts (untimed) --------------------------------------------------------------
+    torch.cuda.synchronize()
     kept = counts[:B].sum().item()
     prefilter = counts[B:2 * B].sum().item()
 
-    # ---- roofline of the dominant kernel family: profiled passes of the same step ---------------
+    # ---- the same loop from pinned host memory (PCIe-inclusive) -------------------------------------
+    h2d = None
+    if not args.no_h2d:
+        host = [torch.from_numpy(imgs_np[j]).pin_memory() for j in range(NB)]
+        stage = [torch.empty((B, 640, 640, 3), dtype=torch.uint8, device=dev) for _ in range(NH)]
+        hstep_no = [0]
+
+        def hstep():
+            k = hstep_no[0]
+            hstep_no[0] += 1
+            i, j = k % NH, k % NB
+            d, c = outs[i]
+            with torch.cuda.stream(streams[i]):
+                stage[i].copy_(host[j], non_blocking=True)
+                engs[i].run_batch_device(stage[i].data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
+                if world > 1:
+                    return gatherers[i].gather(outs[i])
+
+        for _ in range(2 * lcm + args.warmup):
+            hstep()
+        hel, _ = timed(hstep, K)
+        h2d = {"value": world * B * K / hel, "unit": "images/sec", "ms_per_step": hel / K * 1e3,
+               "note": "batch starts in pinned host memory: hipMemcpyAsync of 78.6 MB per step on the handle's stream, then the "
+                       "same pipeline; copies of one handle overlap the kernels of the others"}
+
+    # ---- roofline of the dominant conv kernel family: profiled passes of the same step ---------------
     roofline, families = None, {}
     if rank == 0 and args.profile_steps > 0:
+        torch.cuda.synchronize()
         torch.cuda.set_stream(streams[0])
         launches = []
         for _ in range(args.profile_steps):
             eng.profile_next(True)
-            eng.run_batch_device(imgs.data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, dets.data_ptr(), counts.data_ptr())
+            eng.run_batch_device(imgs[0].data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, dets.data_ptr(), counts.data_ptr())
             torch.cuda.synchronize()
             launches.append(eng.profile_read())
         for run in launches:
@@ -209,63 +275,62 @@ def main():
         n = float(args.profile_steps)
         for f in families.values():
             f["ms"] /= n; f["flops"] /= n; f["bytes"] /= n; f["launches"] = int(f["launches"] / n)
-        dom = max(families, key=lambda k: families[k]["ms"])
+        det_fams = {k: v for k, v in families.items() if v["flops"] > 0 and not k.startswith("cls_")}
+        dom = max(det_fams, key=lambda k: det_fams[k]["ms"])
         f = families[dom]
-        # which roof bounds the dominant family: its algorithmic intensity against the ridge (2.5 PFLOP/s / 8 TB/s)
-        ridge = PEAK_FP16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
         tfl = f["flops"] / (f["ms"] * 1e-3) / 1e12
         gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
-        if f["flops"] > 0 and f["bytes"] > 0 and f["flops"] / f["bytes"] >= ridge:
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": tfl, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tfl / PEAK_FP16_TFLOPS, "traffic": None}
-        else:
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": gbs / PEAK_HBM_GBS, "traffic": None}
-        roofline["flop_per_byte"] = f["flops"] / f["bytes"] if f["bytes"] > 0 else None
-        roofline["achieved_tflops"] = tfl
-        roofline["algorithmic_bytes_per_launch"] = f["bytes"] / max(f["launches"], 1)
+        # the conv path is a dense contraction: SURVEY 8(d) prescribes the fp16 MFMA roof for it; HBM view alongside
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": tfl, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tfl / PEAK_FP16_TFLOPS, "traffic": None,
+                    "launches_per_step": f["launches"], "avg_launch_ms": f["ms"] / max(f["launches"], 1),
+                    "algorithmic_flops_per_launch": f["flops"] / max(f["launches"], 1),
+                    "algorithmic_bytes_per_launch": f["bytes"] / max(f["launches"], 1),
+                    "flop_per_byte": f["flops"] / f["bytes"] if f["bytes"] > 0 else None,
+                    "hbm_view": {"achieved_gbs": gbs, "peak_gbs": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS},
+                    "timing": "HIP events on the library's stream around every launch of profiled (eager) passes, this process"}
         # HBM bytes per launch from the PMC passes (separate rocprofv3 runs, tools/pmc_profile.sh + tools/pmc_traffic.py;
         # committed under profiles/): offline by nature, read here so that the line carries it next to `achieved`
-        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        tfile = os.path.join(_ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic.json")
         if os.path.exists(tfile) and args.preset == "v1" and args.precision == "fp16" and B == 64:
             with open(tfile) as fh:
-                fam = json.load(fh).get("families", {}).get(dom)
-            if fam:
-                roofline["traffic"] = fam["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same workload)"
-            with open(tfile) as fh:
                 fams = json.load(fh).get("families", {})
-            step_bytes = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in fams.values())
-            # whole-step view: every launch's PMC traffic over the measured step time (set below, once elapsed is known)
-            roofline["step_traffic_bytes"] = step_bytes
-        roofline["launches_per_step"] = f["launches"]
-        roofline["avg_launch_ms"] = f["ms"] / max(f["launches"], 1)
-        roofline["algorithmic_per_step"] = f["flops"] if f["flops"] > 0 else f["bytes"]
-        conv_fl = sum(v["flops"] for k, v in families.items() if k.startswith(("conv", "stem")))
+            if dom in fams:
+                roofline["traffic"] = fams[dom]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = (f"profiles/{PROFILE_ROUND}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                                              "same workload, separate passes)")
+                if "rocprof_avg_launch_ms" in fams[dom]:
+                    roofline["avg_launch_ms_rocprof"] = fams[dom]["rocprof_avg_launch_ms"]
+            roofline["step_traffic_bytes"] = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for v in fams.values())
+        conv_fl = sum(v["flops"] for k, v in det_fams.items())
+        conv_ms = sum(v["ms"] for k, v in det_fams.items())
         step_ms = sum(v["ms"] for v in families.values())
-        roofline["detector_conv_tflops_over_whole_step"] = conv_fl / (step_ms * 1e-3) / 1e12 if step_ms > 0 else None
+        roofline["detector_conv_tflops_in_conv_kernels"] = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
         roofline["profiled_step_ms"] = step_ms
+        roofline["profiled_launches"] = sum(v["launches"] for v in families.values())
+        roofline["families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(families.items(), key=lambda kv: -kv[1]["ms"])}
         if args.dump_profile:
             with open(args.dump_profile, "w") as fh:
                 json.dump({"families": families, "launches": launches[-1]}, fh, indent=1)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(param, binf, cls_state, imgs_np, args.cpu_images)
+        cpu = cpu_baseline(param, binf, cls_state, imgs_np[0], args.cpu_images)
 
     if rank == 0:
-        total_images = world * B * args.steps
-        ms_per_step = elapsed / args.steps * 1e3
+        total_images = world * B * K
+        ms_per_step = elapsed / K * 1e3
         flop_img = 2.0 * eng.det_macs
         if roofline is not None and roofline.get("step_traffic_bytes"):
             roofline["step_hbm_gbs"] = roofline["step_traffic_bytes"] / (ms_per_step * 1e-3) / 1e9
             roofline["step_hbm_frac"] = roofline["step_hbm_gbs"] / PEAK_HBM_GBS
+        wm = np.array(window_ms)
         line = {
             "metric": "images/sec end-to-end (det+NMS+clf) 640x640 batch64",
             "value": total_images / elapsed,
             "unit": "images/sec",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": K,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
@@ -280,12 +345,17 @@ def main():
                 "detector": f"YOLO-LitePi {args.preset} architecture, seeded random weights (LSUV-scaled), "
                             f"{flop_img / 1e9:.3f} GFLOP/image, class bias calibrated to ~{TARGET_CANDIDATES} candidates/image",
                 "classifier": f"ShuffleNetV2 x1.0, {NUM_CLASSES} classes, seeded random weights, 64x64 ROIs",
-                "conf": CONF, "iou": IOU, "min_area": MIN_AREA, "max_det": args.max_det, "steps_in_flight": len(engs),
-                "host_enqueue_ms_per_step": round(host_enqueue_s * 1e3 / args.steps, 4),
+                "conf": CONF, "iou": IOU, "min_area": MIN_AREA, "max_det": args.max_det, "steps_in_flight": NH,
+                "distinct_input_batches": NB,
+                "host_enqueue_ms_per_step": round(host_enqueue_s * 1e3 / K, 4),
                 "global_batch": world * B,
                 "rois_per_step_rank0": int(kept), "boxes_pre_area_filter_rank0": int(prefilter),
                 "detector_fp16_roofline_frac_e2e": (total_images / elapsed) * flop_img / (world * PEAK_FP16_TFLOPS * 1e12),
             },
+            "windows": {"n": int(len(wm)), "steps_each": K, "ms_per_step_median": float(np.median(wm)),
+                        "ms_per_step_p95": float(np.percentile(wm, 95)), "ms_per_step_min": float(wm.min()),
+                        "images_per_sec_median": world * B / (float(np.median(wm)) * 1e-3)},
+            "h2d_inclusive": h2d,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -116,6 +116,29 @@ struct lp_handle {
   std::vector<ImgGeom> geom_cache;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int last_roi_count = 0;
+  // ---- captured steps: the launch sequence of a call is a pure function of (entry point, buffers, batch, geometry,
+  //      thresholds), so the second call with the same key is captured into a hipGraph and later calls replay it
+  //      (one hipGraphLaunch instead of ~40 kernel launches on the host).  LITEPI_NO_GRAPH=1 keeps every call eager.
+  struct GraphKey {
+    int kind, B, geom_ver, min_area;
+    const void* p0; void* p1; void* p2;
+    float conf, iou;
+    bool operator==(const GraphKey& o) const {
+      return kind == o.kind && B == o.B && geom_ver == o.geom_ver && min_area == o.min_area && p0 == o.p0 && p1 == o.p1 && p2 == o.p2 &&
+             conf == o.conf && iou == o.iou;
+    }
+  };
+  struct GraphEntry { GraphKey key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool failed = false; unsigned long stamp = 0; };
+  std::vector<GraphEntry> graphs;
+  int geom_ver = 0;
+  unsigned long graph_clock = 0;
+  void drop_graphs() {
+    for (auto& g : graphs) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    graphs.clear();
+  }
 
   RoiTable roi_table() {
     RoiTable t;
@@ -124,7 +147,10 @@ struct lp_handle {
     return t;
   }
   void ensure_src(size_t bytes) {
-    if (d_src.bytes < bytes) d_src.alloc(bytes + bytes / 4, false);
+    if (d_src.bytes < bytes) {
+      d_src.alloc(bytes + bytes / 4, false);
+      ++geom_ver;  // captured steps hold the old address
+    }
   }
   void alloc_post_buffers() {
     const int B = cfg.max_batch, A = det->num_anchors(), nc = det->num_classes();
@@ -142,6 +168,7 @@ struct lp_handle {
     LP_HIP(hipMemcpyAsync(d_geom.p, g.data(), g.size() * sizeof(ImgGeom), hipMemcpyHostToDevice, stream));
     LP_HIP(hipStreamSynchronize(stream));  // g may be a temporary; uploads are rare (shape changes only)
     geom_cache = g;
+    ++geom_ver;
   }
 };
 
@@ -209,6 +236,7 @@ void lp_destroy(lp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device);
   (void)hipDeviceSynchronize();
+  h->drop_graphs();
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -221,6 +249,7 @@ int lp_load_detector_ncnn(lp_handle* h, const char* param_path, const char* bin_
   LP_HIP(hipSetDevice(h->cfg.device));
   std::unique_ptr<Detector> d(new Detector(h->cfg.precision, h->cfg.conv_impl, h->cfg.max_batch, h->cfg.det_input));
   d->load(param_path, bin_path);
+  h->drop_graphs();
   h->det = std::move(d);
   h->alloc_post_buffers();
   LP_HIP(hipDeviceSynchronize());
@@ -241,6 +270,7 @@ int lp_load_classifier_tensors(lp_handle* h, int n, const char* const* names, co
   }
   std::unique_ptr<Classifier> c(new Classifier(h->cfg.precision, h->cfg.conv_impl, h->max_rois, h->cfg.num_classes, h->cfg.cls_input));
   c->load(sd);
+  h->drop_graphs();
   h->cls = std::move(c);
   LP_HIP(hipDeviceSynchronize());
   LP_API_END
@@ -360,6 +390,55 @@ void enqueue_classify(lp_handle* h, const uint8_t* src, int B, lp_det* dets, flo
   }
 }
 
+// Run `enqueue` (kernel launches on h->stream only: no allocation, no synchronisation) eagerly the first time a key is
+// seen -- that call also performs every one-time set-up (LDS attributes, lazy packing) --, capture it into a hipGraph the
+// second time, replay the graph from then on.
+template <typename F>
+void run_or_capture(lp_handle* h, const lp_handle::GraphKey& key, bool allow, F&& enqueue) {
+  static const bool disabled = getenv("LITEPI_NO_GRAPH") != nullptr;
+  if (disabled || !allow) { enqueue(); return; }
+  lp_handle::GraphEntry* e = nullptr;
+  for (auto& g : h->graphs)
+    if (g.key == key) { e = &g; break; }
+  if (!e) {  // first sight: eager, remember the key
+    if (h->graphs.size() >= 32) {  // evict the least recently used entry
+      size_t lru = 0;
+      for (size_t i = 1; i < h->graphs.size(); ++i)
+        if (h->graphs[i].stamp < h->graphs[lru].stamp) lru = i;
+      if (h->graphs[lru].exec) (void)hipGraphExecDestroy(h->graphs[lru].exec);
+      if (h->graphs[lru].graph) (void)hipGraphDestroy(h->graphs[lru].graph);
+      h->graphs.erase(h->graphs.begin() + lru);
+    }
+    lp_handle::GraphEntry ne;
+    ne.key = key;
+    ne.stamp = ++h->graph_clock;
+    h->graphs.push_back(ne);
+    enqueue();
+    return;
+  }
+  e->stamp = ++h->graph_clock;
+  if (e->failed) { enqueue(); return; }
+  if (!e->exec) {
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { e->failed = true; enqueue(); return; }
+    bool ok = true;
+    std::string err;
+    try { enqueue(); } catch (const lp::Error& ex) { ok = false; err = ex.what(); }
+    hipGraph_t graph = nullptr;
+    if (hipStreamEndCapture(h->stream, &graph) != hipSuccess || !graph) ok = false;
+    if (ok && hipGraphInstantiate(&e->exec, graph, nullptr, nullptr, 0) != hipSuccess) { ok = false; e->exec = nullptr; }
+    if (!ok) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      e->failed = true;
+      LP_CHECK(err.empty(), LP_ERR_STATE, "%s", err.c_str());
+      enqueue();
+      return;
+    }
+    e->graph = graph;
+  }
+  LP_HIP(hipGraphLaunch(e->exec, h->stream));
+}
+
 // upload B host images of individual sizes into d_src; returns their geometry
 std::vector<ImgGeom> upload_images(lp_handle* h, const uint8_t* const* imgs, const int* hs, const int* ws, int B) {
   std::vector<ImgGeom> g(B);
@@ -413,8 +492,11 @@ int lp_detect(lp_handle* h, const uint8_t* const* imgs, const int* hs, const int
   std::vector<ImgGeom> g = upload_images(h, imgs, hs, ws, B);
   h->upload_geom(g);
   Profiler* prof = begin_profile(h);
-  enqueue_detect(h, h->d_src.as<uint8_t>(), g, B, conf, nullptr, prof);
-  enqueue_nms(h, B, iou, -1, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), false, prof);
+  lp_handle::GraphKey key{2, B, h->geom_ver, -1, h->d_src.p, h->d_dets.p, h->d_counts.p, conf, iou};
+  run_or_capture(h, key, prof == nullptr, [&]() {
+    enqueue_detect(h, h->d_src.as<uint8_t>(), g, B, conf, nullptr, prof);
+    enqueue_nms(h, B, iou, -1, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), false, prof);
+  });
   LP_HIP(hipMemcpyAsync(dets, h->d_dets.p, (size_t)B * h->cfg.max_det * sizeof(lp_det), hipMemcpyDeviceToHost, h->stream));
   LP_HIP(hipMemcpyAsync(counts, h->d_counts.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
   LP_HIP(hipStreamSynchronize(h->stream));
@@ -434,12 +516,19 @@ int lp_run_batch(lp_handle* h, const uint8_t* const* imgs, const int* hs, const 
   std::vector<ImgGeom> g = upload_images(h, imgs, hs, ws, B);
   h->upload_geom(g);
   Profiler* prof = begin_profile(h);
+  // two captured halves with the stage-boundary events between them (PipelineMetrics wants detection and classification
+  // times separately, e2e.py:452-499)
   LP_HIP(hipEventRecord(h->ev[0], h->stream));
-  enqueue_detect(h, h->d_src.as<uint8_t>(), g, B, conf, nullptr, prof);
-  LP_HIP(hipEventRecord(h->ev[1], h->stream));
-  enqueue_nms(h, B, iou, min_area, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), true, prof);
+  lp_handle::GraphKey k1{3, B, h->geom_ver, min_area, h->d_src.p, h->d_dets.p, h->d_counts.p, conf, iou};
+  run_or_capture(h, k1, prof == nullptr, [&]() {
+    enqueue_detect(h, h->d_src.as<uint8_t>(), g, B, conf, nullptr, prof);
+    enqueue_nms(h, B, iou, min_area, h->d_dets.as<lp_det>(), h->d_counts.as<int>(), true, prof);
+  });
   LP_HIP(hipEventRecord(h->ev[2], h->stream));
-  enqueue_classify(h, h->d_src.as<uint8_t>(), B, h->d_dets.as<lp_det>(), nullptr, nullptr, nullptr, prof);
+  lp_handle::GraphKey k2{4, B, h->geom_ver, min_area, h->d_src.p, h->d_dets.p, h->d_counts.p, conf, iou};
+  run_or_capture(h, k2, prof == nullptr, [&]() {
+    enqueue_classify(h, h->d_src.as<uint8_t>(), B, h->d_dets.as<lp_det>(), nullptr, nullptr, nullptr, prof);
+  });
   LP_HIP(hipEventRecord(h->ev[3], h->stream));
   LP_HIP(hipMemcpyAsync(dets, h->d_dets.p, (size_t)B * h->cfg.max_det * sizeof(lp_det), hipMemcpyDeviceToHost, h->stream));
   std::vector<int> cnt(3 * B);
@@ -481,10 +570,13 @@ int lp_run_batch_device(lp_handle* h, const void* dev_imgs, int B, int H, int W,
   h->upload_geom(g);
   Profiler* prof = begin_profile(h);
   const uint8_t* src = static_cast<const uint8_t*>(dev_imgs);
-  enqueue_detect(h, src, g, B, conf, nullptr, prof);
   const bool classify = h->cls && h->cls->loaded();
-  enqueue_nms(h, B, iou, classify ? min_area : -1, static_cast<lp_det*>(dev_dets), static_cast<int*>(dev_counts), classify, prof);
-  if (classify) enqueue_classify(h, src, B, static_cast<lp_det*>(dev_dets), nullptr, nullptr, nullptr, prof);
+  lp_handle::GraphKey key{1, B, h->geom_ver, min_area, dev_imgs, dev_dets, dev_counts, conf, iou};
+  run_or_capture(h, key, prof == nullptr, [&]() {
+    enqueue_detect(h, src, g, B, conf, nullptr, prof);
+    enqueue_nms(h, B, iou, classify ? min_area : -1, static_cast<lp_det*>(dev_dets), static_cast<int*>(dev_counts), classify, prof);
+    if (classify) enqueue_classify(h, src, B, static_cast<lp_det*>(dev_dets), nullptr, nullptr, nullptr, prof);
+  });
   if (prof) prof->enabled = false;  // records are collected by lp_profile_read after the caller synchronises
   LP_API_END
 }

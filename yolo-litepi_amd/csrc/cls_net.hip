@@ -104,17 +104,23 @@ __device__ __forceinline__ void dwconv(const char* in, int irow, char* out, int 
 #pragma unroll
       for (int j = 0; j < 4; ++j) { acc[j] = b0[j]; acc[4 + j] = b1[j]; }
     }
-#pragma unroll
+    // one window row (3 taps: 36 registers of operands) in flight at a time: the pointwise weight fragments of the
+    // surrounding GEMMs stay live across this phase, and nine taps of operands on top of them spill
+#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * STRIDE - 1 + ky;
+      if (iy < 0 || iy >= WIN) continue;
+      const char* rowp = in + ((r * WIN + iy) * WIN) * irow + cg * 16;
+      const float* wrow = w + (ky * 3) * C + cg * 8;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int iy = oy * STRIDE - 1 + ky, ix = ox * STRIDE - 1 + kx;
-        const bool ok = iy >= 0 && iy < WIN && ix >= 0 && ix < WIN;
+        const int ix = ox * STRIDE - 1 + kx;
+        const bool ok = ix >= 0 && ix < WIN;
         u32x4 raw = u32x4{0u, 0u, 0u, 0u};
-        if (ok) raw = *reinterpret_cast<const u32x4*>(in + ((r * WIN + iy) * WIN + ix) * irow + cg * 16);
+        if (ok) raw = *reinterpret_cast<const u32x4*>(rowp + ix * irow);
         const half8 v = __builtin_bit_cast(half8, raw);
-        const floatx4 w0 = *reinterpret_cast<const floatx4*>(w + (ky * 3 + kx) * C + cg * 8);
-        const floatx4 w1 = *reinterpret_cast<const floatx4*>(w + (ky * 3 + kx) * C + cg * 8 + 4);
+        const floatx4 w0 = *reinterpret_cast<const floatx4*>(wrow + kx * C);
+        const floatx4 w1 = *reinterpret_cast<const floatx4*>(wrow + kx * C + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           acc[j] = fmaf((float)v[j], w0[j], acc[j]);
@@ -136,7 +142,7 @@ __device__ __forceinline__ int shuffle_phys(int l, int bf, int bfp) { return l <
 // dw3x3 -> pw2+ReLU, then channel_shuffle.  TT tiles of 16 channels, S K steps, the wave handles tile rounds
 // t = wave, wave + 8, .. with PT pixel tiles from p0.  f1 holds this block's pw1 fragments for the wave's FIRST round on
 // entry (loaded by the caller / the previous block) and the next block's on exit (w1n; nullptr: none).
-template <int BF, int BFP, int W, int PT, int ROUNDS>
+template <int BF, int BFP, int W, int PT, int ROUNDS, bool PREF = true>
 __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, int trow, const FusedBlockW& bw, const u32x4_t* w1n, int nroi,
                                          int p0, int tile0, int tstride, u32x4 (&f1)[ROUNDS][BFP / 32 + ((BFP % 32) ? 1 : 0)], int tid) {
   constexpr int TT = BFP / 16, S = BFP / 32 + ((BFP % 32) ? 1 : 0);
@@ -144,27 +150,44 @@ __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, 
   const int g = lane >> 4, col = lane & 15;
   u32x4 f2[ROUNDS][S];
   floatx4 acc[ROUNDS][PT];
+  // A wave whose round has no tile left (15 tiles over 8 waves) recomputes the last tile and skips the stores: loads and
+  // MFMAs stay unconditional -- with the loads inside `if (tile < TT)` blocks the register allocator spilled every fragment
+  // of the block straight after loading it, one L2 round trip at a time.
+  int tc[ROUNDS];
+  bool live[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int t = tile0 + r * tstride;
+    live[r] = t < TT;
+    tc[r] = live[r] ? t : TT - 1;
+  }
   // ---- t1 = relu(W1 . x_hi + b1)
+  // PREF (stages 2, 3: 2-4 fragments per set): pw2's fragments are requested before pw1 runs and the next block's pw1
+  // fragments before the depthwise phase, so no GEMM waits for L2.  Stage 4 (16 fragments = 64 registers per set, two
+  // rounds) holds ONE set at a time: its pw1 fragments are loaded on entry (one exposed L2 round trip per block), pw2's
+  // during the depthwise phase.
+  if (PREF) {
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int t = tile0 + r * tstride;
-    if (t < TT) wload<S>(f2[r], bw.w2, t, S, lane);  // lands while pw1 + dw run
+    for (int r = 0; r < ROUNDS; ++r) wload<S>(f2[r], bw.w2, tc[r], S, lane);  // lands while pw1 + dw run
+  } else {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) wload<S>(f1[r], bw.w1, tc[r], S, lane);
   }
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
-    const int t = tile0 + r * tstride;
-    if (t < TT) {
-      zero_acc<PT>(acc[r]);
-      gemm_acc<S, PT>(f1[r], S, 0, X + BFP * 2, xrow, BFP, p0, lane, acc[r]);
-      store_relu<PT>(T1, trow, p0, t, bw.b1, acc[r], lane);
-    }
+    zero_acc<PT>(acc[r]);
+    gemm_acc<S, PT>(f1[r], S, 0, X + BFP * 2, xrow, BFP, p0, lane, acc[r]);
+    if (live[r]) store_relu<PT>(T1, trow, p0, tc[r], bw.b1, acc[r], lane);
   }
-  if (w1n) {
+  asm volatile("" ::: "memory");
+  if (PREF) {
+    if (w1n) {
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-      const int t = tile0 + r * tstride;
-      if (t < TT) wload<S>(f1[r], w1n, t, S, lane);
+      for (int r = 0; r < ROUNDS; ++r) wload<S>(f1[r], w1n, tc[r], S, lane);
     }
+  } else {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) wload<S>(f2[r], bw.w2, tc[r], S, lane);
   }
   __syncthreads();
   // ---- t2 = dw3x3(t1) + bd
@@ -174,20 +197,16 @@ __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, 
   half4 x1v[ROUNDS][PT];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
-    const int t = tile0 + r * tstride;
-    if (t < TT) {
-      zero_acc<PT>(acc[r]);
-      gemm_acc<S, PT>(f2[r], S, 0, T2, trow, BFP, p0, lane, acc[r]);
+    zero_acc<PT>(acc[r]);
+    gemm_acc<S, PT>(f2[r], S, 0, T2, trow, BFP, p0, lane, acc[r]);
 #pragma unroll
-      for (int p = 0; p < PT; ++p) x1v[r][p] = *reinterpret_cast<const half4*>(X + (p0 + p * 16 + col) * xrow + (t * 16 + 4 * g) * 2);
-    }
+    for (int p = 0; p < PT; ++p) x1v[r][p] = *reinterpret_cast<const half4*>(X + (p0 + p * 16 + col) * xrow + (tc[r] * 16 + 4 * g) * 2);
   }
   __syncthreads();  // every x_lo value is in registers before any interleaved pair is written
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
-    const int t = tile0 + r * tstride;
-    if (t < TT) {
-      const int ch0 = t * 16 + 4 * g;
+    if (live[r]) {
+      const int ch0 = tc[r] * 16 + 4 * g;
       const floatx4 bias = *reinterpret_cast<const floatx4*>(bw.b2 + ch0);
 #pragma unroll
       for (int p = 0; p < PT; ++p) {
@@ -227,8 +246,7 @@ __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, 
 
 __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, col = lane & 15;
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int R = *a.m_dyn;
   if ((int)blockIdx.x >= R) return;
   char* IN = smem + CF_IN;
@@ -237,11 +255,15 @@ __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArg
   char* X2 = smem + CF_X2;
   char* T2 = smem;  // [64 px][144]: the IN region is dead once the stem has run
   // X2's padding channels are never written by the shuffle stores and must read as zero
-  for (int i = tid; i < 64 * CF_X2ROW / 16; i += CN_THREADS) *reinterpret_cast<u32x4*>(X2 + i * 16) = u32x4{0u, 0u, 0u, 0u};
-  if (tid < 2) *reinterpret_cast<u32x4*>(smem + (tid ? CF_IN + 12288 : 0)) = u32x4{0u, 0u, 0u, 0u};  // guards
-  const half8 sa0 = __builtin_bit_cast(half8, a.stem_w[lane]), sa1 = __builtin_bit_cast(half8, a.stem_w[64 + lane]);
+  for (int i = tid0; i < 64 * CF_X2ROW / 16; i += CN_THREADS) *reinterpret_cast<u32x4*>(X2 + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  if (tid0 < 2) *reinterpret_cast<u32x4*>(smem + (tid0 ? CF_IN + 12288 : 0)) = u32x4{0u, 0u, 0u, 0u};  // guards
+  const half8 sa0 = __builtin_bit_cast(half8, a.stem_w[lane0]), sa1 = __builtin_bit_cast(half8, a.stem_w[64 + lane0]);
 
   for (int r = blockIdx.x; r < R; r += gridDim.x) {
+    int tid = tid0, lane = lane0;  // see cls_back_kernel: keeps per-lane addresses from being hoisted out of the ROI loop
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, col = lane & 15;
     // ---- crop -> LDS (12288 B, 16 B per lane)
     {
       const u32x4* src = reinterpret_cast<const u32x4*>(a.rgb + (size_t)r * 12288);
@@ -439,8 +461,7 @@ __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArg
 
 __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, col = lane & 15;
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int R = *a.m_dyn;
   const int ngroups = (R + 3) >> 2;
   if ((int)blockIdx.x >= ngroups) return;
@@ -449,9 +470,15 @@ __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs 
   char* RC = smem + CB_RC;
   char* X4 = smem + CB_X4;
   // X4's padding channels are never written by the shuffle stores and must read as zero
-  for (int i = tid; i < 16 * CB_X4ROW / 16; i += CN_THREADS) *reinterpret_cast<u32x4*>(X4 + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  for (int i = tid0; i < 16 * CB_X4ROW / 16; i += CN_THREADS) *reinterpret_cast<u32x4*>(X4 + i * 16) = u32x4{0u, 0u, 0u, 0u};
 
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // per-lane addresses must not be hoisted out of this loop: LICM otherwise keeps ~100 loop-invariant address registers
+    // live across the whole network and spills them (360 spilled registers measured)
+    int tid = tid0, lane = lane0;
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, col = lane & 15;
     const int roi0 = grp * 4;
     const int nroi = (R - roi0) < 4 ? (R - roi0) : 4;
     u32x4 f3[1][4];
@@ -475,41 +502,49 @@ __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs 
     char* T2 = RC + 16 * CF_X3ROW;       // [16 px][496]
     u32x4 f4[2][8];
     {
-      u32x4 fa[2][8];
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-        if (wave + 8 * r < 15) wload<8>(fa[r], a.s40.pw1, wave + 8 * r, 8, lane);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int t = wave + 8 * r;
-        if (t < 15) {
-          floatx4 acc[4];
-          zero_acc<4>(acc);
-          gemm_acc<8, 4>(fa[r], 8, 0, X3, CF_X3ROW, 256, 0, lane, acc);
-          store_relu<4>(T1, CB_T4ROW, 0, t, a.s40.pw1b, acc, lane);
-        }
+      // 15 tiles over 8 waves: round 1 of wave 7 recomputes tile 14 and stores nothing (see s1_block).  No 16-fragment
+      // set is kept across a depthwise phase; each is requested right before the barrier that precedes its GEMM.
+      // branch1: dw -> pw (result kept in 8 registers); branch2: pw -> dw -> pw.
+      const int t0 = wave, t1 = wave + 8 < 15 ? wave + 8 : 14;
+      const bool live1 = wave + 8 < 15;
+      floatx4 y1[2][1];
+      {
+        u32x4 fb[2][8];
+        wload<8>(fb[0], a.s40.pwb1, t0, 8, lane);
+        wload<8>(fb[1], a.s40.pwb1, t1, 8, lane);
+        dwconv<256, 4, 2, 2>(X3, CF_X3ROW, D1, CF_X3ROW, a.s40.dw1, a.s40.dw1b, 4, tid);
+        __syncthreads();
+        zero_acc<1>(y1[0]);
+        zero_acc<1>(y1[1]);
+        gemm_acc<8, 1>(fb[0], 8, 0, D1, CF_X3ROW, 256, 0, lane, y1[0]);
+        gemm_acc<8, 1>(fb[1], 8, 0, D1, CF_X3ROW, 256, 0, lane, y1[1]);
       }
-      u32x4 fb[2][8], fc[2][8];
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-        if (wave + 8 * r < 15) {
-          wload<8>(fb[r], a.s40.pwb1, wave + 8 * r, 8, lane);
-          wload<8>(fc[r], a.s40.pw2, wave + 8 * r, 8, lane);
-        }
-      dwconv<256, 4, 2, 2>(X3, CF_X3ROW, D1, CF_X3ROW, a.s40.dw1, a.s40.dw1b, 4, tid);
+      asm volatile("" ::: "memory");
+      {
+        u32x4 fa[2][8];
+        wload<8>(fa[0], a.s40.pw1, t0, 8, lane);
+        wload<8>(fa[1], a.s40.pw1, t1, 8, lane);
+        floatx4 acc[4];
+        zero_acc<4>(acc);
+        gemm_acc<8, 4>(fa[0], 8, 0, X3, CF_X3ROW, 256, 0, lane, acc);
+        store_relu<4>(T1, CB_T4ROW, 0, t0, a.s40.pw1b, acc, lane);
+        zero_acc<4>(acc);
+        gemm_acc<8, 4>(fa[1], 8, 0, X3, CF_X3ROW, 256, 0, lane, acc);
+        if (live1) store_relu<4>(T1, CB_T4ROW, 0, t1, a.s40.pw1b, acc, lane);
+      }
+      u32x4 fc[2][8];
+      wload<8>(fc[0], a.s40.pw2, t0, 8, lane);
+      wload<8>(fc[1], a.s40.pw2, t1, 8, lane);
       __syncthreads();
       dwconv<240, 4, 2, 2>(T1, CB_T4ROW, T2, CB_T4ROW, a.s40.dw2, a.s40.dw2b, 4, tid);
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int t = wave + 8 * r;
-        if (t < 15) {
-          floatx4 y1[1], y2[1];
-          zero_acc<1>(y1);
-          zero_acc<1>(y2);
-          gemm_acc<8, 1>(fb[r], 8, 0, D1, CF_X3ROW, 256, 0, lane, y1);
-          gemm_acc<8, 1>(fc[r], 8, 0, T2, CB_T4ROW, 240, 0, lane, y2);
-          wload<8>(f4[r], a.s4[0].w1, t, 8, lane);
+        const int t = r ? t1 : t0;
+        floatx4 y2[1];
+        zero_acc<1>(y2);
+        gemm_acc<8, 1>(fc[r], 8, 0, T2, CB_T4ROW, 240, 0, lane, y2);
+        if (r == 0 || live1) {
           const int ch0 = t * 16 + 4 * g;
           const floatx4 b1 = *reinterpret_cast<const floatx4*>(a.s40.pwb1b + ch0), b2 = *reinterpret_cast<const floatx4*>(a.s40.pw2b + ch0);
 #pragma unroll
@@ -517,19 +552,22 @@ __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs 
             const int c = ch0 + i;
             if (c < BF4) {
               half2v pr;
-              pr[0] = (half_t)fmaxf(y1[0][i] + b1[i], 0.f);
+              pr[0] = (half_t)fmaxf(y1[r][0][i] + b1[i], 0.f);
               pr[1] = (half_t)fmaxf(y2[0][i] + b2[i], 0.f);
               *reinterpret_cast<half2v*>(X4 + col * CB_X4ROW + shuffle_phys(2 * c, BF4, BFP4) * 2) = pr;
             }
           }
         }
       }
+      asm volatile("" ::: "memory");
+      wload<8>(f4[0], a.s4[0].w1, t0, 8, lane);
+      wload<8>(f4[1], a.s4[0].w1, t1, 8, lane);
     }
     __syncthreads();
     // ================= stage4.1-3 on 4 x (2x2) pixels =================
 #pragma unroll 1
     for (int b = 0; b < 3; ++b)
-      s1_block<BF4, BFP4, 2, 1, 2>(X4, CB_X4ROW, RB, RB + 16 * CB_T4ROW, CB_T4ROW, a.s4[b], b + 1 < 3 ? a.s4[b + 1].w1 : nullptr, 4, 0, wave, 8, f4, tid);
+      s1_block<BF4, BFP4, 2, 1, 2, true>(X4, CB_X4ROW, RB, RB + 16 * CB_T4ROW, CB_T4ROW, a.s4[b], b + 1 < 3 ? a.s4[b + 1].w1 : nullptr, 4, 0, wave, 8, f4, tid);
 
     // ================= conv5 1x1 (464 -> 1024) + ReLU, mean over the 2x2 map =================
     char* Mn = RC;                                              // [4 ROIs][1024] fp16
