@@ -29,6 +29,9 @@ struct ConvLayer {
   int T2 = 0, Cout2 = 0, act2 = ACT_NONE;
   DevBuf d_w2, d_bias2;
   std::string name;
+  // host copies of the physical fp32 weights (build / attach_tail arguments): the Detect-head fusion re-packs them into
+  // one weight stream (HeadLayer); a few MB per model
+  std::vector<float> w_host, b_host, w2_host, b2_host;
   double macs_per_pixel() const { return (double)k * k * Cin * Cout; }
 
   // w_phys: fp32 [Cout][k*k][Cin] over PHYSICAL channels (zeros at padding channels);

@@ -1435,6 +1435,8 @@ void ConvLayer::build(int prec_, int impl_, int k_, int stride_, int cin, int co
   const int G = prec == LP_FP16 ? 8 : 4;
   const size_t es = elem_size(prec);
   const int tiles_total = ceil_div(Cout, 16);
+  w_host = w_phys;
+  b_host = bias_phys;
 
   // bias, padded so every quad load is in bounds
   std::vector<float> b(round_up(Cout, 64) + 64, 0.f);
@@ -1592,6 +1594,8 @@ void ConvLayer::attach_tail(int cout2_phys, int act2_, const std::vector<float>&
   T2 = ceil_div(cout2_phys, 16);
   Cout2 = cout2_phys;
   act2 = act2_;
+  w2_host = w2_phys;
+  b2_host = bias2_phys;
   const int G = prec == LP_FP16 ? 8 : 4;
   const int S2 = prec == LP_FP16 ? (NT + 1) / 2 : NT;
   std::vector<uint8_t> buf((size_t)T2 * S2 * 64 * 16, 0);

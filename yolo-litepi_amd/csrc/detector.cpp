@@ -96,7 +96,8 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   const size_t es = prec_ == LP_FP16 ? 2 : 4;
 
   tensors_.clear(); blob2tensor_.clear(); buffers_.clear(); convs_.clear(); ops_.clear(); levels_.clear();
-  bnecks_.clear(); dws_.clear(); attns_.clear();
+  bnecks_.clear(); dws_.clear(); attns_.clear(); heads_.clear();
+  fused_head_ = false;
   loaded_ = false;
 
   std::map<std::string, int> producer;
@@ -835,6 +836,75 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   LP_HIP(hipMemcpy(d_strides_.p, strides->data.data(), strides->data.size() * 4, hipMemcpyHostToDevice));
   d_dfl_.alloc(dfl.size() * 4);
   LP_HIP(hipMemcpy(d_dfl_.p, dfl.data(), dfl.size() * 4, hipMemcpyHostToDevice));
+
+  // ---- Detect-head fusion (fp16 MFMA plan; LITEPI_NO_HEADFUSE=1: off).  Per level the planner has emitted three ops:
+  //      A = the two first 3x3 convs merged (sibling merge: box tower 64 | class tower c3 channels in one buffer),
+  //      B = box tower's second 3x3 + its 1x1 projection (fused tail), C = the same for the class tower.  When every level
+  //      has exactly this shape, each (A, B, C) triple becomes one HEAD op (head_fused_kernel) that also decodes and filters,
+  //      and the stand-alone decode launch disappears.
+  if (!getenv("LITEPI_NO_HEADFUSE") && prec_ == LP_FP16 && impl_ == IMPL_MFMA && reg_max_ == 16) {
+    struct Trip { int a, b, c, c3; };
+    std::vector<Trip> trips;
+    auto producer_of = [&](int tensor) {
+      for (size_t q = 0; q < ops_.size(); ++q)
+        if (ops_[q].kind == DetOp::CONV && ops_[q].out == tensor) return (int)q;
+      return -1;
+    };
+    bool all = true;
+    for (auto& lv : levels_) {
+      const int ob = producer_of(lv.box), oc = producer_of(lv.cls);
+      if (ob < 0 || oc < 0) { all = false; break; }
+      const ConvLayer& cb = *convs_[ops_[ob].conv];
+      const ConvLayer& cc = *convs_[ops_[oc].conv];
+      const Tensor& tb = tensors_[ops_[ob].in];
+      const Tensor& tc = tensors_[ops_[oc].in];
+      bool ok = cb.k == 3 && cb.stride == 1 && cb.T2 > 0 && cb.act == ACT_SILU && cb.act2 == ACT_NONE && cb.Cin == 64 && cb.Cout == 64 &&
+                cb.Cout2 == 64 && cc.k == 3 && cc.stride == 1 && cc.T2 > 0 && cc.act == ACT_SILU && cc.act2 == ACT_NONE && cc.Cin == cc.Cout &&
+                ops_[ob].res < 0 && ops_[oc].res < 0 && tb.buf >= 0 && tb.buf == tc.buf && tb.parent < 0 && tc.parent < 0 && tb.off == 0 &&
+                tc.off == tb.Cp && tb.Cp == 64 && tc.Cp == cc.Cin && buffers_[tb.buf].Cp == 64 + cc.Cin;
+      int oa = -1;
+      for (size_t q = 0; ok && q < ops_.size(); ++q)
+        if (ops_[q].kind == DetOp::CONV && ops_[q].out >= 0 && tensors_[ops_[q].out].buf == tb.buf && (int)q != ob && (int)q != oc) oa = (int)q;
+      ok = ok && oa >= 0 && oa < ob && oa < oc;
+      if (ok) {
+        const ConvLayer& ca = *convs_[ops_[oa].conv];
+        const Tensor& ti = tensors_[ops_[oa].in];
+        ok = ca.k == 3 && ca.stride == 1 && ca.T2 == 0 && ca.act == ACT_SILU && ca.Cout == 64 + cc.Cin && ops_[oa].res < 0 && ops_[oa].in2 < 0 &&
+             ca.Cin == ti.Cp && !ca.b_host.empty() && tensors_[lv.cls].C == nc_ &&
+             HeadLayer::supported(ca.Cin, 64, cc.Cin, nc_, reg_max_, lv.H, lv.W);
+      }
+      if (!ok) { all = false; break; }
+      trips.push_back({oa, ob, oc, cc.Cin});
+    }
+    if (all && trips.size() == levels_.size()) {
+      std::vector<char> dead(ops_.size(), 0);
+      for (size_t q = 0; q < trips.size(); ++q) {
+        const Trip& t = trips[q];
+        const ConvLayer& ca = *convs_[ops_[t.a].conv];
+        const ConvLayer& cb = *convs_[ops_[t.b].conv];
+        const ConvLayer& cc = *convs_[ops_[t.c].conv];
+        HeadLayer::Src src;
+        src.wa = &ca.w_host; src.ba = &ca.b_host;
+        src.wbb = &cb.w_host; src.bbb = &cb.b_host; src.wpb = &cb.w2_host; src.bpb = &cb.b2_host;
+        src.wbc = &cc.w_host; src.bbc = &cc.b_host; src.wpc = &cc.w2_host; src.bpc = &cc.b2_host;
+        src.ncp = cc.Cout2;
+        heads_.emplace_back(new HeadLayer());
+        heads_.back()->name = ops_[t.a].layer + "+" + ops_[t.b].layer + "+" + ops_[t.c].layer + "+decode";
+        heads_.back()->build(ca.Cin, t.c3, nc_, levels_[q].H, levels_[q].W, maxB_, src);
+        DetOp& op = ops_[t.a];
+        op.kind = DetOp::HEAD; op.conv = (int)heads_.size() - 1; op.in2 = (int)q; op.out = -1;
+        op.layer = heads_.back()->name;
+        op.flops = ops_[t.a].flops + ops_[t.b].flops + ops_[t.c].flops;
+        op.bytes = (double)tensors_[op.in].C * levels_[q].H * levels_[q].W * esd;
+        dead[t.b] = dead[t.c] = 1;
+      }
+      std::vector<DetOp> kept;
+      for (size_t q = 0; q < ops_.size(); ++q)
+        if (!dead[q]) kept.push_back(ops_[q]);
+      ops_.swap(kept);
+      fused_head_ = true;
+    }
+  }
   loaded_ = true;
 }
 
@@ -904,9 +974,15 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         launch_copy(prec_, view(op.in), view(op.out), B, st);
         kname = std::string("copy") + sfx;
         break;
+      case DetOp::HEAD:
+        heads_[op.conv]->launch(view(op.in), B, levels_[op.in2].off, A_, d_anchors_.as<float>(), d_strides_.as<float>(), d_dfl_.as<float>(), out0,
+                                geom, cand, cand_count, conf, st);
+        kname = std::string("head_fused") + sfx;
+        break;
     }
     if (prof) prof->end(st, kname, op.layer, op.flops * B, op.bytes * B);
   }
+  if (fused_head_) return;  // every level decoded and filtered inside its head kernel
   DecodeArgs a;
   memset(&a, 0, sizeof(a));
   a.nlevels = (int)levels_.size();

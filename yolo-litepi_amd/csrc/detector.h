@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "conv.h"
+#include "head.h"
 #include "kernels.h"
 #include "ncnn_graph.h"
 
@@ -35,7 +36,7 @@ struct Tensor {
 struct Buffer { int Cp = 0, H = 0, W = 0; DevBuf mem; };
 
 struct DetOp {
-  enum Kind { STEM, STEMBLOCK, CONV, BNECK, DWCONV, ATTN, UPSAMPLE, SPPF, ADD, COPY } kind = CONV;
+  enum Kind { STEM, STEMBLOCK, CONV, BNECK, DWCONV, ATTN, UPSAMPLE, SPPF, ADD, COPY, HEAD } kind = CONV;
   int conv = -1;                 // index into convs (CONV) / bnecks (BNECK)
   int in = -1, in2 = -1, res = -1, out = -1, out2 = -1, out3 = -1;
   std::string layer;
@@ -68,6 +69,8 @@ class Detector {
   std::vector<Buffer> buffers_;
   std::vector<std::unique_ptr<ConvLayer>> convs_;
   std::vector<std::unique_ptr<BottleneckPair>> bnecks_;
+  std::vector<std::unique_ptr<HeadLayer>> heads_;  // fused Detect head, one per level (fp16 MFMA plan)
+  bool fused_head_ = false;                        // every level fused: the stand-alone decode launch is gone
   // YOLO11 extras: stand-alone depthwise convs and the C2PSA attention block
   struct DwLayer { DevBuf w, b; int act = ACT_NONE; };
   struct AttnLayer { DevBuf pe_w, pe_b; int heads = 0, dk = 0, dv = 0; float scale = 1.f; };

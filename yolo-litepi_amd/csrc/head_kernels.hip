@@ -1,0 +1,535 @@
+// Fused Detect head of one pyramid level on gfx950 (fp16 storage, fp32 accumulate): ONE launch runs
+//     box tower  : 3x3 (Cin -> 64) + SiLU -> 3x3 (64 -> 64) + SiLU -> 1x1 (64 -> 4 x 16 DFL logits)
+//     class tower: 3x3 (Cin -> c3) + SiLU -> 3x3 (c3 -> c3) + SiLU -> 1x1 (c3 -> nc)
+//     decode     : softmax over the 16 bins of each box side, expectation, dist2bbox, x stride, class sigmoid,
+//                  conf filter / xywh->xyxy / un-letterbox / clip -> candidates (+ out0 when requested)
+// i.e. the reference graph's Detect module for one level (model.ncnn.param:151-182) plus its decode tail (:184-208)
+// and the filter half of NCNNDetector.postprocess (e2e.py:255-278).  This is 51.5 % of the detector's FLOPs; the
+// layer-at-a-time plan wrote and re-read the 96-channel first-conv output and the 65-channel projections through HBM
+// and needed four launches per level.
+//
+// One workgroup (4 waves, one per SIMD) owns a TH x TW tile of anchors of one image:
+//   stage A  both first 3x3 convs as one GEMM (64 + 32*C3T output channels) over the (TH+2) x (TW+2) region stage B
+//            needs; result (zero outside the image = stage B's padding) -> LDS image MID, fp16
+//   stage B  the second 3x3 convs from MID; accumulators stay in registers
+//   stage C  the 1x1 projections straight from the stage-B accumulators: a 32x32 accumulator tile (channel rows in the
+//            registers, pixel on the lane) IS the B operand of the next MFMA once its rows are rounded to fp16, with the
+//            projection's K order permuted to match (MI355X guide, "an accumulator tile as the next MFMA's operand")
+//   decode   in registers: the projection rows are permuted so that a lane holds the 16 bins of one box side
+// MFMA: v_mfma_f32_32x32x16_f16, D[out-channel][pixel] = W . X.  A wave computes RT (or 2) row tiles x P pixel tiles per
+// K step: (RT + P) KB of LDS operands per RT*P MFMAs of 32 cycles -> 20-45 % of the LDS rate, so the matrix pipe is
+// the limiter.  Weights: every workgroup consumes the same 150-300 fragments (1 KiB each) in the same order, so the
+// host packs them into one stream and the kernel moves it through a two-slot LDS ring by LDS-DMA (global_load_lds),
+// chunk c+1 in flight while chunk c is consumed; the input tile is staged by LDS-DMA too.
+#include "head.h"
+#include "post_dev.h"
+
+namespace lp {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define HD_RING 24576  /* bytes per ring slot = 24 fragments */
+#define HD_GLDS16(gptr, lptr)                                                                        \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),          \
+                                   (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
+
+__device__ __forceinline__ float hd_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ half8 lds_h8(const char* p) { return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(p)); }
+__device__ __forceinline__ floatx16 mfma32(half8 a, half8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <int C3T, int PA, int PB>
+__global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
+  constexpr int RT = 2 + C3T;       // row tiles (32 channels) of the merged first convs: box 2 | class C3T
+  constexpr int SPM = 4 * RT + 1;   // 16-byte slots per MID pixel, one of them padding (odd: conflict-free pixel stride)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int n = blockIdx.x % a.N, tile = blockIdx.x / a.N;   // image fastest: an image's tiles meet in one XCD's L2
+  const int ty0 = tile / a.tiles_x, tx0 = tile - ty0 * a.tiles_x;
+  const int oy0 = ty0 * a.TH, ox0 = tx0 * a.TW;
+  const int TH = a.TH, TW = a.TW, KPT = a.KPT;
+  const int RWin = TW + 4, IHin = TH + 4, SPin = 2 * KPT + 1, RSin = RWin * SPin;
+  const int RW1 = TW + 2, R1 = (TH + 2) * RW1, R2 = TH * TW;
+  const int nA = (R1 + 31) >> 5, nB = (R2 + 31) >> 5;
+  char* IN = smem;
+  char* MID = smem + ((IHin * RSin * 16 + 1023) & ~1023);
+  char* RING = MID + ((R1 * SPM * 16 + 1023) & ~1023);
+  const char* zeros = reinterpret_cast<const char*>(a.zeros);
+  const char* wstream = reinterpret_cast<const char*>(a.wstream);
+
+  // ---- weight-stream chunk c -> ring slot c & 1 (nothing waits here)
+  auto issue = [&](int c) {
+    const char* src = wstream + (size_t)a.coff[c] * 1024 + lane * 16;
+    char* dst = RING + (c & 1) * HD_RING;
+    const int nf = a.csz[c];
+    for (int p = wave; p < nf; p += 4) HD_GLDS16(src + p * 1024, dst + p * 1024);
+  };
+  // ---- input tile (halo 2) -> IN: rows of RSin 16-byte slots = (pixel, channel group); pad slots, pixels outside the
+  //      image and the row's tail read a zero line (= the conv's zero padding)
+  {
+    const int pcs = (RSin + 63) >> 6;
+    const int nitems = IHin * pcs;
+    const unsigned rcp_sp = (65536u + SPin - 1) / SPin;  // exact for sl < 2048 (host-checked)
+    const char* in_b = reinterpret_cast<const char*>(a.in);
+    for (int it = wave; it < nitems; it += 4) {
+      const int iy = it / pcs, pc = it - iy * pcs;
+      const int gy = oy0 - 2 + iy;
+      const int sl = pc * 64 + lane;
+      const int ix = (int)(((unsigned)sl * rcp_sp) >> 16), cgs = sl - ix * SPin;
+      const int gx = ox0 - 2 + ix;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ix < RWin && cgs < 2 * KPT;
+      const char* src = ok ? in_b + ((((long)n * a.H + gy) * a.W + gx) * a.in_pitch + cgs * 8) * 2 : zeros;
+      if (sl < RSin) HD_GLDS16(src, IN + (iy * RSin + pc * 64) * 16);
+    }
+  }
+  issue(0);
+
+  // ---- this lane's pixels
+  int pixA[PA];   // byte offset of the lane's stage-A pixel (region-1 pixel (ry, rx) -> IN pixel (ry, rx)), + its K half
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    int idx = 32 * (wave + 4 * p) + r;
+    idx = idx < R1 ? idx : R1 - 1;
+    const int ry = idx / RW1, rx = idx - ry * RW1;
+    pixA[p] = (ry * RWin + rx) * SPin * 16 + h * 16;
+  }
+  int pixB[PB];
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    int idx = 32 * (wave + 4 * p) + r;
+    idx = idx < R2 ? idx : R2 - 1;
+    const int ty = idx / TW, tx = idx - ty * TW;
+    pixB[p] = (ty * RW1 + tx) * SPM * 16 + h * 16;
+  }
+  const int lane16 = lane * 16;
+
+  // ======================= stage A: [64 + 32*C3T] x (9 * Cin) x region-1 pixels =======================
+  floatx16 accA[RT][PA];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accA[rt][p][i] = 0.f;
+  int c = 0;
+  {
+    int tap = 0, cg = 0;
+    const int ncA = a.nchunks - 5 - (C3T == 2 ? 2 : 0);   // stream = A chunks | 3 box-B | 1 or 3 class-B | 1 C
+    for (; c < ncA; ++c) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(c + 1);
+      const char* wb = RING + (c & 1) * HD_RING + lane16;
+      const int ks = a.cks[c];
+      // (every chunk holds a multiple of 3 K steps: the body is unrolled by 3 so that the operand reads of the next step
+      //  are in flight under the MFMAs of the current one -- one wave per SIMD has no other latency cover)
+      for (int s0 = 0; s0 < ks; s0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int s = s0 + u;
+          const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+          const int boff = ((dy * RWin + dx) * SPin + 2 * cg) * 16;
+          half8 af[RT], bf[PA];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) af[rt] = lds_h8(wb + (s * RT + rt) * 1024);
+#pragma unroll
+          for (int p = 0; p < PA; ++p) bf[p] = lds_h8(IN + pixA[p] + boff);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < PA; ++p) accA[rt][p] = mfma32(af[rt], bf[p], accA[rt][p]);
+          if (++cg == KPT) { cg = 0; ++tap; }
+        }
+      }
+    }
+  }
+  // ---- SiLU, fp16, -> MID (zero outside the image: stage B's padding).  The weight rows are permuted at pack time
+  //      so that this lane holds channels 32*rt + 16*h .. +15 of its pixel: two 16-byte stores per row tile.
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int pt = wave + 4 * p;
+    const int idx = 32 * pt + r;
+    if (pt < nA && idx < R1) {
+      const int ry = idx / RW1, rx = idx - ry * RW1;
+      const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
+      const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      char* dst = MID + idx * SPM * 16 + h * 32;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        half8 q0, q1;
+        const float* bp = a.biasA + rt * 32 + h * 16;
+        const floatx4 b0 = *reinterpret_cast<const floatx4*>(bp), b1 = *reinterpret_cast<const floatx4*>(bp + 4),
+                      b2 = *reinterpret_cast<const floatx4*>(bp + 8), b3 = *reinterpret_cast<const floatx4*>(bp + 12);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          q0[i] = inside ? (half_t)hd_silu(accA[rt][p][i] + b0[i]) : (half_t)0.f;
+          q0[4 + i] = inside ? (half_t)hd_silu(accA[rt][p][4 + i] + b1[i]) : (half_t)0.f;
+          q1[i] = inside ? (half_t)hd_silu(accA[rt][p][8 + i] + b2[i]) : (half_t)0.f;
+          q1[4 + i] = inside ? (half_t)hd_silu(accA[rt][p][12 + i] + b3[i]) : (half_t)0.f;
+        }
+        *reinterpret_cast<half8*>(dst + rt * 64) = q0;
+        *reinterpret_cast<half8*>(dst + rt * 64 + 16) = q1;
+      }
+    }
+  }
+
+  // ======================= stage B, box tower: 64 x (9 * 64) x tile pixels =======================
+  floatx16 accB[2][PB];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accB[rt][p][i] = 0.f;
+  {
+    int ks0 = 0;
+    const int cend = c + 3;
+    for (; c < cend; ++c) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (first pass: also orders the MID stores)
+      __builtin_amdgcn_s_barrier();
+      issue(c + 1);
+      const char* wb = RING + (c & 1) * HD_RING + lane16;
+#pragma unroll
+      for (int s = 0; s < 12; ++s) {
+        const int kq = ks0 + s;
+        const int tap = kq >> 2, cg = kq & 3;
+        const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+        const int boff = ((dy * RW1 + dx) * SPM + 2 * cg) * 16;
+        half8 af[2], bf[PB];
+        af[0] = lds_h8(wb + (s * 2) * 1024);
+        af[1] = lds_h8(wb + (s * 2 + 1) * 1024);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) bf[p] = lds_h8(MID + pixB[p] + boff);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int p = 0; p < PB; ++p) accB[rt][p] = mfma32(af[rt], bf[p], accB[rt][p]);
+      }
+      ks0 += 12;
+    }
+  }
+  // ======================= stage B, class tower: (32*C3T) x (9 * 32*C3T) x tile pixels =======================
+  floatx16 accC[C3T][PB];
+#pragma unroll
+  for (int rt = 0; rt < C3T; ++rt)
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accC[rt][p][i] = 0.f;
+  {
+    int kq = 0;
+    const int cend = c + (C3T == 2 ? 3 : 1);
+    for (; c < cend; ++c) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(c + 1);   // the last class chunk requests the projection chunk
+      const char* wb = RING + (c & 1) * HD_RING + lane16;
+      const int ks = a.cks[c];
+      for (int s0 = 0; s0 < ks; s0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u, ++kq) {
+          const int s = s0 + u;
+          const int tap = C3T == 2 ? kq >> 2 : kq >> 1, cg = C3T == 2 ? kq & 3 : kq & 1;
+          const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+          const int boff = ((dy * RW1 + dx) * SPM + 8 + 2 * cg) * 16;
+          half8 af[C3T], bf[PB];
+#pragma unroll
+          for (int rt = 0; rt < C3T; ++rt) af[rt] = lds_h8(wb + (s * C3T + rt) * 1024);
+#pragma unroll
+          for (int p = 0; p < PB; ++p) bf[p] = lds_h8(MID + pixB[p] + boff);
+#pragma unroll
+          for (int rt = 0; rt < C3T; ++rt)
+#pragma unroll
+            for (int p = 0; p < PB; ++p) accC[rt][p] = mfma32(af[rt], bf[p], accC[rt][p]);
+        }
+      }
+    }
+  }
+  // ======================= stage C: the 1x1 projections from the accumulators, then decode =======================
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  half8 wcb[2][4], wcc[2 * C3T];
+  {
+    const char* wb = RING + (c & 1) * HD_RING + lane16;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wcb[rt][q] = lds_h8(wb + (rt * 4 + q) * 1024);
+#pragma unroll
+    for (int q = 0; q < 2 * C3T; ++q) wcc[q] = lds_h8(wb + (8 + q) * 1024);
+  }
+  float dflw[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dflw[i] = a.dfl_w[i];
+  const ImgGeom gm = a.geom[n];
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    // B operands: element j of K step (mt, s) of this lane = channel 32*mt + 16*h + 8*s + j = accumulator register 8*s + j
+    floatx16 ob[2], oc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ob[0][i] = 0.f; ob[1][i] = 0.f; oc[i] = 0.f; }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float* bp = a.biasB + mt * 32 + h * 16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const floatx4 b0 = *reinterpret_cast<const floatx4*>(bp + 8 * s), b1 = *reinterpret_cast<const floatx4*>(bp + 8 * s + 4);
+        half8 bq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bq[j] = (half_t)hd_silu(accB[mt][p][8 * s + j] + b0[j]);
+          bq[4 + j] = (half_t)hd_silu(accB[mt][p][8 * s + 4 + j] + b1[j]);
+        }
+        ob[0] = mfma32(wcb[0][mt * 2 + s], bq, ob[0]);
+        ob[1] = mfma32(wcb[1][mt * 2 + s], bq, ob[1]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < C3T; ++mt) {
+      const float* bp = a.biasB + 64 + mt * 32 + h * 16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const floatx4 b0 = *reinterpret_cast<const floatx4*>(bp + 8 * s), b1 = *reinterpret_cast<const floatx4*>(bp + 8 * s + 4);
+        half8 bq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bq[j] = (half_t)hd_silu(accC[mt][p][8 * s + j] + b0[j]);
+          bq[4 + j] = (half_t)hd_silu(accC[mt][p][8 * s + 4 + j] + b1[j]);
+        }
+        oc = mfma32(wcc[mt * 2 + s], bq, oc);
+      }
+    }
+    // ---- decode (model.ncnn.param:184-208).  The projection rows are permuted so that this lane holds, for row tile rt,
+    //      the 16 bins of box side 2*rt + h; logits are rounded to fp16 first, as the stored projection output was.
+    float dist[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float* bp = a.biasC + rt * 32 + h * 16;
+      float l[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) l[i] = (float)(half_t)(ob[rt][i] + bp[i]);
+      float mx = l[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, l[i]);
+      float sum = 0.f, ex = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = __expf(l[i] - mx);
+        sum += e;
+        ex += e * dflw[i];
+      }
+      dist[rt] = ex / sum;
+    }
+    const float x0 = __shfl_xor(dist[0], 32), x1 = __shfl_xor(dist[1], 32);
+    const float d0 = h ? x0 : dist[0], d1 = h ? dist[0] : x0, d2 = h ? x1 : dist[1], d3 = h ? dist[1] : x1;
+    // class scores: this lane holds classes 16*h .. 16*h + 15
+    float best = -1.f;
+    int best_c = 0;
+    float sc[16];
+    {
+      const float* bp = a.biasC + 64 + h * 16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sc[i] = 1.f / (1.f + __expf(-(float)(half_t)(oc[i] + bp[i])));
+        if (16 * h + i < a.nc && sc[i] > best) { best = sc[i]; best_c = 16 * h + i; }
+      }
+    }
+    const float ob_ = __shfl_xor(best, 32);
+    const int oc_ = __shfl_xor(best_c, 32);
+    if (h == 0 && ob_ > best) { best = ob_; best_c = oc_; }   // first maximum in class order: the upper half wins only if larger
+    const int pt = wave + 4 * p;
+    const int idx = 32 * pt + r;
+    const int ty = idx / TW, tx = idx - ty * TW;
+    const int gy = oy0 + ty, gx = ox0 + tx;
+    const bool valid = pt < nB && idx < R2 && gy < a.H && gx < a.W;
+    if (valid) {
+      const int anchor = a.anchor_off + gy * a.W + gx;
+      float* o = a.out0 ? a.out0 + (long)n * (4 + a.nc) * a.A + anchor : nullptr;
+      if (o) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (16 * h + i < a.nc) o[(long)(4 + 16 * h + i) * a.A] = sc[i];
+      }
+      if (h == 0) {
+        const float ax = a.anchors[anchor], ay = a.anchors[a.A + anchor], s = a.strides[anchor];
+        const float bx1 = ax - d0, by1 = ay - d1, bx2 = ax + d2, by2 = ay + d3;
+        const float cx = (bx1 + bx2) * 0.5f * s, cy = (by1 + by2) * 0.5f * s;
+        const float w = (bx2 - bx1) * s, hh = (by2 - by1) * s;
+        if (o) { o[0] = cx; o[(long)a.A] = cy; o[2L * a.A] = w; o[3L * a.A] = hh; }
+        emit_candidate(cx, cy, w, hh, best, best_c, anchor, gm, a.conf, a.cand + (long)n * a.A, a.cand_count + n);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+// MFMA row rho of a 32-row tile carries physical channel 16*((rho>>2)&1) + 4*(rho>>3) + (rho&3): the D fragment of lane
+// half h then holds channels 16*h .. 16*h+15 in its 16 registers
+static inline int row_channel(int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); }
+
+static size_t head_lds(int th, int tw, int kpt, int c3t) {
+  const size_t in = ((size_t)(th + 4) * (tw + 4) * (2 * kpt + 1) * 16 + 1023) & ~(size_t)1023;
+  const size_t mid = ((size_t)(th + 2) * (tw + 2) * (4 * (2 + c3t) + 1) * 16 + 1023) & ~(size_t)1023;
+  return in + mid + 2 * HD_RING;
+}
+
+// tile shapes in order of preference: (TH, TW, PA, PB) with ceil((TH+2)(TW+2)/32) <= 4*PA, ceil(TH*TW/32) <= 4*PB
+static const int kHeadTiles[][4] = {{16, 16, 3, 2}, {10, 20, 3, 2}, {8, 16, 2, 1}, {10, 10, 2, 1}, {8, 8, 1, 1}};
+
+static bool pick_tile(int h, int w, int kpt, int c3t, int batch, int& th, int& tw, int& pa, int& pb) {
+  long best_cost = -1;
+  for (auto& t : kHeadTiles) {
+    if (head_lds(t[0], t[1], kpt, c3t) > 160 * 1024) continue;
+    // MFMA tile slots spent per image (stage A row tiles weigh 2 + c3t, stage B 2 + c3t too but over 9*64 / 9*32 K)
+    const long tiles = (long)ceil_div(h, t[0]) * ceil_div(w, t[1]);
+    const long cost = tiles * (4L * t[2] * (2 + c3t) * kpt * 9 + 4L * t[3] * (2 * 36 + c3t * c3t * 18));
+    const long wgs = tiles * batch;
+    // prefer the cheapest shape that still gives every CU a workgroup
+    const long adj = wgs < 256 ? cost * 2 : cost;
+    if (best_cost < 0 || adj < best_cost) { best_cost = adj; th = t[0]; tw = t[1]; pa = t[2]; pb = t[3]; }
+  }
+  return best_cost >= 0;
+}
+
+bool HeadLayer::supported(int cin_phys, int c2, int c3, int nc, int reg_max, int h, int w) {
+  if (c2 != 64 || reg_max != 16 || nc < 1 || nc > 32 || c3 < 8 || c3 > 64 || c3 % 8 != 0) return false;
+  if (cin_phys % 16 != 0 || cin_phys < 16 || cin_phys > 256) return false;
+  int th, tw, pa, pb;
+  return pick_tile(h, w, cin_phys / 16, c3 > 32 ? 2 : 1, 1, th, tw, pa, pb);
+}
+
+void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hint, const Src& s) {
+  Cin = cin_phys; c3 = c3_; nc = nc_; H = h; W = w;
+  C3T = c3 > 32 ? 2 : 1;
+  KPT = Cin / 16;
+  LP_CHECK(pick_tile(h, w, KPT, C3T, batch_hint > 0 ? batch_hint : 1, TH, TW, PA, PB), LP_ERR_STATE, "Detect head %s: no tile shape fits LDS", name.c_str());
+  lds_bytes = head_lds(TH, TW, KPT, C3T);
+  const int RT = 2 + C3T, CM = 32 * C3T;
+  // K steps of stage A per chunk: a divisor of 9*KPT with RT*KSA <= 24 fragments
+  KSA = 1;
+  for (int k = 1; k <= 24 / RT; ++k)
+    if ((9 * KPT) % k == 0) KSA = k;
+  std::vector<uint16_t> stream;
+  auto frag = [&](auto&& weight_of) {  // weight_of(row rho, k element e of the K step) -> float; appends one 1 KiB fragment
+    const size_t base = stream.size();
+    stream.resize(base + 512);
+    for (int lane = 0; lane < 64; ++lane)
+      for (int j = 0; j < 8; ++j) stream[base + lane * 8 + j] = f32_to_f16(weight_of(lane & 31, 8 * (lane >> 5) + j));
+  };
+  coff.clear(); csz.clear(); cks.clear();
+  auto begin_chunk = [&]() { coff.push_back((unsigned short)(stream.size() / 512)); };
+  auto end_chunk = [&](int ksteps) {
+    const size_t nf = stream.size() / 512 - coff.back();
+    LP_CHECK(nf <= 24, LP_ERR_STATE, "Detect head: chunk of %zu fragments", nf);
+    csz.push_back((unsigned char)nf);
+    cks.push_back((unsigned char)ksteps);
+  };
+  const std::vector<float>& wa = *s.wa;  // [64 + c3][9][Cin]
+  // ---- stage A: K step (tap, cg): element e = input channel 16*cg + e
+  for (int ks = 0; ks < 9 * KPT; ++ks) {
+    if (ks % KSA == 0) begin_chunk();
+    const int tap = ks / KPT, cg = ks % KPT;
+    for (int rt = 0; rt < RT; ++rt)
+      frag([&](int rho, int e) {
+        const int c = rt * 32 + row_channel(rho);          // physical MID channel
+        const int src = c < 64 ? c : (c - 64 < c3 ? 64 + (c - 64) : -1);
+        return src < 0 ? 0.f : wa[((size_t)src * 9 + tap) * Cin + 16 * cg + e];
+      });
+    if (ks % KSA == KSA - 1) end_chunk(KSA);
+  }
+  // ---- stage B box: K step kq = (tap, cg), 4 per tap
+  for (int kq = 0; kq < 36; ++kq) {
+    if (kq % 12 == 0) begin_chunk();
+    const int tap = kq >> 2, cg = kq & 3;
+    for (int rt = 0; rt < 2; ++rt)
+      frag([&](int rho, int e) { return (*s.wbb)[((size_t)(rt * 32 + row_channel(rho)) * 9 + tap) * 64 + 16 * cg + e]; });
+    if (kq % 12 == 11) end_chunk(12);
+  }
+  // ---- stage B class: 2*C3T K steps per tap
+  {
+    const int per_tap = 2 * C3T, total = 9 * per_tap, per_chunk = C3T == 2 ? 12 : 18;
+    for (int kq = 0; kq < total; ++kq) {
+      if (kq % per_chunk == 0) begin_chunk();
+      const int tap = kq / per_tap, cg = kq % per_tap;
+      for (int rt = 0; rt < C3T; ++rt)
+        frag([&](int rho, int e) {
+          const int co = rt * 32 + row_channel(rho), ci = 16 * cg + e;
+          return (co < c3 && ci < c3) ? (*s.wbc)[((size_t)co * 9 + tap) * c3 + ci] : 0.f;
+        });
+      if (kq % per_chunk == per_chunk - 1) end_chunk(per_chunk);
+    }
+  }
+  // ---- stage C: K step (mt, s): element e of lane half hh = mid channel 32*mt + 16*hh + 8*s + (e & 7), hh = e >> 3
+  begin_chunk();
+  for (int rt = 0; rt < 2; ++rt)
+    for (int q = 0; q < 4; ++q)
+      frag([&](int rho, int e) {
+        const int mt = q >> 1, sq = q & 1;
+        const int ci = 32 * mt + 16 * (e >> 3) + 8 * sq + (e & 7);
+        return (*s.wpb)[(size_t)(rt * 32 + row_channel(rho)) * 64 + ci];
+      });
+  for (int q = 0; q < 2 * C3T; ++q)
+    frag([&](int rho, int e) {
+      const int mt = q >> 1, sq = q & 1;
+      const int ci = 32 * mt + 16 * (e >> 3) + 8 * sq + (e & 7), co = row_channel(rho);
+      return (co < nc && ci < c3) ? (*s.wpc)[(size_t)co * c3 + ci] : 0.f;
+    });
+  end_chunk(0);
+  nchunks = (int)coff.size();
+  LP_CHECK(nchunks <= 39 && stream.size() / 512 < 65536, LP_ERR_STATE, "Detect head: weight stream too long");
+  coff.push_back(coff.back());  // issue(nchunks) is a no-op chunk of size 0
+  csz.push_back(0);
+  cks.push_back(0);
+  d_stream.alloc(stream.size() * 2 + 64);
+  LP_HIP(hipMemcpy(d_stream.p, stream.data(), stream.size() * 2, hipMemcpyHostToDevice));
+  std::vector<float> bA(32 * RT + 16, 0.f), bB(32 * RT + 16, 0.f), bC(64 + 32 + 16, 0.f);
+  for (int c = 0; c < 64; ++c) { bA[c] = (*s.ba)[c]; bB[c] = s.bbb->empty() ? 0.f : (*s.bbb)[c]; bC[c] = s.bpb->empty() ? 0.f : (*s.bpb)[c]; }
+  for (int c = 0; c < c3; ++c) { bA[64 + c] = (*s.ba)[64 + c]; bB[64 + c] = s.bbc->empty() ? 0.f : (*s.bbc)[c]; }
+  for (int c = 0; c < nc; ++c) bC[64 + c] = s.bpc->empty() ? 0.f : (*s.bpc)[c];
+  auto up = [](DevBuf& d, const std::vector<float>& v) {
+    d.alloc(v.size() * 4);
+    LP_HIP(hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  };
+  up(d_biasA, bA); up(d_biasB, bB); up(d_biasC, bC);
+  (void)CM;
+  macs_per_image = (double)h * w * (9.0 * Cin * (64 + c3) + 9.0 * 64 * 64 + 9.0 * c3 * c3 + 64.0 * 64 + (double)c3 * nc);
+}
+
+void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float* anchors, const float* strides, const float* dfl_w,
+                       float* out0, const ImgGeom* geom, Cand* cand, int* cand_count, float conf, hipStream_t st) const {
+  HeadArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in.base; a.in_pitch = in.pitch; a.wstream = d_stream.p;
+  a.biasA = d_biasA.as<float>(); a.biasB = d_biasB.as<float>(); a.biasC = d_biasC.as<float>();
+  a.zeros = d_biasC.as<float>() + 96;  // the bias buffer ends in 16 zero floats
+  a.anchors = anchors; a.strides = strides; a.dfl_w = dfl_w; a.out0 = out0; a.geom = geom; a.cand = cand; a.cand_count = cand_count;
+  a.conf = conf;
+  a.N = N; a.H = in.H; a.W = in.W; a.Cin = Cin;
+  a.TH = TH; a.TW = TW; a.tiles_x = ceil_div(in.W, TW); a.ntiles = a.tiles_x * ceil_div(in.H, TH);
+  a.KPT = KPT; a.nchunks = nchunks; a.A = A; a.nc = nc; a.anchor_off = anchor_off;
+  LP_CHECK(in.C == Cin && in.H == H && in.W == W && (int)coff.size() <= 40 && (TW + 4) * (2 * KPT + 1) < 2048, LP_ERR_STATE,
+           "Detect head %s: view does not match the plan", name.c_str());
+  for (size_t i = 0; i < coff.size(); ++i) { a.coff[i] = coff[i]; a.csz[i] = csz[i]; a.cks[i] = cks[i]; }
+  const dim3 grid((unsigned)(a.ntiles * N));
+#define LP_HEAD(C3T_, PA_, PB_)                                                                                   \
+  {                                                                                                               \
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_>), 160 * 1024);            \
+    hipLaunchKernelGGL((head_fused_kernel<C3T_, PA_, PB_>), grid, dim3(256), lds_bytes, st, a);                    \
+  }
+  if (C3T == 1) {
+    if (PA == 3 && PB == 2) LP_HEAD(1, 3, 2) else if (PA == 2 && PB == 1) LP_HEAD(1, 2, 1) else LP_HEAD(1, 1, 1)
+  } else {
+    if (PA == 3 && PB == 2) LP_HEAD(2, 3, 2) else if (PA == 2 && PB == 1) LP_HEAD(2, 2, 1) else LP_HEAD(2, 1, 1)
+  }
+#undef LP_HEAD
+  LP_HIP(hipGetLastError());
+}
+
+}  // namespace lp
