@@ -24,6 +24,9 @@
 #include "head.h"
 #include "post_dev.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace lp {
 
 typedef _Float16 half_t;
@@ -32,14 +35,53 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-#define HD_RING 24576  /* bytes per ring slot = 24 fragments */
+#define HD_SLOT 12288  /* bytes per ring slot = 12 fragments */
+#define HD_NSLOT 4
 #define HD_GLDS16(gptr, lptr)                                                                        \
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),          \
                                    (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
 
-__device__ __forceinline__ float hd_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+// diagnostic phase stamps (never enabled on the product path: a.stamps is null)
+#define HD_STAMP(k)                                                                                    \
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = ((k) == 0 || (k) == 15) ? wall_clock64() : clock64();
+
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+// x * sigmoid(x) for two values: the multiplies and the add are two-wide (v_pk_*_f32), the exponential and the reciprocal
+// are the hardware transcendentals (1 ulp), as Tr<half>::silu in conv_kernels.hip
+__device__ __forceinline__ floatx2 hd_silu2(floatx2 v) {
+  const floatx2 t = v * floatx2{-1.4426950408889634f, -1.4426950408889634f};
+  floatx2 e;
+  e[0] = __builtin_amdgcn_exp2f(t[0]);
+  e[1] = __builtin_amdgcn_exp2f(t[1]);
+  e = e + floatx2{1.f, 1.f};
+  floatx2 rc;
+  rc[0] = __builtin_amdgcn_rcpf(e[0]);
+  rc[1] = __builtin_amdgcn_rcpf(e[1]);
+  return v * rc;
+}
+// 8 accumulator values (bias already inside) -> SiLU -> 8 halfs
+__device__ __forceinline__ half8 silu_h8(const floatx16& acc, int base) {
+  half8 q;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const floatx2 y = hd_silu2(floatx2{acc[base + j], acc[base + j + 1]});
+    q[j] = (half_t)y[0];
+    q[j + 1] = (half_t)y[1];
+  }
+  return q;
+}
 __device__ __forceinline__ half8 lds_h8(const char* p) { return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(p)); }
 __device__ __forceinline__ floatx16 mfma32(half8 a, half8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// accumulator tile initialised with the bias of this lane's 16 channels (bias + 0 ..15)
+__device__ __forceinline__ floatx16 bias16(const float* __restrict__ b) {
+  floatx16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const floatx4 x = *reinterpret_cast<const floatx4*>(b + 4 * q);
+    v[4 * q] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
+  }
+  return v;
+}
 
 template <int C3T, int PA, int PB>
 __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
@@ -59,35 +101,73 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
   char* IN = smem;
   char* MID = smem + ((IHin * RSin * 16 + 1023) & ~1023);
   char* RING = MID + ((R1 * SPM * 16 + 1023) & ~1023);
-  const char* zeros = reinterpret_cast<const char*>(a.zeros);
-  const char* wstream = reinterpret_cast<const char*>(a.wstream);
+  // the stream exists in a.nrep copies: workgroups that share an XCD (ids 8 apart) read different copies, so the 32 CUs
+  // of an XCD do not all pull the same L2 lines at the same moment
+  const char* wstream = reinterpret_cast<const char*>(a.wstream) + (size_t)((blockIdx.x >> 3) % a.nrep) * a.rep_stride;
+  const int nch = a.nchunks;
+  HD_STAMP(0)
+  HD_STAMP(1)
 
-  // ---- weight-stream chunk c -> ring slot c & 1 (nothing waits here)
-  auto issue = [&](int c) {
-    const char* src = wstream + (size_t)a.coff[c] * 1024 + lane * 16;
-    char* dst = RING + (c & 1) * HD_RING;
-    const int nf = a.csz[c];
-    for (int p = wave; p < nf; p += 4) HD_GLDS16(src + p * 1024, dst + p * 1024);
+  // ---- weight ring: chunk c of the stream -> slot c & 3 by LDS-DMA.  EVERY wave issues exactly three 1 KiB pieces per
+  //      chunk (piece indices past the chunk's end re-read its last fragment into the slot's unused tail; chunk indices
+  //      past the stream's end re-read the last chunk into a slot nobody reads), so "chunk c has landed" is the counted
+  //      wait vmcnt(6): all but this wave's six youngest vector-memory operations -- the pieces of chunks c+1 and c+2 -- are
+  //      done.  Three chunks of prefetch (~2.5k cycles of MFMAs) cover the ~1 us a piece takes to land under load; with one
+  //      chunk of prefetch every chunk boundary stalled (stamps: 2x the MFMA time in every K loop).
+  auto issue_piece = [&](int c, int j) {
+    const int cc = c < nch ? c : nch - 1;
+    const int nf = a.csz[cc];
+    const int p = wave + 4 * j;
+    const int ps = p < nf ? p : nf - 1;
+    HD_GLDS16(wstream + ((size_t)a.coff[cc] + ps) * 1024 + lane * 16, RING + (c & (HD_NSLOT - 1)) * HD_SLOT + p * 1024);
   };
-  // ---- input tile (halo 2) -> IN: rows of RSin 16-byte slots = (pixel, channel group); pad slots, pixels outside the
-  //      image and the row's tail read a zero line (= the conv's zero padding)
+  // ---- input tile (halo 2) -> IN through registers: rows of RSin 16-byte slots = (pixel, channel group); pad slots, pixels
+  //      outside the image and the row's tail are zeros (= the conv's zero padding).  A wave takes rows wave, wave + 4, ..;
+  //      what depends on the lane only (pixel, channel group, validity of a slot) is computed once per 64-slot piece.
   {
-    const int pcs = (RSin + 63) >> 6;
-    const int nitems = IHin * pcs;
-    const unsigned rcp_sp = (65536u + SPin - 1) / SPin;  // exact for sl < 2048 (host-checked)
-    const char* in_b = reinterpret_cast<const char*>(a.in);
-    for (int it = wave; it < nitems; it += 4) {
-      const int iy = it / pcs, pc = it - iy * pcs;
-      const int gy = oy0 - 2 + iy;
+    const int pcs = (RSin + 63) >> 6;                    // <= 5 (host-checked)
+    const unsigned rcp_sp = (65536u + SPin - 1) / SPin;  // exact for slot indices < 2048 (host-checked)
+    int voff[5];
+    bool xok[5];
+#pragma unroll
+    for (int pc = 0; pc < 5; ++pc) {
       const int sl = pc * 64 + lane;
       const int ix = (int)(((unsigned)sl * rcp_sp) >> 16), cgs = sl - ix * SPin;
       const int gx = ox0 - 2 + ix;
-      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ix < RWin && cgs < 2 * KPT;
-      const char* src = ok ? in_b + ((((long)n * a.H + gy) * a.W + gx) * a.in_pitch + cgs * 8) * 2 : zeros;
-      if (sl < RSin) HD_GLDS16(src, IN + (iy * RSin + pc * 64) * 16);
+      xok[pc] = pc < pcs && sl < RSin && gx >= 0 && gx < a.W && ix < RWin && cgs < 2 * KPT;
+      voff[pc] = (ix * a.in_pitch + cgs * 8) * 2;
+    }
+    const char* in_n = reinterpret_cast<const char*>(a.in) + ((long)n * a.H * a.W) * a.in_pitch * 2;
+    u32x4 v[5][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int iy = wave + 4 * j;
+      const int gy = oy0 - 2 + iy;
+      const bool rok = iy < IHin && gy >= 0 && gy < a.H;
+      const char* rowp = in_n + ((long)gy * a.W + (ox0 - 2)) * a.in_pitch * 2;
+#pragma unroll
+      for (int pc = 0; pc < 5; ++pc) {
+        v[j][pc] = u32x4{0u, 0u, 0u, 0u};
+        if (rok && xok[pc]) v[j][pc] = *reinterpret_cast<const u32x4*>(rowp + voff[pc]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) issue_piece(0, j);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) issue_piece(1, j);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) issue_piece(2, j);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int iy = wave + 4 * j;
+#pragma unroll
+      for (int pc = 0; pc < 5; ++pc) {
+        const int sl = pc * 64 + lane;
+        if (iy < IHin && pc < pcs && sl < RSin) *reinterpret_cast<u32x4*>(IN + (iy * RSin + sl) * 16) = v[j][pc];
+      }
     }
   }
-  issue(0);
+  HD_STAMP(2)
 
   // ---- this lane's pixels
   int pixA[PA];   // byte offset of the lane's stage-A pixel (region-1 pixel (ry, rx) -> IN pixel (ry, rx)), + its K half
@@ -107,27 +187,29 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
     pixB[p] = (ty * RW1 + tx) * SPM * 16 + h * 16;
   }
   const int lane16 = lane * 16;
+  // one chunk: wait for it, let everybody leave the slot that chunk c+3 will overwrite, then run `body(wb, s, first)` for
+  // its K steps in groups of three; the three pieces of chunk c+3 are requested behind the first three K steps' MFMAs
+#define HD_CHUNK_BEGIN                                                      \
+  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");              \
+  __builtin_amdgcn_s_barrier();                                             \
+  const char* wb = RING + (c & (HD_NSLOT - 1)) * HD_SLOT + lane16;          \
+  const int ks = a.cks[c];
 
   // ======================= stage A: [64 + 32*C3T] x (9 * Cin) x region-1 pixels =======================
   floatx16 accA[RT][PA];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt) {
+    const floatx16 b = bias16(a.biasA + rt * 32 + h * 16);
 #pragma unroll
-    for (int p = 0; p < PA; ++p)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) accA[rt][p][i] = 0.f;
+    for (int p = 0; p < PA; ++p) accA[rt][p] = b;
+  }
   int c = 0;
   {
     int tap = 0, cg = 0;
-    const int ncA = a.nchunks - 5 - (C3T == 2 ? 2 : 0);   // stream = A chunks | 3 box-B | 1 or 3 class-B | 1 C
+    const int ncA = nch - (C3T == 2 ? 13 : 9);   // stream = A chunks | 6 box-B | 2 (6) class-B | 1 C
     for (; c < ncA; ++c) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      issue(c + 1);
-      const char* wb = RING + (c & 1) * HD_RING + lane16;
-      const int ks = a.cks[c];
-      // (every chunk holds a multiple of 3 K steps: the body is unrolled by 3 so that the operand reads of the next step
-      //  are in flight under the MFMAs of the current one -- one wave per SIMD has no other latency cover)
+      HD_CHUNK_BEGIN
+      if (c == 0) { HD_STAMP(3) }
       for (int s0 = 0; s0 < ks; s0 += 3) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -143,60 +225,60 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
           for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int p = 0; p < PA; ++p) accA[rt][p] = mfma32(af[rt], bf[p], accA[rt][p]);
+          if (s0 == 0) issue_piece(c + 3, u);
           if (++cg == KPT) { cg = 0; ++tap; }
         }
       }
     }
   }
+  HD_STAMP(4)
   // ---- SiLU, fp16, -> MID (zero outside the image: stage B's padding).  The weight rows are permuted at pack time
   //      so that this lane holds channels 32*rt + 16*h .. +15 of its pixel: two 16-byte stores per row tile.
+  {
+    const bool interior = oy0 >= 1 && ox0 >= 1 && oy0 + TH + 1 <= a.H && ox0 + TW + 1 <= a.W;  // block-uniform
 #pragma unroll
-  for (int p = 0; p < PA; ++p) {
-    const int pt = wave + 4 * p;
-    const int idx = 32 * pt + r;
-    if (pt < nA && idx < R1) {
-      const int ry = idx / RW1, rx = idx - ry * RW1;
-      const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
-      const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      char* dst = MID + idx * SPM * 16 + h * 32;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        half8 q0, q1;
-        const float* bp = a.biasA + rt * 32 + h * 16;
-        const floatx4 b0 = *reinterpret_cast<const floatx4*>(bp), b1 = *reinterpret_cast<const floatx4*>(bp + 4),
-                      b2 = *reinterpret_cast<const floatx4*>(bp + 8), b3 = *reinterpret_cast<const floatx4*>(bp + 12);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          q0[i] = inside ? (half_t)hd_silu(accA[rt][p][i] + b0[i]) : (half_t)0.f;
-          q0[4 + i] = inside ? (half_t)hd_silu(accA[rt][p][4 + i] + b1[i]) : (half_t)0.f;
-          q1[i] = inside ? (half_t)hd_silu(accA[rt][p][8 + i] + b2[i]) : (half_t)0.f;
-          q1[4 + i] = inside ? (half_t)hd_silu(accA[rt][p][12 + i] + b3[i]) : (half_t)0.f;
+    for (int p = 0; p < PA; ++p) {
+      const int pt = wave + 4 * p;
+      const int idx = 32 * pt + r;
+      if (pt < nA && idx < R1) {
+        bool inside = true;
+        if (!interior) {
+          const int ry = idx / RW1, rx = idx - ry * RW1;
+          const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
+          inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         }
-        *reinterpret_cast<half8*>(dst + rt * 64) = q0;
-        *reinterpret_cast<half8*>(dst + rt * 64 + 16) = q1;
+        char* dst = MID + idx * SPM * 16 + h * 32;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          half8 q0 = silu_h8(accA[rt][p], 0), q1 = silu_h8(accA[rt][p], 8);
+          if (!inside) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { q0[j] = (half_t)0.f; q1[j] = (half_t)0.f; }
+          }
+          *reinterpret_cast<half8*>(dst + rt * 64) = q0;
+          *reinterpret_cast<half8*>(dst + rt * 64 + 16) = q1;
+        }
       }
     }
   }
+  HD_STAMP(5)
 
   // ======================= stage B, box tower: 64 x (9 * 64) x tile pixels =======================
   floatx16 accB[2][PB];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < 2; ++rt) {
+    const floatx16 b = bias16(a.biasB + rt * 32 + h * 16);
 #pragma unroll
-    for (int p = 0; p < PB; ++p)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) accB[rt][p][i] = 0.f;
+    for (int p = 0; p < PB; ++p) accB[rt][p] = b;
+  }
   {
-    int ks0 = 0;
-    const int cend = c + 3;
+    int kq = 0;
+    const int cend = c + 6;
     for (; c < cend; ++c) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (first pass: also orders the MID stores)
-      __builtin_amdgcn_s_barrier();
-      issue(c + 1);
-      const char* wb = RING + (c & 1) * HD_RING + lane16;
+      HD_CHUNK_BEGIN   // (first pass: the wait + barrier also order the MID stores before the reads below)
+      (void)ks;
 #pragma unroll
-      for (int s = 0; s < 12; ++s) {
-        const int kq = ks0 + s;
+      for (int s = 0; s < 6; ++s, ++kq) {
         const int tap = kq >> 2, cg = kq & 3;
         const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
         const int boff = ((dy * RW1 + dx) * SPM + 2 * cg) * 16;
@@ -209,27 +291,24 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
           for (int p = 0; p < PB; ++p) accB[rt][p] = mfma32(af[rt], bf[p], accB[rt][p]);
+        if (s < 3) issue_piece(c + 3, s);
       }
-      ks0 += 12;
     }
   }
+  HD_STAMP(6)
   // ======================= stage B, class tower: (32*C3T) x (9 * 32*C3T) x tile pixels =======================
   floatx16 accC[C3T][PB];
 #pragma unroll
-  for (int rt = 0; rt < C3T; ++rt)
+  for (int rt = 0; rt < C3T; ++rt) {
+    const floatx16 b = bias16(a.biasB + 64 + rt * 32 + h * 16);
 #pragma unroll
-    for (int p = 0; p < PB; ++p)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) accC[rt][p][i] = 0.f;
+    for (int p = 0; p < PB; ++p) accC[rt][p] = b;
+  }
   {
     int kq = 0;
-    const int cend = c + (C3T == 2 ? 3 : 1);
+    const int cend = c + (C3T == 2 ? 6 : 2);
     for (; c < cend; ++c) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      issue(c + 1);   // the last class chunk requests the projection chunk
-      const char* wb = RING + (c & 1) * HD_RING + lane16;
-      const int ks = a.cks[c];
+      HD_CHUNK_BEGIN
       for (int s0 = 0; s0 < ks; s0 += 3) {
 #pragma unroll
         for (int u = 0; u < 3; ++u, ++kq) {
@@ -246,16 +325,17 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
           for (int rt = 0; rt < C3T; ++rt)
 #pragma unroll
             for (int p = 0; p < PB; ++p) accC[rt][p] = mfma32(af[rt], bf[p], accC[rt][p]);
+          if (s0 == 0) issue_piece(c + 3, u);
         }
       }
     }
   }
   // ======================= stage C: the 1x1 projections from the accumulators, then decode =======================
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  HD_STAMP(7)
   half8 wcb[2][4], wcc[2 * C3T];
   {
-    const char* wb = RING + (c & 1) * HD_RING + lane16;
+    HD_CHUNK_BEGIN
+    (void)ks;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -263,56 +343,37 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
 #pragma unroll
     for (int q = 0; q < 2 * C3T; ++q) wcc[q] = lds_h8(wb + (8 + q) * 1024);
   }
+  HD_STAMP(8)
   float dflw[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) dflw[i] = a.dfl_w[i];
   const ImgGeom gm = a.geom[n];
+  const floatx16 bC0 = bias16(a.biasC + h * 16), bC1 = bias16(a.biasC + 32 + h * 16), bCc = bias16(a.biasC + 64 + h * 16);
 #pragma unroll
   for (int p = 0; p < PB; ++p) {
     // B operands: element j of K step (mt, s) of this lane = channel 32*mt + 16*h + 8*s + j = accumulator register 8*s + j
     floatx16 ob[2], oc;
+    ob[0] = bC0; ob[1] = bC1; oc = bCc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { ob[0][i] = 0.f; ob[1][i] = 0.f; oc[i] = 0.f; }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const float* bp = a.biasB + mt * 32 + h * 16;
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const floatx4 b0 = *reinterpret_cast<const floatx4*>(bp + 8 * s), b1 = *reinterpret_cast<const floatx4*>(bp + 8 * s + 4);
-        half8 bq;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bq[j] = (half_t)hd_silu(accB[mt][p][8 * s + j] + b0[j]);
-          bq[4 + j] = (half_t)hd_silu(accB[mt][p][8 * s + 4 + j] + b1[j]);
-        }
+        const half8 bq = silu_h8(accB[mt][p], 8 * s);
         ob[0] = mfma32(wcb[0][mt * 2 + s], bq, ob[0]);
         ob[1] = mfma32(wcb[1][mt * 2 + s], bq, ob[1]);
       }
-    }
 #pragma unroll
-    for (int mt = 0; mt < C3T; ++mt) {
-      const float* bp = a.biasB + 64 + mt * 32 + h * 16;
+    for (int mt = 0; mt < C3T; ++mt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const floatx4 b0 = *reinterpret_cast<const floatx4*>(bp + 8 * s), b1 = *reinterpret_cast<const floatx4*>(bp + 8 * s + 4);
-        half8 bq;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bq[j] = (half_t)hd_silu(accC[mt][p][8 * s + j] + b0[j]);
-          bq[4 + j] = (half_t)hd_silu(accC[mt][p][8 * s + 4 + j] + b1[j]);
-        }
-        oc = mfma32(wcc[mt * 2 + s], bq, oc);
-      }
-    }
+      for (int s = 0; s < 2; ++s) oc = mfma32(wcc[mt * 2 + s], silu_h8(accC[mt][p], 8 * s), oc);
     // ---- decode (model.ncnn.param:184-208).  The projection rows are permuted so that this lane holds, for row tile rt,
     //      the 16 bins of box side 2*rt + h; logits are rounded to fp16 first, as the stored projection output was.
     float dist[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      const float* bp = a.biasC + rt * 32 + h * 16;
       float l[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) l[i] = (float)(half_t)(ob[rt][i] + bp[i]);
+      for (int i = 0; i < 16; ++i) l[i] = (float)(half_t)ob[rt][i];
       float mx = l[0];
 #pragma unroll
       for (int i = 1; i < 16; ++i) mx = fmaxf(mx, l[i]);
@@ -331,12 +392,12 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
     float best = -1.f;
     int best_c = 0;
     float sc[16];
-    {
-      const float* bp = a.biasC + 64 + h * 16;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        sc[i] = 1.f / (1.f + __expf(-(float)(half_t)(oc[i] + bp[i])));
-        if (16 * h + i < a.nc && sc[i] > best) { best = sc[i]; best_c = 16 * h + i; }
+    for (int i = 0; i < 16; ++i) {
+      sc[i] = 0.f;
+      if (16 * h + i < a.nc) {   // (nc = 1: one lane half evaluates one sigmoid)
+        sc[i] = 1.f / (1.f + __expf(-(float)(half_t)oc[i]));
+        if (sc[i] > best) { best = sc[i]; best_c = 16 * h + i; }
       }
     }
     const float ob_ = __shfl_xor(best, 32);
@@ -365,6 +426,10 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
       }
     }
   }
+  HD_STAMP(9)
+  HD_STAMP(15)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing dummy pieces must land before the LDS is released
+#undef HD_CHUNK_BEGIN
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -377,7 +442,7 @@ static inline int row_channel(int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho
 static size_t head_lds(int th, int tw, int kpt, int c3t) {
   const size_t in = ((size_t)(th + 4) * (tw + 4) * (2 * kpt + 1) * 16 + 1023) & ~(size_t)1023;
   const size_t mid = ((size_t)(th + 2) * (tw + 2) * (4 * (2 + c3t) + 1) * 16 + 1023) & ~(size_t)1023;
-  return in + mid + 2 * HD_RING;
+  return in + mid + (size_t)HD_NSLOT * HD_SLOT;
 }
 
 // tile shapes in order of preference: (TH, TW, PA, PB) with ceil((TH+2)(TW+2)/32) <= 4*PA, ceil(TH*TW/32) <= 4*PB
@@ -386,7 +451,7 @@ static const int kHeadTiles[][4] = {{16, 16, 3, 2}, {10, 20, 3, 2}, {8, 16, 2, 1
 static bool pick_tile(int h, int w, int kpt, int c3t, int batch, int& th, int& tw, int& pa, int& pb) {
   long best_cost = -1;
   for (auto& t : kHeadTiles) {
-    if (head_lds(t[0], t[1], kpt, c3t) > 160 * 1024) continue;
+    if (head_lds(t[0], t[1], kpt, c3t) > 160 * 1024 || (t[1] + 4) * (2 * kpt + 1) > 320 || t[0] + 4 > 20) continue;
     // MFMA tile slots spent per image (stage A row tiles weigh 2 + c3t, stage B 2 + c3t too but over 9*64 / 9*32 K)
     const long tiles = (long)ceil_div(h, t[0]) * ceil_div(w, t[1]);
     const long cost = tiles * (4L * t[2] * (2 + c3t) * kpt * 9 + 4L * t[3] * (2 * 36 + c3t * c3t * 18));
@@ -412,10 +477,10 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   LP_CHECK(pick_tile(h, w, KPT, C3T, batch_hint > 0 ? batch_hint : 1, TH, TW, PA, PB), LP_ERR_STATE, "Detect head %s: no tile shape fits LDS", name.c_str());
   lds_bytes = head_lds(TH, TW, KPT, C3T);
   const int RT = 2 + C3T, CM = 32 * C3T;
-  // K steps of stage A per chunk: a divisor of 9*KPT with RT*KSA <= 24 fragments
-  KSA = 1;
-  for (int k = 1; k <= 24 / RT; ++k)
-    if ((9 * KPT) % k == 0) KSA = k;
+  // chunks hold at most 12 fragments (one ring slot) and a multiple of three K steps (the kernel's K loops are unrolled by 3):
+  // stage A 3 K steps x RT row tiles, stage B box 6 x 2, class 9 x 1 (6 x 2 for two class row tiles), projections 10 (12)
+  KSA = 3;
+  LP_CHECK(RT * KSA <= 12 && (9 * KPT) % KSA == 0, LP_ERR_STATE, "Detect head: chunking");
   std::vector<uint16_t> stream;
   auto frag = [&](auto&& weight_of) {  // weight_of(row rho, k element e of the K step) -> float; appends one 1 KiB fragment
     const size_t base = stream.size();
@@ -427,7 +492,7 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   auto begin_chunk = [&]() { coff.push_back((unsigned short)(stream.size() / 512)); };
   auto end_chunk = [&](int ksteps) {
     const size_t nf = stream.size() / 512 - coff.back();
-    LP_CHECK(nf <= 24, LP_ERR_STATE, "Detect head: chunk of %zu fragments", nf);
+    LP_CHECK(nf >= 1 && nf <= 12, LP_ERR_STATE, "Detect head: chunk of %zu fragments", nf);
     csz.push_back((unsigned char)nf);
     cks.push_back((unsigned char)ksteps);
   };
@@ -446,15 +511,15 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   }
   // ---- stage B box: K step kq = (tap, cg), 4 per tap
   for (int kq = 0; kq < 36; ++kq) {
-    if (kq % 12 == 0) begin_chunk();
+    if (kq % 6 == 0) begin_chunk();
     const int tap = kq >> 2, cg = kq & 3;
     for (int rt = 0; rt < 2; ++rt)
       frag([&](int rho, int e) { return (*s.wbb)[((size_t)(rt * 32 + row_channel(rho)) * 9 + tap) * 64 + 16 * cg + e]; });
-    if (kq % 12 == 11) end_chunk(12);
+    if (kq % 6 == 5) end_chunk(6);
   }
   // ---- stage B class: 2*C3T K steps per tap
   {
-    const int per_tap = 2 * C3T, total = 9 * per_tap, per_chunk = C3T == 2 ? 12 : 18;
+    const int per_tap = 2 * C3T, total = 9 * per_tap, per_chunk = C3T == 2 ? 6 : 9;
     for (int kq = 0; kq < total; ++kq) {
       if (kq % per_chunk == 0) begin_chunk();
       const int tap = kq / per_tap, cg = kq % per_tap;
@@ -483,12 +548,12 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
     });
   end_chunk(0);
   nchunks = (int)coff.size();
-  LP_CHECK(nchunks <= 39 && stream.size() / 512 < 65536, LP_ERR_STATE, "Detect head: weight stream too long");
-  coff.push_back(coff.back());  // issue(nchunks) is a no-op chunk of size 0
-  csz.push_back(0);
-  cks.push_back(0);
-  d_stream.alloc(stream.size() * 2 + 64);
-  LP_HIP(hipMemcpy(d_stream.p, stream.data(), stream.size() * 2, hipMemcpyHostToDevice));
+  LP_CHECK(nchunks <= 64 && stream.size() / 512 < 65536, LP_ERR_STATE, "Detect head: weight stream too long (%d chunks)", nchunks);
+  nrep = getenv("LITEPI_HEAD_REPL") ? std::max(1, atoi(getenv("LITEPI_HEAD_REPL"))) : 8;
+  rep_stride = (stream.size() * 2 + 4096 + 255) & ~(size_t)255;
+  d_stream.alloc(rep_stride * nrep + 64);
+  for (int j = 0; j < nrep; ++j)
+    LP_HIP(hipMemcpy(d_stream.as<char>() + (size_t)j * rep_stride, stream.data(), stream.size() * 2, hipMemcpyHostToDevice));
   std::vector<float> bA(32 * RT + 16, 0.f), bB(32 * RT + 16, 0.f), bC(64 + 32 + 16, 0.f);
   for (int c = 0; c < 64; ++c) { bA[c] = (*s.ba)[c]; bB[c] = s.bbb->empty() ? 0.f : (*s.bbb)[c]; bC[c] = s.bpb->empty() ? 0.f : (*s.bpb)[c]; }
   for (int c = 0; c < c3; ++c) { bA[64 + c] = (*s.ba)[64 + c]; bB[64 + c] = s.bbc->empty() ? 0.f : (*s.bbc)[c]; }
@@ -514,10 +579,17 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
   a.N = N; a.H = in.H; a.W = in.W; a.Cin = Cin;
   a.TH = TH; a.TW = TW; a.tiles_x = ceil_div(in.W, TW); a.ntiles = a.tiles_x * ceil_div(in.H, TH);
   a.KPT = KPT; a.nchunks = nchunks; a.A = A; a.nc = nc; a.anchor_off = anchor_off;
-  LP_CHECK(in.C == Cin && in.H == H && in.W == W && (int)coff.size() <= 40 && (TW + 4) * (2 * KPT + 1) < 2048, LP_ERR_STATE,
+  a.nrep = nrep; a.rep_stride = (unsigned)rep_stride;
+  LP_CHECK(in.C == Cin && in.H == H && in.W == W && (int)coff.size() <= 64 && (TW + 4) * (2 * KPT + 1) <= 320 && TH + 4 <= 20, LP_ERR_STATE,
            "Detect head %s: view does not match the plan", name.c_str());
   for (size_t i = 0; i < coff.size(); ++i) { a.coff[i] = coff[i]; a.csz[i] = csz[i]; a.cks[i] = cks[i]; }
   const dim3 grid((unsigned)(a.ntiles * N));
+  static const char* stamp_path = getenv("LITEPI_HEAD_STAMPS");
+  DevBuf d_stamps;
+  if (stamp_path && *stamp_path) {
+    d_stamps.alloc((size_t)grid.x * 16 * 8);
+    a.stamps = d_stamps.as<unsigned long long>();
+  }
 #define LP_HEAD(C3T_, PA_, PB_)                                                                                   \
   {                                                                                                               \
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_>), 160 * 1024);            \
@@ -530,6 +602,17 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
   }
 #undef LP_HEAD
   LP_HIP(hipGetLastError());
+  if (a.stamps) {  // diagnostic: dump [grid][16] stamps, one record per launch
+    LP_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> hs((size_t)grid.x * 16);
+    LP_HIP(hipMemcpy(hs.data(), d_stamps.p, hs.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(stamp_path, "ab")) {
+      const unsigned long long hdr[4] = {0x48454144ull, grid.x, (unsigned long long)in.H, (unsigned long long)N};
+      fwrite(hdr, 8, 4, f);
+      fwrite(hs.data(), 8, hs.size(), f);
+      fclose(f);
+    }
+  }
 }
 
 }  // namespace lp
