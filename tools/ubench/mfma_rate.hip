@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k(long long* out, float* sink, int iters)
   floatx4 acc4[9];
   for (int q = 0; q < 9; ++q) { for (int i = 0; i < 16; ++i) acc[q][i] = 0.f; acc4[q] = floatx4{0, 0, 0, 0}; }
   const long long t0 = clock64();
-  for (int it = 0; it < iters; ++it) {
+  for (int it = 0; it < (MODE == 3 ? 0 : iters); ++it) {
     if (MODE == 0) {
 #pragma unroll
       for (int q = 0; q < 9; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[q], 0, 0, 0);
@@ -39,6 +39,29 @@ __global__ __launch_bounds__(256) void k(long long* out, float* sink, int iters)
         for (int p = 0; p < 3; ++p) acc[r * 3 + p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[r], bf[p], acc[r * 3 + p], 0, 0, 0);
     }
   }
+  if (MODE == 3) {  // mode 2 with the fragments of step it+1 requested before the MFMAs of step it (two named register sets)
+    auto ld = [&](half8 (&af)[3], half8 (&bf)[3], int it) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        af[q] = __builtin_bit_cast(half8, *(const u32x4*)(lds + ((it * 3 + q) & 31) * 1024 + lane * 16));
+        bf[q] = __builtin_bit_cast(half8, *(const u32x4*)(lds + 32768 + (q * 7 + it) % 16 * 1040 + (lane & 31) * 80 + (lane >> 5) * 16));
+      }
+    };
+    auto mm = [&](const half8 (&af)[3], const half8 (&bf)[3]) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) acc[r * 3 + p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[r], bf[p], acc[r * 3 + p], 0, 0, 0);
+    };
+    half8 a0[3], b0[3], a1[3], b1[3];
+    ld(a0, b0, 0);
+    for (int it = 0; it < iters; it += 2) {
+      ld(a1, b1, it + 1);
+      mm(a0, b0);
+      ld(a0, b0, it + 2);
+      mm(a1, b1);
+    }
+  }
   const long long t1 = clock64();
   float s = 0.f;
   for (int q = 0; q < 9; ++q) { for (int i = 0; i < 16; ++i) s += acc[q][i]; s += acc4[q][0]; }
@@ -50,12 +73,13 @@ int main() {
   long long* d; float* s;
   hipMalloc(&d, 8 * 1024); hipMalloc(&s, 4 * 1024 * 256);
   const int iters = 2000;
-  for (int mode = 0; mode < 3; ++mode)
+  for (int mode = 0; mode < 4; ++mode)
     for (int grid : {1, 256, 1024}) {
       for (int rep = 0; rep < 2; ++rep) {
         if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, d, s, iters);
         if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, d, s, iters);
         if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, d, s, iters);
+        if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, d, s, iters);
         hipDeviceSynchronize();
       }
       long long h[1024];

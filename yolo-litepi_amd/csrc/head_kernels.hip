@@ -35,11 +35,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-#define HD_SLOT 12288  /* bytes per ring slot = 12 fragments */
-#define HD_NSLOT 4
-#define HD_GLDS16(gptr, lptr)                                                                        \
-  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),          \
-                                   (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
+#define HD_SLOT 24576  /* bytes per ring slot = 24 fragments */
 
 // diagnostic phase stamps (never enabled on the product path: a.stamps is null)
 #define HD_STAMP(k)                                                                                    \
@@ -83,7 +79,40 @@ __device__ __forceinline__ floatx16 bias16(const float* __restrict__ b) {
   return v;
 }
 
-template <int C3T, int PA, int PB>
+// K loop of one weight chunk: acc[rt][p] += W(rt, step s) . X(pixels of p, K offset next_boff()) for s < KS.  The operand
+// fragments of step s+1 are requested BEFORE the MFMAs of step s (two register sets, static indices after unrolling): with
+// one wave per SIMD nothing else covers the LDS latency -- the compiler's own schedule of the plain loop ran at 53 cycles
+// per MFMA, this form at 37 (tools/ubench/mfma_rate.hip), against 32 for the bare instruction.  side(j), j < 6, runs behind
+// the MFMAs of step j: the weight ring's store + reload of piece j (see the kernel).
+template <int NA, int NB, int KS, typename F, typename G>
+__device__ __forceinline__ void kloop(const char* wb, const char* img, const int (&pix)[NB], F&& next_boff, G&& side, floatx16 (&acc)[NA][NB]) {
+  half8 af[2][NA], bf[2][NB];
+  auto ld = [&](int set, int s) {
+    const int boff = next_boff();
+#pragma unroll
+    for (int rt = 0; rt < NA; ++rt) af[set][rt] = lds_h8(wb + (s * NA + rt) * 1024);
+#pragma unroll
+    for (int p = 0; p < NB; ++p) bf[set][p] = lds_h8(img + pix[p] + boff);
+  };
+  ld(0, 0);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (s + 1 < KS) ld((s + 1) & 1, s + 1);
+    // pin the order: without this the scheduler sinks the reads below the MFMAs and folds the two register sets into one
+    // (reads of step s+1 issued after the last MFMA of step s: ~100 idle matrix-pipe cycles per step, 50+ cycles per MFMA)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < NA; ++rt)
+#pragma unroll
+      for (int p = 0; p < NB; ++p) acc[rt][p] = mfma32(af[s & 1][rt], bf[s & 1][p], acc[rt][p]);
+    if (s < 6) side(s);
+  }
+#pragma unroll
+  for (int j = KS; j < 6; ++j) side(j);
+}
+
+// NPC: 64-slot pieces per input-tile row, KSA: K steps per stage-A chunk (both fixed by the level's tile shape, see host)
+template <int C3T, int PA, int PB, int NPC, int KSA>
 __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
   constexpr int RT = 2 + C3T;       // row tiles (32 channels) of the merged first convs: box 2 | class C3T
   constexpr int SPM = 4 * RT + 1;   // 16-byte slots per MID pixel, one of them padding (odd: conflict-free pixel stride)
@@ -101,71 +130,75 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
   char* IN = smem;
   char* MID = smem + ((IHin * RSin * 16 + 1023) & ~1023);
   char* RING = MID + ((R1 * SPM * 16 + 1023) & ~1023);
-  // the stream exists in a.nrep copies: workgroups that share an XCD (ids 8 apart) read different copies, so the 32 CUs
-  // of an XCD do not all pull the same L2 lines at the same moment
-  const char* wstream = reinterpret_cast<const char*>(a.wstream) + (size_t)((blockIdx.x >> 3) % a.nrep) * a.rep_stride;
+  const char* wstream = reinterpret_cast<const char*>(a.wstream) + lane * 16;
   const int nch = a.nchunks;
   HD_STAMP(0)
   HD_STAMP(1)
 
-  // ---- weight ring: chunk c of the stream -> slot c & 3 by LDS-DMA.  EVERY wave issues exactly three 1 KiB pieces per
-  //      chunk (piece indices past the chunk's end re-read its last fragment into the slot's unused tail; chunk indices
-  //      past the stream's end re-read the last chunk into a slot nobody reads), so "chunk c has landed" is the counted
-  //      wait vmcnt(6): all but this wave's six youngest vector-memory operations -- the pieces of chunks c+1 and c+2 -- are
-  //      done.  Three chunks of prefetch (~2.5k cycles of MFMAs) cover the ~1 us a piece takes to land under load; with one
-  //      chunk of prefetch every chunk boundary stalled (stamps: 2x the MFMA time in every K loop).
-  auto issue_piece = [&](int c, int j) {
-    const int cc = c < nch ? c : nch - 1;
-    const int nf = a.csz[cc];
-    const int p = wave + 4 * j;
-    const int ps = p < nf ? p : nf - 1;
-    HD_GLDS16(wstream + ((size_t)a.coff[cc] + ps) * 1024 + lane * 16, RING + (c & (HD_NSLOT - 1)) * HD_SLOT + p * 1024);
+  // ---- weight ring, two 24 KiB slots, filled THROUGH REGISTERS: a wave owns pieces wave, wave + 4, .. (six 1 KiB
+  //      fragments) of every chunk.  Behind the MFMAs of K step j of chunk c it stores piece j of chunk c+1 -- loaded one
+  //      chunk earlier -- into the slot everybody left at the last barrier, and requests piece j of chunk c+2 into the same
+  //      registers; plain loads, so the compiler counts the waits, and every piece has one whole chunk of MFMAs to arrive.
+  //      (The first version moved the stream by LDS-DMA: each global_load_lds piece cost 100+ issue cycles that the in-order
+  //      wave could not hide behind its MFMAs; a global load + ds_write pair costs ~25.)  Piece indices past a chunk's end
+  //      re-read its last fragment into the slot's unused tail: no control flow around the loads (see cls_net.hip for what
+  //      that does to the register allocator).
+  u32x4 wreg[6];
+  // (every chunk occupies a whole 24 KiB slot image in the stream, two zero chunks follow the last one: the source of
+  //  piece j of chunk c is wstream + c * 24 KiB + (wave + 4j) KiB -- no chunk table, no clamping, no scalar loads in the K loop)
+  const char* wsrc = wstream;
+  auto wsource = [&](int c) { wsrc = wstream + (size_t)c * HD_SLOT + wave * 1024; };
+  auto wload1 = [&](int j) { wreg[j] = *reinterpret_cast<const u32x4*>(wsrc + j * 4096); };
+  auto wstore1 = [&](int c, int j) {
+    *reinterpret_cast<u32x4*>(RING + (c & 1) * HD_SLOT + lane * 16 + (wave + 4 * j) * 1024) = wreg[j];
   };
   // ---- input tile (halo 2) -> IN through registers: rows of RSin 16-byte slots = (pixel, channel group); pad slots, pixels
   //      outside the image and the row's tail are zeros (= the conv's zero padding).  A wave takes rows wave, wave + 4, ..;
   //      what depends on the lane only (pixel, channel group, validity of a slot) is computed once per 64-slot piece.
   {
-    const int pcs = (RSin + 63) >> 6;                    // <= 5 (host-checked)
     const unsigned rcp_sp = (65536u + SPin - 1) / SPin;  // exact for slot indices < 2048 (host-checked)
-    int voff[5];
-    bool xok[5];
+    int voff[NPC];
+    bool xok[NPC];
 #pragma unroll
-    for (int pc = 0; pc < 5; ++pc) {
+    for (int pc = 0; pc < NPC; ++pc) {
       const int sl = pc * 64 + lane;
       const int ix = (int)(((unsigned)sl * rcp_sp) >> 16), cgs = sl - ix * SPin;
       const int gx = ox0 - 2 + ix;
-      xok[pc] = pc < pcs && sl < RSin && gx >= 0 && gx < a.W && ix < RWin && cgs < 2 * KPT;
-      voff[pc] = (ix * a.in_pitch + cgs * 8) * 2;
+      xok[pc] = sl < RSin && gx >= 0 && gx < a.W && ix < RWin && cgs < 2 * KPT;
+      voff[pc] = xok[pc] ? (ix * a.in_pitch + cgs * 8) * 2 : (ox0 >= 2 ? 0 : (2 - ox0) * a.in_pitch * 2);
     }
     const char* in_n = reinterpret_cast<const char*>(a.in) + ((long)n * a.H * a.W) * a.in_pitch * 2;
-    u32x4 v[5][5];
+    u32x4 v[5][NPC];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int iy = wave + 4 * j;
       const int gy = oy0 - 2 + iy;
       const bool rok = iy < IHin && gy >= 0 && gy < a.H;
-      const char* rowp = in_n + ((long)gy * a.W + (ox0 - 2)) * a.in_pitch * 2;
+      const char* rowp = in_n + ((long)(rok ? gy : 0) * a.W + (ox0 - 2)) * a.in_pitch * 2;
 #pragma unroll
-      for (int pc = 0; pc < 5; ++pc) {
-        v[j][pc] = u32x4{0u, 0u, 0u, 0u};
-        if (rok && xok[pc]) v[j][pc] = *reinterpret_cast<const u32x4*>(rowp + voff[pc]);
+      for (int pc = 0; pc < NPC; ++pc) {
+        // unconditional load from a valid address (voff of an invalid slot points at the row's first in-image pixel), masked after
+        const u32x4 x = *reinterpret_cast<const u32x4*>(rowp + voff[pc]);
+        v[j][pc] = (rok && xok[pc]) ? x : u32x4{0u, 0u, 0u, 0u};
       }
     }
+    u32x4 w0[6];   // chunk 0 goes through a register set of its own so that chunk 1 can be requested in the same breath
 #pragma unroll
-    for (int j = 0; j < 3; ++j) issue_piece(0, j);
+    for (int j = 0; j < 6; ++j) w0[j] = *reinterpret_cast<const u32x4*>(wstream + (wave + 4 * j) * 1024);
+    wsource(1);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) issue_piece(1, j);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) issue_piece(2, j);
+    for (int j = 0; j < 6; ++j) wload1(j);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int iy = wave + 4 * j;
 #pragma unroll
-      for (int pc = 0; pc < 5; ++pc) {
+      for (int pc = 0; pc < NPC; ++pc) {
         const int sl = pc * 64 + lane;
-        if (iy < IHin && pc < pcs && sl < RSin) *reinterpret_cast<u32x4*>(IN + (iy * RSin + sl) * 16) = v[j][pc];
+        if (iy < IHin && sl < RSin) *reinterpret_cast<u32x4*>(IN + (iy * RSin + sl) * 16) = v[j][pc];
       }
     }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4*>(RING + lane * 16 + (wave + 4 * j) * 1024) = w0[j];
   }
   HD_STAMP(2)
 
@@ -179,21 +212,38 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
     pixA[p] = (ry * RWin + rx) * SPin * 16 + h * 16;
   }
   int pixB[PB];
+  float anc_x[PB], anc_y[PB], anc_s[PB];   // requested now, used by the decode at the very end
+  int anchor_i[PB];
+  bool pvalid[PB];
 #pragma unroll
   for (int p = 0; p < PB; ++p) {
-    int idx = 32 * (wave + 4 * p) + r;
-    idx = idx < R2 ? idx : R2 - 1;
+    const int pt = wave + 4 * p;
+    const int idx0 = 32 * pt + r;
+    const int idx = idx0 < R2 ? idx0 : R2 - 1;
     const int ty = idx / TW, tx = idx - ty * TW;
     pixB[p] = (ty * RW1 + tx) * SPM * 16 + h * 16;
+    const int gy = oy0 + ty, gx = ox0 + tx;
+    pvalid[p] = pt < nB && idx0 < R2 && gy < a.H && gx < a.W;
+    anchor_i[p] = a.anchor_off + (pvalid[p] ? gy * a.W + gx : 0);
+    anc_x[p] = a.anchors[anchor_i[p]];
+    anc_y[p] = a.anchors[a.A + anchor_i[p]];
+    anc_s[p] = a.strides[anchor_i[p]];
   }
+  const ImgGeom gm = a.geom[n];
+  float dflw[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dflw[i] = a.dfl_w[i];
   const int lane16 = lane * 16;
-  // one chunk: wait for it, let everybody leave the slot that chunk c+3 will overwrite, then run `body(wb, s, first)` for
-  // its K steps in groups of three; the three pieces of chunk c+3 are requested behind the first three K steps' MFMAs
-#define HD_CHUNK_BEGIN                                                      \
-  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");              \
-  __builtin_amdgcn_s_barrier();                                             \
-  const char* wb = RING + (c & (HD_NSLOT - 1)) * HD_SLOT + lane16;          \
-  const int ks = a.cks[c];
+  int c = 0;
+  // one chunk: the barrier publishes chunk c (stored during chunk c-1) and frees the other slot for chunk c+1
+#define HD_CHUNK_BEGIN                                             \
+  wsource(c + 2);                                                 \
+  __syncthreads();                                                \
+  const char* wb = RING + (c & 1) * HD_SLOT + lane16;
+  auto ring_side = [&](int j) {
+    wstore1(c + 1, j);
+    wload1(j);
+  };
 
   // ======================= stage A: [64 + 32*C3T] x (9 * Cin) x region-1 pixels =======================
   floatx16 accA[RT][PA];
@@ -203,32 +253,25 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
 #pragma unroll
     for (int p = 0; p < PA; ++p) accA[rt][p] = b;
   }
-  int c = 0;
   {
-    int tap = 0, cg = 0;
-    const int ncA = nch - (C3T == 2 ? 13 : 9);   // stream = A chunks | 6 box-B | 2 (6) class-B | 1 C
+    // K offset of the running step = (tap row * RWin + tap column) pixels + channel-group pair, kept incrementally
+    int cg = 0, dx = 0, boff_run = 0;
+    const int d_tap = SPin * 16 - 32 * (KPT - 1), d_row = (RWin - 2) * SPin * 16 - 32 * (KPT - 1);
+    auto next_boff = [&]() {
+      const int boff = boff_run;
+      if (++cg == KPT) {
+        cg = 0;
+        if (++dx == 3) { dx = 0; boff_run += d_row; } else boff_run += d_tap;
+      } else {
+        boff_run += 32;
+      }
+      return boff;
+    };
+    const int ncA = nch - (C3T == 2 ? 7 : 5);   // stream = A chunks | 3 box-B | 1 class-B (3 with two class row tiles) | 1 C
     for (; c < ncA; ++c) {
       HD_CHUNK_BEGIN
       if (c == 0) { HD_STAMP(3) }
-      for (int s0 = 0; s0 < ks; s0 += 3) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int s = s0 + u;
-          const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
-          const int boff = ((dy * RWin + dx) * SPin + 2 * cg) * 16;
-          half8 af[RT], bf[PA];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) af[rt] = lds_h8(wb + (s * RT + rt) * 1024);
-#pragma unroll
-          for (int p = 0; p < PA; ++p) bf[p] = lds_h8(IN + pixA[p] + boff);
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int p = 0; p < PA; ++p) accA[rt][p] = mfma32(af[rt], bf[p], accA[rt][p]);
-          if (s0 == 0) issue_piece(c + 3, u);
-          if (++cg == KPT) { cg = 0; ++tap; }
-        }
-      }
+      kloop<RT, PA, KSA>(wb, IN, pixA, next_boff, ring_side, accA);
     }
   }
   HD_STAMP(4)
@@ -271,28 +314,20 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
 #pragma unroll
     for (int p = 0; p < PB; ++p) accB[rt][p] = b;
   }
+  int tapB[9];   // byte offset of tap (dy, dx) in MID
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tapB[t] = ((t / 3) * RW1 + (t % 3)) * SPM * 16;
   {
-    int kq = 0;
-    const int cend = c + 6;
-    for (; c < cend; ++c) {
-      HD_CHUNK_BEGIN   // (first pass: the wait + barrier also order the MID stores before the reads below)
-      (void)ks;
 #pragma unroll
-      for (int s = 0; s < 6; ++s, ++kq) {
-        const int tap = kq >> 2, cg = kq & 3;
-        const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
-        const int boff = ((dy * RW1 + dx) * SPM + 2 * cg) * 16;
-        half8 af[2], bf[PB];
-        af[0] = lds_h8(wb + (s * 2) * 1024);
-        af[1] = lds_h8(wb + (s * 2 + 1) * 1024);
-#pragma unroll
-        for (int p = 0; p < PB; ++p) bf[p] = lds_h8(MID + pixB[p] + boff);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int p = 0; p < PB; ++p) accB[rt][p] = mfma32(af[rt], bf[p], accB[rt][p]);
-        if (s < 3) issue_piece(c + 3, s);
-      }
+    for (int cb = 0; cb < 3; ++cb, ++c) {
+      int kq = cb * 12;   // compile-time after unrolling: tap and channel group of every step are immediates
+      auto next_boff = [&]() {
+        const int boff = tapB[kq >> 2] + (kq & 3) * 32;
+        ++kq;
+        return boff;
+      };
+      HD_CHUNK_BEGIN   // (first pass: the barrier also orders the MID stores before the reads below)
+      kloop<2, PB, 12>(wb, MID, pixB, next_boff, ring_side, accB);
     }
   }
   HD_STAMP(6)
@@ -305,37 +340,24 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
     for (int p = 0; p < PB; ++p) accC[rt][p] = b;
   }
   {
-    int kq = 0;
-    const int cend = c + (C3T == 2 ? 6 : 2);
-    for (; c < cend; ++c) {
+#pragma unroll
+    for (int cb = 0; cb < (C3T == 2 ? 3 : 1); ++cb, ++c) {
+      int kq = cb * 12;
+      auto next_boff = [&]() {
+        const int tap = C3T == 2 ? kq >> 2 : kq >> 1, cg = C3T == 2 ? kq & 3 : kq & 1;
+        ++kq;
+        return tapB[tap] + (8 + 2 * cg) * 16;
+      };
       HD_CHUNK_BEGIN
-      for (int s0 = 0; s0 < ks; s0 += 3) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u, ++kq) {
-          const int s = s0 + u;
-          const int tap = C3T == 2 ? kq >> 2 : kq >> 1, cg = C3T == 2 ? kq & 3 : kq & 1;
-          const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
-          const int boff = ((dy * RW1 + dx) * SPM + 8 + 2 * cg) * 16;
-          half8 af[C3T], bf[PB];
-#pragma unroll
-          for (int rt = 0; rt < C3T; ++rt) af[rt] = lds_h8(wb + (s * C3T + rt) * 1024);
-#pragma unroll
-          for (int p = 0; p < PB; ++p) bf[p] = lds_h8(MID + pixB[p] + boff);
-#pragma unroll
-          for (int rt = 0; rt < C3T; ++rt)
-#pragma unroll
-            for (int p = 0; p < PB; ++p) accC[rt][p] = mfma32(af[rt], bf[p], accC[rt][p]);
-          if (s0 == 0) issue_piece(c + 3, u);
-        }
-      }
+      kloop<C3T, PB, (C3T == 2 ? 12 : 18)>(wb, MID, pixB, next_boff, ring_side, accC);
     }
   }
   // ======================= stage C: the 1x1 projections from the accumulators, then decode =======================
   HD_STAMP(7)
   half8 wcb[2][4], wcc[2 * C3T];
   {
-    HD_CHUNK_BEGIN
-    (void)ks;
+    __syncthreads();
+    const char* wb = RING + (c & 1) * HD_SLOT + lane16;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -344,10 +366,6 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
     for (int q = 0; q < 2 * C3T; ++q) wcc[q] = lds_h8(wb + (8 + q) * 1024);
   }
   HD_STAMP(8)
-  float dflw[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) dflw[i] = a.dfl_w[i];
-  const ImgGeom gm = a.geom[n];
   const floatx16 bC0 = bias16(a.biasC + h * 16), bC1 = bias16(a.biasC + 32 + h * 16), bCc = bias16(a.biasC + 64 + h * 16);
 #pragma unroll
   for (int p = 0; p < PB; ++p) {
@@ -403,13 +421,8 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
     const float ob_ = __shfl_xor(best, 32);
     const int oc_ = __shfl_xor(best_c, 32);
     if (h == 0 && ob_ > best) { best = ob_; best_c = oc_; }   // first maximum in class order: the upper half wins only if larger
-    const int pt = wave + 4 * p;
-    const int idx = 32 * pt + r;
-    const int ty = idx / TW, tx = idx - ty * TW;
-    const int gy = oy0 + ty, gx = ox0 + tx;
-    const bool valid = pt < nB && idx < R2 && gy < a.H && gx < a.W;
-    if (valid) {
-      const int anchor = a.anchor_off + gy * a.W + gx;
+    if (pvalid[p]) {
+      const int anchor = anchor_i[p];
       float* o = a.out0 ? a.out0 + (long)n * (4 + a.nc) * a.A + anchor : nullptr;
       if (o) {
 #pragma unroll
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
           if (16 * h + i < a.nc) o[(long)(4 + 16 * h + i) * a.A] = sc[i];
       }
       if (h == 0) {
-        const float ax = a.anchors[anchor], ay = a.anchors[a.A + anchor], s = a.strides[anchor];
+        const float ax = anc_x[p], ay = anc_y[p], s = anc_s[p];
         const float bx1 = ax - d0, by1 = ay - d1, bx2 = ax + d2, by2 = ay + d3;
         const float cx = (bx1 + bx2) * 0.5f * s, cy = (by1 + by2) * 0.5f * s;
         const float w = (bx2 - bx1) * s, hh = (by2 - by1) * s;
@@ -428,7 +441,6 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
   }
   HD_STAMP(9)
   HD_STAMP(15)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's trailing dummy pieces must land before the LDS is released
 #undef HD_CHUNK_BEGIN
 }
 
@@ -442,45 +454,49 @@ static inline int row_channel(int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho
 static size_t head_lds(int th, int tw, int kpt, int c3t) {
   const size_t in = ((size_t)(th + 4) * (tw + 4) * (2 * kpt + 1) * 16 + 1023) & ~(size_t)1023;
   const size_t mid = ((size_t)(th + 2) * (tw + 2) * (4 * (2 + c3t) + 1) * 16 + 1023) & ~(size_t)1023;
-  return in + mid + (size_t)HD_NSLOT * HD_SLOT;
+  return in + mid + 2 * (size_t)HD_SLOT;
 }
 
-// tile shapes in order of preference: (TH, TW, PA, PB) with ceil((TH+2)(TW+2)/32) <= 4*PA, ceil(TH*TW/32) <= 4*PB
-static const int kHeadTiles[][4] = {{16, 16, 3, 2}, {10, 20, 3, 2}, {8, 16, 2, 1}, {10, 10, 2, 1}, {8, 8, 1, 1}};
-
-static bool pick_tile(int h, int w, int kpt, int c3t, int batch, int& th, int& tw, int& pa, int& pb) {
-  long best_cost = -1;
-  for (auto& t : kHeadTiles) {
-    if (head_lds(t[0], t[1], kpt, c3t) > 160 * 1024 || (t[1] + 4) * (2 * kpt + 1) > 320 || t[0] + 4 > 20) continue;
-    // MFMA tile slots spent per image (stage A row tiles weigh 2 + c3t, stage B 2 + c3t too but over 9*64 / 9*32 K)
-    const long tiles = (long)ceil_div(h, t[0]) * ceil_div(w, t[1]);
-    const long cost = tiles * (4L * t[2] * (2 + c3t) * kpt * 9 + 4L * t[3] * (2 * 36 + c3t * c3t * 18));
-    const long wgs = tiles * batch;
-    // prefer the cheapest shape that still gives every CU a workgroup
-    const long adj = wgs < 256 ? cost * 2 : cost;
-    if (best_cost < 0 || adj < best_cost) { best_cost = adj; th = t[0]; tw = t[1]; pa = t[2]; pb = t[3]; }
-  }
-  return best_cost >= 0;
+// One kernel configuration per (class row tiles, K steps per tap = Cin / 16): tile shape TH x TW, pixel tiles per wave in stage
+// A / B (ceil((TH+2)(TW+2)/32) <= 4*PA, ceil(TH*TW/32) <= 4*PB), 64-slot pieces per input-tile row, K steps per stage-A chunk
+// (a divisor of 9*KPT with (2+C3T)*KSA <= 24 fragments).  Chosen for LDS (input tile + first-conv image + 48 KiB ring <= 160
+// KiB) and for whole tiles on the 80 / 40 / 20 maps of a 640 input; other map sizes run the same shapes with masked edges.
+struct HeadCfg { int c3t, kpt, th, tw, pa, pb, npc, ksa; };
+static const HeadCfg kHeadCfg[] = {
+    {1, 2, 16, 16, 3, 2, 2, 6},   // v1 P3: Cin 32
+    {1, 4, 10, 20, 3, 2, 4, 6},   // v1 P4: Cin 64
+    {1, 8, 10, 10, 2, 1, 4, 8},   // v1 P5: Cin 128
+    {2, 3, 10, 20, 3, 2, 3, 3},   // v2 P3: Cin 48
+    {2, 6, 10, 10, 2, 1, 3, 6},   // v2 P4: Cin 96
+    {2, 12, 8, 8, 1, 1, 5, 6},    // v2 P5: Cin 192
+};
+static const HeadCfg* find_cfg(int c3t, int kpt) {
+  for (auto& c : kHeadCfg)
+    if (c.c3t == c3t && c.kpt == kpt) return &c;
+  return nullptr;
 }
 
 bool HeadLayer::supported(int cin_phys, int c2, int c3, int nc, int reg_max, int h, int w) {
   if (c2 != 64 || reg_max != 16 || nc < 1 || nc > 32 || c3 < 8 || c3 > 64 || c3 % 8 != 0) return false;
-  if (cin_phys % 16 != 0 || cin_phys < 16 || cin_phys > 256) return false;
-  int th, tw, pa, pb;
-  return pick_tile(h, w, cin_phys / 16, c3 > 32 ? 2 : 1, 1, th, tw, pa, pb);
+  if (cin_phys % 16 != 0) return false;
+  (void)h; (void)w;
+  return find_cfg(c3 > 32 ? 2 : 1, cin_phys / 16) != nullptr;
 }
 
 void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hint, const Src& s) {
   Cin = cin_phys; c3 = c3_; nc = nc_; H = h; W = w;
   C3T = c3 > 32 ? 2 : 1;
   KPT = Cin / 16;
-  LP_CHECK(pick_tile(h, w, KPT, C3T, batch_hint > 0 ? batch_hint : 1, TH, TW, PA, PB), LP_ERR_STATE, "Detect head %s: no tile shape fits LDS", name.c_str());
+  const HeadCfg* cfg = find_cfg(C3T, KPT);
+  LP_CHECK(cfg, LP_ERR_STATE, "Detect head %s: no kernel configuration for Cin %d", name.c_str(), Cin);
+  TH = cfg->th; TW = cfg->tw; PA = cfg->pa; PB = cfg->pb; NPC = cfg->npc; KSA = cfg->ksa;
   lds_bytes = head_lds(TH, TW, KPT, C3T);
   const int RT = 2 + C3T, CM = 32 * C3T;
-  // chunks hold at most 12 fragments (one ring slot) and a multiple of three K steps (the kernel's K loops are unrolled by 3):
-  // stage A 3 K steps x RT row tiles, stage B box 6 x 2, class 9 x 1 (6 x 2 for two class row tiles), projections 10 (12)
-  KSA = 3;
-  LP_CHECK(RT * KSA <= 12 && (9 * KPT) % KSA == 0, LP_ERR_STATE, "Detect head: chunking");
+  // chunks hold at most 24 fragments (one ring slot): stage A KSA K steps x RT row tiles, stage B box 12 x 2, class 18 x 1
+  // (12 x 2 for two class row tiles), projections 10 (12)
+  LP_CHECK(lds_bytes <= 160 * 1024 && ((TW + 4) * (2 * KPT + 1) + 63) / 64 == NPC && (9 * KPT) % KSA == 0 && RT * KSA <= 24 && TH + 4 <= 20 &&
+               (TH + 2) * (TW + 2) <= 128 * PA && TH * TW <= 128 * PB, LP_ERR_STATE, "Detect head %s: inconsistent configuration", name.c_str());
+  (void)batch_hint;
   std::vector<uint16_t> stream;
   auto frag = [&](auto&& weight_of) {  // weight_of(row rho, k element e of the K step) -> float; appends one 1 KiB fragment
     const size_t base = stream.size();
@@ -492,9 +508,10 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   auto begin_chunk = [&]() { coff.push_back((unsigned short)(stream.size() / 512)); };
   auto end_chunk = [&](int ksteps) {
     const size_t nf = stream.size() / 512 - coff.back();
-    LP_CHECK(nf >= 1 && nf <= 12, LP_ERR_STATE, "Detect head: chunk of %zu fragments", nf);
+    LP_CHECK(nf >= 1 && nf <= 24, LP_ERR_STATE, "Detect head: chunk of %zu fragments", nf);
     csz.push_back((unsigned char)nf);
     cks.push_back((unsigned char)ksteps);
+    stream.resize((size_t)(coff.back() + 24) * 512, 0);   // every chunk is a whole 24 KiB slot image
   };
   const std::vector<float>& wa = *s.wa;  // [64 + c3][9][Cin]
   // ---- stage A: K step (tap, cg): element e = input channel 16*cg + e
@@ -511,15 +528,15 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   }
   // ---- stage B box: K step kq = (tap, cg), 4 per tap
   for (int kq = 0; kq < 36; ++kq) {
-    if (kq % 6 == 0) begin_chunk();
+    if (kq % 12 == 0) begin_chunk();
     const int tap = kq >> 2, cg = kq & 3;
     for (int rt = 0; rt < 2; ++rt)
       frag([&](int rho, int e) { return (*s.wbb)[((size_t)(rt * 32 + row_channel(rho)) * 9 + tap) * 64 + 16 * cg + e]; });
-    if (kq % 6 == 5) end_chunk(6);
+    if (kq % 12 == 11) end_chunk(12);
   }
   // ---- stage B class: 2*C3T K steps per tap
   {
-    const int per_tap = 2 * C3T, total = 9 * per_tap, per_chunk = C3T == 2 ? 6 : 9;
+    const int per_tap = 2 * C3T, total = 9 * per_tap, per_chunk = C3T == 2 ? 12 : 18;
     for (int kq = 0; kq < total; ++kq) {
       if (kq % per_chunk == 0) begin_chunk();
       const int tap = kq / per_tap, cg = kq % per_tap;
@@ -549,6 +566,7 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   end_chunk(0);
   nchunks = (int)coff.size();
   LP_CHECK(nchunks <= 64 && stream.size() / 512 < 65536, LP_ERR_STATE, "Detect head: weight stream too long (%d chunks)", nchunks);
+  stream.resize(stream.size() + (size_t)2 * 24 * 512, 0);   // the ring requests two chunks past the end
   nrep = getenv("LITEPI_HEAD_REPL") ? std::max(1, atoi(getenv("LITEPI_HEAD_REPL"))) : 8;
   rep_stride = (stream.size() * 2 + 4096 + 255) & ~(size_t)255;
   d_stream.alloc(rep_stride * nrep + 64);
@@ -580,7 +598,7 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
   a.TH = TH; a.TW = TW; a.tiles_x = ceil_div(in.W, TW); a.ntiles = a.tiles_x * ceil_div(in.H, TH);
   a.KPT = KPT; a.nchunks = nchunks; a.A = A; a.nc = nc; a.anchor_off = anchor_off;
   a.nrep = nrep; a.rep_stride = (unsigned)rep_stride;
-  LP_CHECK(in.C == Cin && in.H == H && in.W == W && (int)coff.size() <= 64 && (TW + 4) * (2 * KPT + 1) <= 320 && TH + 4 <= 20, LP_ERR_STATE,
+  LP_CHECK(in.C == Cin && in.H == H && in.W == W && (int)coff.size() <= 64, LP_ERR_STATE,
            "Detect head %s: view does not match the plan", name.c_str());
   for (size_t i = 0; i < coff.size(); ++i) { a.coff[i] = coff[i]; a.csz[i] = csz[i]; a.cks[i] = cks[i]; }
   const dim3 grid((unsigned)(a.ntiles * N));
@@ -590,16 +608,18 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
     d_stamps.alloc((size_t)grid.x * 16 * 8);
     a.stamps = d_stamps.as<unsigned long long>();
   }
-#define LP_HEAD(C3T_, PA_, PB_)                                                                                   \
+#define LP_HEAD(C3T_, PA_, PB_, NPC_, KSA_)                                                                           \
   {                                                                                                               \
-    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_>), 160 * 1024);            \
-    hipLaunchKernelGGL((head_fused_kernel<C3T_, PA_, PB_>), grid, dim3(256), lds_bytes, st, a);                    \
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_>), 160 * 1024); \
+    hipLaunchKernelGGL((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_>), grid, dim3(256), lds_bytes, st, a);         \
   }
-  if (C3T == 1) {
-    if (PA == 3 && PB == 2) LP_HEAD(1, 3, 2) else if (PA == 2 && PB == 1) LP_HEAD(1, 2, 1) else LP_HEAD(1, 1, 1)
-  } else {
-    if (PA == 3 && PB == 2) LP_HEAD(2, 3, 2) else if (PA == 2 && PB == 1) LP_HEAD(2, 2, 1) else LP_HEAD(2, 1, 1)
-  }
+  if (C3T == 1 && KPT == 2) LP_HEAD(1, 3, 2, 2, 6)
+  else if (C3T == 1 && KPT == 4) LP_HEAD(1, 3, 2, 4, 6)
+  else if (C3T == 1 && KPT == 8) LP_HEAD(1, 2, 1, 4, 8)
+  else if (C3T == 2 && KPT == 3) LP_HEAD(2, 3, 2, 3, 3)
+  else if (C3T == 2 && KPT == 6) LP_HEAD(2, 2, 1, 3, 6)
+  else if (C3T == 2 && KPT == 12) LP_HEAD(2, 1, 1, 5, 6)
+  else throw Error(LP_ERR_STATE, "Detect head: no kernel configuration");
 #undef LP_HEAD
   LP_HIP(hipGetLastError());
   if (a.stamps) {  // diagnostic: dump [grid][16] stamps, one record per launch
