@@ -120,6 +120,7 @@ struct ConvArgs {
   int up_pitch, up_cg;
   int tile_major;              // 0: grid = (image, tile, split) (XCD-aware, default); 1: (tile, image, split)
   unsigned rcp_tx, rcp_cg, rcp_ps, rcp_pcs;  // 3x3 kernel: 16-bit reciprocals of tiles_x, CGc, PS/16, pieces per tile row
+  unsigned magic_hw, magic_w;  // floor(2^32 / pix_per_item), floor(2^32 / Wout): flat pixel index -> (image, row, column) (fast_div)
   const void* zeros;           // >= 16 zero bytes (source of the 3x3 kernel's padding slots)
   unsigned long long* stamps;  // diagnostic only (lp_test_conv + LITEPI_STAMPS): 16 clock stamps per workgroup
 };
@@ -146,6 +147,7 @@ struct BneckArgs {
   void* out3;
   int cat_pitch, out3_pitch, C3, act3;
   int kg, sg;       // global K groups and their K steps (sr = register steps, fixed by NT)
+  unsigned long long* stamps;  // diagnostic only (LITEPI_BNECK_STAMPS=<file>): 16 clock stamps per workgroup
 };
 
 // Fused network head: stem 3x3/s2 (uint8 -> 8 ch) + 3x3/s2 conv + its 1x1 tail (stem_block_kernel)

@@ -76,22 +76,53 @@ template <typename T, int ACT> __device__ __forceinline__ float activate_ct(floa
   if (ACT == ACT_RELU) return fmaxf(v, 0.f);
   return v;
 }
+// act(v + b) of a lane's four accumulator values.  SiLU is written on two-wide vectors: the bias add, both multiplies and
+// the +1 become v_pk_*_f32 (two elements per issue), the exponential and the reciprocal stay the hardware transcendentals --
+// 4.5 VALU issues per element instead of 7.  The conv epilogues are the largest VALU consumer of the narrow layers (the
+// VALU, not the matrix pipe, is what the pipelined step is bound by: profiles/README.md), so this is where it counts.
+template <typename T, int ACT> __device__ __forceinline__ floatx4 act4(floatx4 v, floatx4 b) {
+  v = v + b;
+  if (ACT == ACT_SILU) {
+    const floatx4 t = v * -1.4426950408889634f;
+    floatx4 e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(t[i]);
+    e = e + 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+    return v * e;
+  }
+  if (ACT == ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+  }
+  return v;
+}
 
+// Element offset of pixel `pix` in a tensor of channel pitch `pitch`: ONE 32-bit multiply.  The 64-bit product the plain
+// pointer arithmetic asks for is three quarter-rate integer multiplies per address -- with one address per pixel per tensor
+// that was a third of the narrow layers' epilogue issue time.  Every launch checks N*H*W*pitch < 2^32 on the host (span_ok).
+__device__ __forceinline__ unsigned eoff(long pix, int pitch) { return (unsigned)pix * (unsigned)pitch; }
+// x / d for x < 2^31 with m = floor(2^32 / d) (host: div_magic): the estimate is q or q - 1, one correction
+__device__ __forceinline__ int fast_div(int x, int d, unsigned m) {
+  int q = (int)__umulhi((unsigned)x, m);
+  if (x - q * d >= d) ++q;
+  return q;
+}
 // The activation is a template parameter: a run-time switch here costs three scalar branches
 // per output element (hundreds per wave), more than the MFMAs of a small-K layer.
 template <typename T, int EPI, int ACT>
 __device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0, floatx4 v) {
   const floatx4 b = *reinterpret_cast<const floatx4*>(a.bias + ch0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = activate_ct<T, ACT>(v[i] + b[i]);
+  v = act4<T, ACT>(v, b);
   if (EPI == EPI_SHUFFLE) {
     // ShuffleNetV2 channel_shuffle(cat(x1, y), 2) fused into the store: logical output channel 2c = x1[c],
     // 2c+1 = y[c]; each half of the output is padded to half_cp.  This lane's 4 channels c..c+3 become the 8
     // consecutive logical channels 2c..2c+7: one vector load of x1, then 4-byte (x1, y) pairs -- merged into one
     // 16-byte store when the run stays inside one half and is 16-byte aligned (scalar 2-byte traffic made the
     // stride-2 blocks' pointwise convs the slowest launches of the classifier).
-    const T* x1 = reinterpret_cast<const T*>(a.x1) + pix * a.x1_pitch;
-    T* o = reinterpret_cast<T*>(a.out) + pix * a.out_pitch;
+    const T* x1 = reinterpret_cast<const T*>(a.x1) + eoff(pix, a.x1_pitch);
+    T* o = reinterpret_cast<T*>(a.out) + eoff(pix, a.out_pitch);
     if (ch0 + 4 <= a.half_c) {
       const typename Tr<T>::quad xv = *reinterpret_cast<const typename Tr<T>::quad*>(x1 + ch0);
       const int l0 = 2 * ch0;
@@ -128,17 +159,17 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0,
   }
   if (a.res) {
     const typename Tr<T>::quad r =
-        *reinterpret_cast<const typename Tr<T>::quad*>(reinterpret_cast<const T*>(a.res) + pix * a.res_pitch + ch0);
+        *reinterpret_cast<const typename Tr<T>::quad*>(reinterpret_cast<const T*>(a.res) + eoff(pix, a.res_pitch) + ch0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += (float)r[i];
   }
   if (a.out_f32) {
-    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.out) + pix * a.out_pitch + ch0) = v;
+    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(a.out) + eoff(pix, a.out_pitch) + ch0) = v;
   } else {
     typename Tr<T>::quad q;
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = (T)v[i];
-    *reinterpret_cast<typename Tr<T>::quad*>(reinterpret_cast<T*>(a.out) + pix * a.out_pitch + ch0) = q;
+    *reinterpret_cast<typename Tr<T>::quad*>(reinterpret_cast<T*>(a.out) + eoff(pix, a.out_pitch) + ch0) = q;
   }
 }
 
@@ -151,8 +182,8 @@ __device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int 
 template <typename T, int NT, int ACT>
 __device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chbase, const floatx4 (&v)[NT],
                                            const floatx4 (&bias)[NT]) {
-  T* o = reinterpret_cast<T*>(a.out) + pix * a.out_pitch + chbase;
-  const T* r = a.res ? reinterpret_cast<const T*>(a.res) + pix * a.res_pitch + chbase : nullptr;
+  T* o = reinterpret_cast<T*>(a.out) + eoff(pix, a.out_pitch) + chbase;
+  const T* r = a.res ? reinterpret_cast<const T*>(a.res) + eoff(pix, a.res_pitch) + chbase : nullptr;
   store_lane_at<T, NT, ACT>(o, r, chbase, a.Cout, v, bias);
 }
 
@@ -164,10 +195,11 @@ __device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int 
     for (int t = 0; t + 1 < NT; t += 2) {
       if (chbase + t * 4 < Cout) {
         half8 q;
+        const floatx4 y0 = act4<T, ACT>(v[t], bias[t]), y1 = act4<T, ACT>(v[t + 1], bias[t + 1]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          q[i] = (half_t)activate_ct<T, ACT>(v[t][i] + bias[t][i]);
-          q[4 + i] = (half_t)activate_ct<T, ACT>(v[t + 1][i] + bias[t + 1][i]);
+          q[i] = (half_t)y0[i];
+          q[4 + i] = (half_t)y1[i];
         }
         if (r) {
           const half8 rr = *reinterpret_cast<const half8*>(r + t * 4);
@@ -181,8 +213,9 @@ __device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int 
       constexpr int t = NT - 1;
       if (chbase + t * 4 < Cout) {
         half4 q;
+        const floatx4 y0 = act4<T, ACT>(v[t], bias[t]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = (half_t)activate_ct<T, ACT>(v[t][i] + bias[t][i]);
+        for (int i = 0; i < 4; ++i) q[i] = (half_t)y0[i];
         if (r) {
           const half4 rr = *reinterpret_cast<const half4*>(r + t * 4);
 #pragma unroll
@@ -195,9 +228,7 @@ __device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (chbase + t * 4 < Cout) {
-        floatx4 q;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = activate_ct<T, ACT>(v[t][i] + bias[t][i]);
+        floatx4 q = act4<T, ACT>(v[t], bias[t]);
         if (r) {
           const floatx4 rr = *reinterpret_cast<const floatx4*>(r + t * 4);
 #pragma unroll
@@ -226,18 +257,19 @@ __device__ __forceinline__ void tail_store(const ConvArgs& a2, long pix, int g, 
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int s = 0; s < S2; ++s) {
+      const int t1 = (2 * s + 1 < NT) ? 2 * s + 1 : 0;  // clamped: the odd-NT last step has no second quad
+      const floatx4 y0 = act4<T, ACT1>(v[2 * s], bias1[2 * s]);
+      floatx4 y1 = floatx4{0.f, 0.f, 0.f, 0.f};
+      if (2 * s + 1 < NT) y1 = act4<T, ACT1>(v[t1], bias1[t1]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        bq[s][i] = (half_t)activate_ct<T, ACT1>(v[2 * s][i] + bias1[2 * s][i]);
-        const int t1 = (2 * s + 1 < NT) ? 2 * s + 1 : 0;  // clamped: the odd-NT last step has no second quad
-        bq[s][4 + i] = (2 * s + 1 < NT) ? (half_t)activate_ct<T, ACT1>(v[t1][i] + bias1[t1][i]) : (half_t)0.f;
+        bq[s][i] = (half_t)y0[i];
+        bq[s][4 + i] = (half_t)y1[i];
       }
     }
   } else {
 #pragma unroll
-    for (int s = 0; s < S2; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bq[s][i] = activate_ct<T, ACT1>(v[s][i] + bias1[s][i]);
+    for (int s = 0; s < S2; ++s) bq[s] = act4<T, ACT1>(v[s], bias1[s]);
   }
   floatx4 o[T2];
 #pragma unroll
@@ -273,9 +305,9 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const floatx4 (
   if (oy >= a.Hout) return;
   // the five patches of a strip are 4 pixels apart on one row: one address computation, then fixed strides
   const int chbase = ns * 16 * NT + g * 4 * NT;
-  const long pix0 = (long)(n * a.Hout + oy) * a.Wout + oxb;
-  T* o = reinterpret_cast<T*>(a.out) + pix0 * a.out_pitch + chbase;
-  const T* r = a.res ? reinterpret_cast<const T*>(a.res) + pix0 * a.res_pitch + chbase : nullptr;
+  const int pix0 = (n * a.Hout + oy) * a.Wout + oxb;
+  T* o = reinterpret_cast<T*>(a.out) + eoff(pix0, a.out_pitch) + chbase;
+  const T* r = a.res ? reinterpret_cast<const T*>(a.res) + eoff(pix0, a.res_pitch) + chbase : nullptr;
   const int ostep = 4 * a.out_pitch, rstep = 4 * a.res_pitch;
 #pragma unroll
   for (int p = 0; p < 5; ++p) {
@@ -453,7 +485,7 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
     for (int p = 0; p < 5; ++p) {
       const int ox = oxb + p * 4;
       if (oy < a.Hout && ox < a.Wout) {
-        const long pix = (long)(n * a.Hout + oy) * a.Wout + ox;
+        const long pix = (n * a.Hout + oy) * a.Wout + ox;
         floatx4 v[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = acc[t][p];
@@ -490,7 +522,10 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
 // T2 > 0: the C2f's closing 1x1 conv (cv2 over concat[y0, y1, .., y_last]) runs here as well, T2 = its 16-channel
 // output tiles.  y_last never leaves the registers (the accumulator tile is already a B operand, as in tail_store);
 // the other concat segments are gathered from the concat buffer, 16 B per lane per K step.
-template <typename T, int NT, int P1, int P2, bool SEP, int T2 = 0>
+#define BN_STAMP(k)                                                                                                   \
+  if (a.stamps && threadIdx.x == 0)                                                                                 \
+    a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = ((k) == 0 || (k) == 15) ? wall_clock64() : clock64();
+template <typename T, int NT, int P1, int P2, bool SEP, int T2 = 0, int SG = 0>
 __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel(const BneckArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
@@ -499,6 +534,8 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
   const int tile_id = a.tile_major ? blockIdx.x : blockIdx.y;
   const int ty = (int)((tile_id * a.rcp_tx) >> 16), tx = tile_id - ty * a.tiles_x;
   const int n = a.tile_major ? blockIdx.y : blockIdx.x;  // image index fastest: an image's tiles share one XCD's L2 (see conv3x3_mfma_kernel)
+  BN_STAMP(0)
+  BN_STAMP(1)
   const int TH = a.TH, TW = a.TW, LW = a.LW, PS = a.PS, S = a.steps, CG = a.CG;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int IH = TH + 4, IW = TW + 4, H1 = TH + 2, W1 = TW + 2;
@@ -529,6 +566,8 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
   const int iy0 = oy0 - 2, ix0 = ox0 - 2;
   const char* zeros = reinterpret_cast<const char*>(a.zeros);
   {
+    // LDS-DMA (global_load_lds).  (Staging through registers -- request every piece, then store -- was tried here as in the
+    // fused head: 10 % slower for this kernel, the waves sit at the ds_writes for the whole burst of the grid's first round.)
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     for (int p = wave_s; p < 2 * S * NT; p += 4) {
       const u32x4* src = p < S * NT ? reinterpret_cast<const u32x4*>(a.w1) + p * 64 : reinterpret_cast<const u32x4*>(a.w2) + (p - S * NT) * 64;
@@ -549,6 +588,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
       if (sl < RS) LP_GLDS16(src, tile + (iy * RS + pc * 64) * 16);
     }
   }
+  BN_STAMP(2)
   floatx4 bias1[NT], bias2[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -573,6 +613,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
     for (int i = 0; i < P1; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  BN_STAMP(3)
   for (int s = 0; s < S; ++s) {
     const int toff = lds_toff[4 * s + g];
     typename Tr<T>::frag af[NT], bf[P1];
@@ -585,6 +626,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
 #pragma unroll
       for (int i = 0; i < P1; ++i) acc[t][i] = Tr<T>::mma(af[t], bf[i], acc[t][i]);
   }
+  BN_STAMP(4)
   // ---- the intermediate replaces the input tile (every wave is done reading it after the barrier), or goes
   //      to its own region (SEP: no barrier needed before writing)
   if (!SEP) {
@@ -610,8 +652,9 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
         for (int t = 0; t < NT; ++t) {
           if (g * 4 * NT + t * 4 < a.C) {
             typename Tr<T>::quad q;
+            const floatx4 y = act4<T, ACT_SILU>(acc[t][i], bias1[t]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) q[r] = inside ? (T)activate_ct<T, ACT_SILU>(acc[t][i][r] + bias1[t][r]) : (T)0.f;
+            for (int r = 0; r < 4; ++r) q[r] = inside ? (T)y[r] : (T)0.f;
             *reinterpret_cast<typename Tr<T>::quad*>(dst + t * 4) = q;
           }
         }
@@ -623,6 +666,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  BN_STAMP(5)
   // ---- conv_b over the TH x TW output tile
   int pk2[P2], pb2[P2];
 #pragma unroll
@@ -650,6 +694,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
 #pragma unroll
       for (int i = 0; i < P2; ++i) acc2[t][i] = Tr<T>::mma(af[t], bf[i], acc2[t][i]);
   }
+  BN_STAMP(6)
   // ---- epilogue: bias, SiLU, shortcut (x from the preserved input tile, or re-read from global memory)
   const int chbase = g * 4 * NT;
   if constexpr (T2 == 0) {
@@ -658,53 +703,89 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
       const int p = (wave + 4 * i) * 16 + col;
       const int gy = oy0 + (pk2[i] >> 16), gx = ox0 + (pk2[i] & 0xffff);
       if (wave + 4 * i < n2 && p < R2 && gy < a.H && gx < a.W) {
-        const long pix = (long)(n * a.H + gy) * a.W + gx;
+        const int pix = (n * a.H + gy) * a.W + gx;
         floatx4 v[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = acc2[t][i];
         const T* xres = SEP ? reinterpret_cast<const T*>(tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PS) + chbase
-                            : reinterpret_cast<const T*>(a.in) + pix * a.in_pitch + chbase;
-        store_lane_at<T, NT, ACT_SILU>(reinterpret_cast<T*>(a.out) + pix * a.out_pitch + chbase, xres, chbase, a.C, v, bias2);
+                            : reinterpret_cast<const T*>(a.in) + eoff(pix, a.in_pitch) + chbase;
+        store_lane_at<T, NT, ACT_SILU>(reinterpret_cast<T*>(a.out) + eoff(pix, a.out_pitch) + chbase, xres, chbase, a.C, v, bias2);
       }
     }
   } else {
     // ---- ... and cv2 on concat[.., y_last]: per pixel tile, gather the stored segments, turn the accumulators into
     //      y_last (rounded to T and shortcut added exactly as the stand-alone store does), two small GEMMs, store
     constexpr int SGMAX = sizeof(T) == 2 ? 3 : 6;
-    const int ST = a.sg + SR;
+    const int sg_n = SG > 0 ? SG : a.sg;
+    const int ST = sg_n + SR;
     floatx4 bias3[T2];
 #pragma unroll
     for (int t = 0; t < T2; ++t) bias3[t] = *reinterpret_cast<const floatx4*>(a.b3 + g * 4 * T2 + t * 4);
-#pragma unroll
-    for (int i = 0; i < P2; ++i) {
-      if (wave + 4 * i >= n2) continue;  // wave-uniform
+    // The gathered concat segments of pixel tile i + LA are requested before tile i is worked on: one tile's arithmetic
+    // (~600 cycles) does not cover a global load, and with the loads issued where they are used this loop WAS the kernel
+    // (17-27 k of a workgroup's 40-50 k cycles: tools/bneck_stamps.py).
+    constexpr int LA = P2 < 4 ? P2 : 4;
+    auto tile_pixel = [&](int i, bool& valid) {
       const int p = (wave + 4 * i) * 16 + col;
       const int gy = oy0 + (pk2[i] >> 16), gx = ox0 + (pk2[i] & 0xffff);
-      const bool valid = p < R2 && gy < a.H && gx < a.W;
-      const long pix = valid ? (long)(n * a.H + gy) * a.W + gx : 0;
-      typename Tr<T>::frag bg[SGMAX];
-      const T* catp = reinterpret_cast<const T*>(a.cat) + pix * a.cat_pitch + g * G;
+      valid = wave + 4 * i < n2 && p < R2 && gy < a.H && gx < a.W;
+      return valid ? (n * a.H + gy) * a.W + gx : 0;
+    };
+    // SG > 0 (fp16): the number of gathered K steps is a template parameter and this loop is straight-line code -- every
+    // load unconditional from a valid address, masked by an AND where it is USED.  (A wave-uniform `if (s < a.sg)` or a
+    // per-lane `if (valid)` around a load splits the basic block, the value must be complete at the block's end, and the
+    // compiler puts s_waitcnt vmcnt(0) three instructions after every request.)  SG == 0 (fp32, up to 6 steps): branches.
+    constexpr bool FLAT = SG > 0;
+    constexpr int SGN = FLAT ? SG : SGMAX;
+    auto request = [&](int i, u32x4 (&dst)[SGN]) {
+      bool valid;
+      const int pix = tile_pixel(i, valid);
+      const T* catp = reinterpret_cast<const T*>(a.cat) + eoff(pix, a.cat_pitch) + g * G;
 #pragma unroll
-      for (int s = 0; s < SGMAX; ++s) {
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (s < a.sg) {  // wave-uniform: unused steps cost one scalar branch
-          if (valid && 4 * s + g < a.kg) v = *reinterpret_cast<const u32x4*>(catp + 4 * s * G);
+      for (int s = 0; s < SGN; ++s) {
+        if (FLAT) {
+          dst[s] = *reinterpret_cast<const u32x4*>(catp + (4 * s + g < a.kg ? 4 * s * G : 0));
+        } else {
+          dst[s] = u32x4{0u, 0u, 0u, 0u};
+          if (s < a.sg && valid && 4 * s + g < a.kg) dst[s] = *reinterpret_cast<const u32x4*>(catp + 4 * s * G);
         }
-        bg[s] = as_frag<T>(v);
+      }
+    };
+    u32x4 bgq[LA][SGN];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) request(i, bgq[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < P2; ++i) {
+      if (!FLAT && wave + 4 * i >= n2) continue;  // wave-uniform
+      bool valid;
+      const int pix = tile_pixel(i, valid);
+      typename Tr<T>::frag bg[SGN];
+#pragma unroll
+      for (int s = 0; s < SGN; ++s) {
+        const unsigned m = (!FLAT || (valid && 4 * s + g < a.kg)) ? 0xffffffffu : 0u;
+        bg[s] = as_frag<T>(bgq[i % LA][s] & m);
+      }
+      if (i + LA < P2) {
+        request(i + LA, bgq[i % LA]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests up here (the scheduler sinks loads to their first use)
       }
       // y_last: activation, round to T, add the shortcut, round again (= store_lane_at), kept as the register B operand
       const T* xres = SEP ? reinterpret_cast<const T*>(tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PS) + chbase
-                          : reinterpret_cast<const T*>(a.in) + pix * a.in_pitch + chbase;
+                          : reinterpret_cast<const T*>(a.in) + eoff(pix, a.in_pitch) + chbase;
       T yl[NT][4];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         typename Tr<T>::quad xr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) xr[r] = (T)0.f;
-        if (valid && chbase + t * 4 < a.C) xr = *reinterpret_cast<const typename Tr<T>::quad*>(xres + t * 4);
+        if (SEP) {  // x from the preserved LDS tile: always a valid address (the tile's pixel is clamped), masked by the add below
+          if (chbase + t * 4 < a.C) xr = *reinterpret_cast<const typename Tr<T>::quad*>(xres + t * 4);
+        } else if (valid && chbase + t * 4 < a.C) xr = *reinterpret_cast<const typename Tr<T>::quad*>(xres + t * 4);
+        const floatx4 y = act4<T, ACT_SILU>(acc2[t][i], bias2[t]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const T q = (T)activate_ct<T, ACT_SILU>(acc2[t][i][r] + bias2[t][r]);
+          const T q = (T)y[r];
           yl[t][r] = (T)((float)q + (float)xr[r]);
         }
       }
@@ -727,8 +808,8 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
 #pragma unroll
       for (int t = 0; t < T2; ++t) o[t] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < SGMAX; ++s) {
-        if (s < a.sg) {
+      for (int s = 0; s < SGN; ++s) {
+        if (FLAT || s < a.sg) {
 #pragma unroll
           for (int t = 0; t < T2; ++t) o[t] = Tr<T>::mma(as_frag<T>(lds_w3[(t * ST + s) * 64 + lane]), bg[s], o[t]);
         }
@@ -736,14 +817,16 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
 #pragma unroll
       for (int s = 0; s < SR; ++s)
 #pragma unroll
-        for (int t = 0; t < T2; ++t) o[t] = Tr<T>::mma(as_frag<T>(lds_w3[(t * ST + a.sg + s) * 64 + lane]), bq[s], o[t]);
+        for (int t = 0; t < T2; ++t) o[t] = Tr<T>::mma(as_frag<T>(lds_w3[(t * ST + sg_n + s) * 64 + lane]), bq[s], o[t]);
       if (valid) {
-        T* o3 = reinterpret_cast<T*>(a.out3) + pix * a.out3_pitch + g * 4 * T2;
+        T* o3 = reinterpret_cast<T*>(a.out3) + eoff(pix, a.out3_pitch) + g * 4 * T2;
         if (a.act3 == ACT_SILU) store_lane_at<T, T2, ACT_SILU>(o3, nullptr, g * 4 * T2, a.C3, o, bias3);
         else store_lane_at<T, T2, ACT_NONE>(o3, nullptr, g * 4 * T2, a.C3, o, bias3);
       }
     }
   }
+  BN_STAMP(7)
+  BN_STAMP(15)
 }
 
 // ------------------------------------------------------------------------------------
@@ -788,13 +871,13 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const ConvArgs a) {
     for (int p = 0; p < NP; ++p) {
       long pix = pix0 + p * 16 + col;
       pix = pix < M ? pix : M - 1;
-      src[p] = in + pix * a.in_pitch;
+      src[p] = in + eoff(pix, a.in_pitch);
       src2[p] = nullptr;
       if constexpr (UPS) {
-        const int hw = a.Hout * a.Wout;
-        const int n = (int)(pix / hw), rem = (int)(pix - (long)n * hw);
-        const int y = rem / a.Wout, x = rem - y * a.Wout;
-        src2[p] = reinterpret_cast<const T*>(a.up) + ((long)(n * (a.Hout >> 1) + (y >> 1)) * (a.Wout >> 1) + (x >> 1)) * a.up_pitch;
+        const int hw = a.pix_per_item;
+        const int n = fast_div((int)pix, hw, a.magic_hw), rem = (int)pix - n * hw;
+        const int y = fast_div(rem, a.Wout, a.magic_w), x = rem - y * a.Wout;
+        src2[p] = reinterpret_cast<const T*>(a.up) + eoff((n * (a.Hout >> 1) + (y >> 1)) * (a.Wout >> 1) + (x >> 1), a.up_pitch);
       }
     }
     floatx4 acc[NT][NP];
@@ -891,12 +974,13 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a)
     for (int p = 0; p < NP; ++p) {
       long pix = pix0 + p * 16 + col;
       pix = pix < M ? pix : M - 1;
-      const int n = (int)(pix / HWo);
-      const int rem = (int)(pix - (long)n * HWo);
-      const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+      const int n = fast_div((int)pix, HWo, a.magic_hw);
+      const int rem = (int)pix - n * HWo;
+      const int oy = fast_div(rem, a.Wout, a.magic_w), ox = rem - oy * a.Wout;
       iy0[p] = oy * 2 - 1;
       ix0[p] = ox * 2 - 1;
-      src[p] = in + ((long)(n * a.Hin + iy0[p]) * a.Win + ix0[p]) * a.in_pitch;  // dereferenced only when in bounds
+      // dereferenced only when in bounds (the signed pixel index of the padding row/column wraps like the pointer would)
+      src[p] = in + (long)(int)eoff((n * a.Hin + iy0[p]) * a.Win + ix0[p], a.in_pitch);
     }
     floatx4 acc[NT][NP];
 #pragma unroll
@@ -1192,8 +1276,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restric
     const int oy = oy0 + r, ox = ox0 + txe + (g >> 1);
     if (oy < Hout && ox < Wout) {
       half4 q4;
+      const floatx4 y4 = act4<half_t, ACT_SILU>(acc, b4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q4[j] = (half_t)Tr<half_t>::silu(acc[j] + b4[j]);
+      for (int j = 0; j < 4; ++j) q4[j] = (half_t)y4[j];
       *reinterpret_cast<half4*>(out + ((long)(n * Hout + oy) * Wout + ox) * out_pitch + c0) = q4;
     }
   }
@@ -1254,8 +1339,9 @@ __global__ __launch_bounds__(256) void stem_mfma16_kernel(const uint8_t* __restr
     const int oy = oy0 + r, ox = ox0 + tx;
     if (oy < Hout && ox < Wout) {
       half4 q4;
+      const floatx4 y4 = act4<half_t, ACT_SILU>(acc, b4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q4[j] = (half_t)Tr<half_t>::silu(acc[j] + b4[j]);
+      for (int j = 0; j < 4; ++j) q4[j] = (half_t)y4[j];
       *reinterpret_cast<half4*>(out + ((long)(n * Hout + oy) * Wout + ox) * out_pitch + 4 * g) = q4;
     }
   }
@@ -1342,8 +1428,9 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
       const int sy = 2 * oy0 - 1 + r, sx = 2 * ox0 - 1 + c;
       const bool inside = sb_interior || (sy >= 0 && sy < a.H1 && sx >= 0 && sx < a.W1);
       half4 q4;
+      const floatx4 y4 = act4<half_t, ACT_SILU>(acc, sb4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q4[j] = inside ? (half_t)Tr<half_t>::silu(acc[j] + sb4[j]) : (half_t)0.f;
+      for (int j = 0; j < 4; ++j) q4[j] = inside ? (half_t)y4[j] : (half_t)0.f;
       *reinterpret_cast<half4*>(st_tile + (r * SB_LW + c) * 16 + c0 * 2) = q4;
     }
   }
@@ -1378,7 +1465,7 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s], __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(base + toff[s])), acc, 0, 0, 0);
     const int gy = oy0 + oy, gx = ox0 + ox;
     if (gy < a.H2 && gx < a.W2) {
-      const long pix = (long)(n * a.H2 + gy) * a.W2 + gx;
+      const long pix = (n * a.H2 + gy) * a.W2 + gx;
       floatx4 v[1] = {acc};
       tail_store<half_t, 1, 1, ACT_SILU>(a2, pix, g, v, bias1, w2f, bias2);
     }
@@ -1389,6 +1476,8 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
 // Host side: weight packing and launch
 // ====================================================================================
 static size_t elem_size(int prec) { return prec == LP_FP16 ? 2 : 4; }
+static unsigned div_magic(int d) { return d <= 1 ? 0xffffffffu : (unsigned)((1ull << 32) / (unsigned)d); }
+static bool span_ok(int N, const View& v) { return !v.base || (double)N * v.H * v.W * v.pitch < 2147483648.0; }
 
 // LDS geometry of the 3x3 input tile, found by enumerating the ds_read_b128 lane groups
 // ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md, LDS) over every K step: with cg channel groups
@@ -1668,6 +1757,10 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
   a.in_pitch = io.in.pitch; a.out_pitch = io.out.pitch; a.res_pitch = io.res.pitch; a.x1_pitch = io.x1.pitch;
   a.Cin = Cin; a.Cout = Cout; a.act = act;
   a.M = io.N * io.out.H * io.out.W; a.pix_per_item = io.out.H * io.out.W;
+  a.magic_hw = div_magic(a.pix_per_item); a.magic_w = div_magic(io.out.W);
+  // the kernels address with 32-bit element offsets (eoff)
+  LP_CHECK(span_ok(io.N, io.in) && span_ok(io.N, io.out) && span_ok(io.N, io.res) && span_ok(io.N, io.x1) && span_ok(io.N, io.up), LP_ERR_ARG,
+           "conv %s: a tensor of batch %d exceeds 2^31 elements", name.c_str(), io.N);
   a.CK = CK; a.nchunks = nchunks; a.steps_per_chunk = steps; a.CGc = CGc; a.LW = LW; a.PS = PS;
   a.bwh = bwh; a.bww = bww; a.steps = steps; a.nsplit_tiles = NT;
   a.half_c = io.half_c; a.half_cp = io.half_cp; a.out_f32 = io.out_f32; a.stamps = io.stamps;
@@ -1905,11 +1998,21 @@ void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, 
   }
 }
 
+template <typename T, int NT, int P1, int P2, int T2, int SG>
+static void launch_bneck_sg(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  constexpr bool SEP = NT == 1;
+  set_max_dynamic_lds(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2, SG>), 160 * 1024);
+  hipLaunchKernelGGL((bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2, SG>), grid, dim3(256), lds, st, a);
+}
+// fp16 cv2 tails: the gathered K steps (1..3) are a template parameter (straight-line epilogue, see the kernel)
 template <typename T, int NT, int P1, int P2, int T2>
 static void launch_bneck_(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  constexpr bool SEP = NT == 1;
-  set_max_dynamic_lds(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2>), 160 * 1024);
-  hipLaunchKernelGGL((bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2>), grid, dim3(256), lds, st, a);
+  if constexpr (T2 > 0 && sizeof(T) == 2) {
+    if (a.sg == 1) return launch_bneck_sg<T, NT, P1, P2, T2, 1>(a, grid, lds, st);
+    if (a.sg == 2) return launch_bneck_sg<T, NT, P1, P2, T2, 2>(a, grid, lds, st);
+    if (a.sg == 3) return launch_bneck_sg<T, NT, P1, P2, T2, 3>(a, grid, lds, st);
+  }
+  launch_bneck_sg<T, NT, P1, P2, T2, 0>(a, grid, lds, st);
 }
 
 // cv2 tails exist for NT = 1 with T2 in {1, 2} and NT = 2 with T2 in {2, 4} (BottleneckPair::cv2_shape)
@@ -1942,6 +2045,7 @@ static void launch_bneck(const BneckArgs& a, int t2, dim3 grid, size_t lds, hipS
 void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t st, const View* cat) const {
   LP_CHECK(in.C == C && in.H == out.H && in.W == out.W, LP_ERR_STATE, "bottleneck: view mismatch");
   LP_CHECK((in.pitch % 8) == 0 && (out.pitch % 4) == 0, LP_ERR_STATE, "unaligned channel pitch");
+  LP_CHECK(span_ok(N, in) && span_ok(N, out) && (!cat || span_ok(N, *cat)), LP_ERR_ARG, "bottleneck: a tensor of batch %d exceeds 2^31 elements", N);
   BneckArgs k;
   memset(&k, 0, sizeof(k));
   k.in = in.base; k.out = out.base; k.w1 = a.d_w.p; k.w2 = b.d_w.p; k.b1 = a.d_bias.as<float>(); k.b2 = b.d_bias.as<float>();
@@ -1965,6 +2069,13 @@ void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t 
   dim3 grid(N, k.tiles_x * tiles_y);
   if (tile_major) grid = dim3(k.tiles_x * tiles_y, N);
   const bool f16 = prec == LP_FP16;
+  static const char* stamp_path = getenv("LITEPI_BNECK_STAMPS");
+  DevBuf d_stamps;
+  if (stamp_path && *stamp_path) {
+    d_stamps.alloc((size_t)grid.x * grid.y * 16 * 8);
+    LP_HIP(hipMemsetAsync(d_stamps.p, 0, (size_t)grid.x * grid.y * 16 * 8, st));
+    k.stamps = d_stamps.as<unsigned long long>();
+  }
   switch (NT) {
     case 1: if (f16) launch_bneck<half_t, 1>(k, T2, grid, lds_bytes, st); else launch_bneck<float, 1>(k, T2, grid, lds_bytes, st); break;
     case 2: if (f16) launch_bneck<half_t, 2>(k, T2, grid, lds_bytes, st); else launch_bneck<float, 2>(k, T2, grid, lds_bytes, st); break;
@@ -1972,6 +2083,18 @@ void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t 
     default: if (f16) launch_bneck<half_t, 4>(k, T2, grid, lds_bytes, st); else launch_bneck<float, 4>(k, T2, grid, lds_bytes, st); break;
   }
   LP_HIP(hipGetLastError());
+  if (k.stamps) {  // diagnostic: dump [grid][16] stamps, one record per launch (tools/bneck_stamps.py)
+    LP_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> hs((size_t)grid.x * grid.y * 16);
+    LP_HIP(hipMemcpy(hs.data(), d_stamps.p, hs.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(stamp_path, "ab")) {
+      const unsigned long long hdr[8] = {0x424e4543ull, hs.size() / 16, (unsigned long long)in.H, (unsigned long long)N, (unsigned long long)C,
+                                         (unsigned long long)T2, (unsigned long long)TH, (unsigned long long)TW};
+      fwrite(hdr, 8, 8, f);
+      fwrite(hs.data(), 8, hs.size(), f);
+      fclose(f);
+    }
+  }
 }
 
 void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<float>& w_bgr, const std::vector<float>& bias, int k_, int stride_, int pad_) {
