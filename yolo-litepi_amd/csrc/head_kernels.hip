@@ -79,25 +79,52 @@ __device__ __forceinline__ floatx16 bias16(const float* __restrict__ b) {
   return v;
 }
 
-// K loop of one weight chunk: acc[rt][p] += W(rt, step s) . X(pixels of p, K offset next_boff()) for s < KS.  The operand
-// fragments of step s+1 are requested BEFORE the MFMAs of step s (two register sets, static indices after unrolling): with
-// one wave per SIMD nothing else covers the LDS latency -- the compiler's own schedule of the plain loop ran at 53 cycles
-// per MFMA, this form at 37 (tools/ubench/mfma_rate.hip), against 32 for the bare instruction.  side(j), j < 6, runs behind
-// the MFMAs of step j: the weight ring's store + reload of piece j (see the kernel).
-template <int NA, int NB, int KS, typename F, typename G>
-__device__ __forceinline__ void kloop(const char* wb, const char* img, const int (&pix)[NB], F&& next_boff, G&& side, floatx16 (&acc)[NA][NB]) {
-  half8 af[2][NA], bf[2][NB];
-  auto ld = [&](int set, int s) {
+// all of this wave's LDS traffic done, then the workgroup barrier -- NOT __syncthreads(): that also waits for the global
+// loads in flight (vmcnt(0)), i.e. for the ring pieces requested a few hundred cycles ago
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// K loop of weight chunk c (ring slot c & 1): acc[rt][p] += W(rt, step s) . X(pixels of p, K offset next_boff()) for s < KS.
+//  * The operand fragments of step s+1 are requested BEFORE the MFMAs of step s (two register sets, static indices after
+//    unrolling): with one wave per SIMD nothing else covers the LDS latency -- the compiler's own schedule of the plain loop
+//    ran at 53 cycles per MFMA, this form at 37 (tools/ubench/mfma_rate.hip), against 32 for the bare instruction.
+//  * The pipeline runs ACROSS chunks (FIRST / LAST mark the ends of a run of chunks that share acc): the last step of a
+//    chunk first passes the ring barrier -- every wave has stored its pieces of chunk c+1 by then (they ride on steps
+//    0 .. KS-2) and has its last fragments of chunk c in registers, so the barrier publishes slot (c+1)&1 and frees slot c&1 at
+//    once -- and requests step 0 of chunk c+1 before its own MFMAs.  A barrier at the chunk boundary instead drained the
+//    pipeline: ~500 idle matrix-pipe cycles per chunk, 3-12 chunks per stage.  (KS odd: the register sets would swap roles
+//    from chunk to chunk; such chunks run stand-alone, FIRST && LAST.)
+//  * side(j), j < 6: the weight ring's store + reload of piece j (see the kernel).
+template <int NA, int NB, int KS, bool FIRST, bool LAST, typename F, typename G>
+__device__ __forceinline__ void kchunk(const char* ring, int c, int lane16, const char* img, const int (&pix)[NB], F&& next_boff, G&& side,
+                                       floatx16 (&acc)[NA][NB], half8 (&af)[2][NA], half8 (&bf)[2][NB]) {
+  static_assert(KS % 2 == 0 || (FIRST && LAST), "an odd chunk cannot hand its register sets to the next one");
+  static_assert(KS >= 3, "six ring pieces ride on steps 0 .. KS-2");
+  const char* wb = ring + (c & 1) * HD_SLOT + lane16;
+  const char* wbn = ring + ((c + 1) & 1) * HD_SLOT + lane16;
+  auto ld = [&](int set, const char* w, int s) {
     const int boff = next_boff();
 #pragma unroll
-    for (int rt = 0; rt < NA; ++rt) af[set][rt] = lds_h8(wb + (s * NA + rt) * 1024);
+    for (int rt = 0; rt < NA; ++rt) af[set][rt] = lds_h8(w + (s * NA + rt) * 1024);
 #pragma unroll
     for (int p = 0; p < NB; ++p) bf[set][p] = lds_h8(img + pix[p] + boff);
   };
-  ld(0, 0);
+  constexpr int PPS = (6 + KS - 2) / (KS - 1);   // ring pieces per step
+  if (FIRST) {
+    lds_barrier();
+    ld(0, wb, 0);
+  }
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    if (s + 1 < KS) ld((s + 1) & 1, s + 1);
+    if (s + 1 < KS) {
+      ld((s + 1) & 1, wb, s + 1);
+    } else if (!LAST) {
+      lds_barrier();
+      ld(0, wbn, 0);
+    }
     // pin the order: without this the scheduler sinks the reads below the MFMAs and folds the two register sets into one
     // (reads of step s+1 issued after the last MFMA of step s: ~100 idle matrix-pipe cycles per step, 50+ cycles per MFMA)
     __builtin_amdgcn_sched_barrier(0);
@@ -105,10 +132,9 @@ __device__ __forceinline__ void kloop(const char* wb, const char* img, const int
     for (int rt = 0; rt < NA; ++rt)
 #pragma unroll
       for (int p = 0; p < NB; ++p) acc[rt][p] = mfma32(af[s & 1][rt], bf[s & 1][p], acc[rt][p]);
-    if (s < 6) side(s);
-  }
 #pragma unroll
-  for (int j = KS; j < 6; ++j) side(j);
+    for (int j = s * PPS; j < (s + 1) * PPS && j < 6; ++j) side(j);
+  }
 }
 
 // NPC: 64-slot pieces per input-tile row, KSA: K steps per stage-A chunk (both fixed by the level's tile shape, see host)
@@ -235,11 +261,6 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
   for (int i = 0; i < 16; ++i) dflw[i] = a.dfl_w[i];
   const int lane16 = lane * 16;
   int c = 0;
-  // one chunk: the barrier publishes chunk c (stored during chunk c-1) and frees the other slot for chunk c+1
-#define HD_CHUNK_BEGIN                                             \
-  wsource(c + 2);                                                 \
-  __syncthreads();                                                \
-  const char* wb = RING + (c & 1) * HD_SLOT + lane16;
   auto ring_side = [&](int j) {
     wstore1(c + 1, j);
     wload1(j);
@@ -268,10 +289,24 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
       return boff;
     };
     const int ncA = nch - (C3T == 2 ? 7 : 5);   // stream = A chunks | 3 box-B | 1 class-B (3 with two class row tiles) | 1 C
-    for (; c < ncA; ++c) {
-      HD_CHUNK_BEGIN
-      if (c == 0) { HD_STAMP(3) }
-      kloop<RT, PA, KSA>(wb, IN, pixA, next_boff, ring_side, accA);
+    half8 af[2][RT], bf[2][PA];
+    if constexpr (KSA % 2 == 0) {   // one operand pipeline over all of stage A (ncA >= 2, host-checked)
+      wsource(c + 2);
+      kchunk<RT, PA, KSA, true, false>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+      HD_STAMP(3)
+      for (++c; c < ncA - 1; ++c) {
+        wsource(c + 2);
+        kchunk<RT, PA, KSA, false, false>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+      }
+      wsource(c + 2);
+      kchunk<RT, PA, KSA, false, true>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+      ++c;
+    } else {
+      for (; c < ncA; ++c) {
+        wsource(c + 2);
+        kchunk<RT, PA, KSA, true, true>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+        if (c == 0) { HD_STAMP(3) }
+      }
     }
   }
   HD_STAMP(4)
@@ -318,17 +353,24 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) tapB[t] = ((t / 3) * RW1 + (t % 3)) * SPM * 16;
   {
-#pragma unroll
-    for (int cb = 0; cb < 3; ++cb, ++c) {
-      int kq = cb * 12;   // compile-time after unrolling: tap and channel group of every step are immediates
-      auto next_boff = [&]() {
-        const int boff = tapB[kq >> 2] + (kq & 3) * 32;
-        ++kq;
-        return boff;
-      };
-      HD_CHUNK_BEGIN   // (first pass: the barrier also orders the MID stores before the reads below)
-      kloop<2, PB, 12>(wb, MID, pixB, next_boff, ring_side, accB);
-    }
+    // three chunks of 12 steps, one pipeline; tap and channel group of every step are immediates after unrolling.  (The
+    // first barrier also orders the MID stores before the reads.)
+    int kq = 0;
+    auto next_boff = [&]() {
+      const int boff = tapB[kq >> 2] + (kq & 3) * 32;
+      ++kq;
+      return boff;
+    };
+    half8 af[2][2], bf[2][PB];
+    wsource(c + 2);
+    kchunk<2, PB, 12, true, false>(RING, c, lane16, MID, pixB, next_boff, ring_side, accB, af, bf);
+    ++c;
+    wsource(c + 2);
+    kchunk<2, PB, 12, false, false>(RING, c, lane16, MID, pixB, next_boff, ring_side, accB, af, bf);
+    ++c;
+    wsource(c + 2);
+    kchunk<2, PB, 12, false, true>(RING, c, lane16, MID, pixB, next_boff, ring_side, accB, af, bf);
+    ++c;
   }
   HD_STAMP(6)
   // ======================= stage B, class tower: (32*C3T) x (9 * 32*C3T) x tile pixels =======================
@@ -340,23 +382,34 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
     for (int p = 0; p < PB; ++p) accC[rt][p] = b;
   }
   {
-#pragma unroll
-    for (int cb = 0; cb < (C3T == 2 ? 3 : 1); ++cb, ++c) {
-      int kq = cb * 12;
-      auto next_boff = [&]() {
-        const int tap = C3T == 2 ? kq >> 2 : kq >> 1, cg = C3T == 2 ? kq & 3 : kq & 1;
-        ++kq;
-        return tapB[tap] + (8 + 2 * cg) * 16;
-      };
-      HD_CHUNK_BEGIN
-      kloop<C3T, PB, (C3T == 2 ? 12 : 18)>(wb, MID, pixB, next_boff, ring_side, accC);
+    int kq = 0;
+    auto next_boff = [&]() {
+      const int tap = C3T == 2 ? kq >> 2 : kq >> 1, cg = C3T == 2 ? kq & 3 : kq & 1;
+      ++kq;
+      return tapB[tap] + (8 + 2 * cg) * 16;
+    };
+    half8 af[2][C3T], bf[2][PB];
+    if constexpr (C3T == 2) {
+      wsource(c + 2);
+      kchunk<C3T, PB, 12, true, false>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
+      ++c;
+      wsource(c + 2);
+      kchunk<C3T, PB, 12, false, false>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
+      ++c;
+      wsource(c + 2);
+      kchunk<C3T, PB, 12, false, true>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
+      ++c;
+    } else {
+      wsource(c + 2);
+      kchunk<C3T, PB, 18, true, true>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
+      ++c;
     }
   }
   // ======================= stage C: the 1x1 projections from the accumulators, then decode =======================
   HD_STAMP(7)
   half8 wcb[2][4], wcc[2 * C3T];
   {
-    __syncthreads();
+    lds_barrier();   // the projection chunk was stored behind the class tower's steps
     const char* wb = RING + (c & 1) * HD_SLOT + lane16;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -385,24 +438,23 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) oc = mfma32(wcc[mt * 2 + s], silu_h8(accC[mt][p], 8 * s), oc);
     // ---- decode (model.ncnn.param:184-208).  The projection rows are permuted so that this lane holds, for row tile rt,
-    //      the 16 bins of box side 2*rt + h; logits are rounded to fp16 first, as the stored projection output was.
+    //      the 16 bins of box side 2*rt + h.
     float dist[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      float l[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) l[i] = (float)(half_t)ob[rt][i];
+      // (fp32 logits straight from the accumulators: closer to the reference than the fp16 round trip of a stored projection)
+      floatx16 l = ob[rt];
       float mx = l[0];
 #pragma unroll
       for (int i = 1; i < 16; ++i) mx = fmaxf(mx, l[i]);
       float sum = 0.f, ex = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float e = __expf(l[i] - mx);
+        const float e = __builtin_amdgcn_exp2f((l[i] - mx) * 1.4426950408889634f);
         sum += e;
         ex += e * dflw[i];
       }
-      dist[rt] = ex / sum;
+      dist[rt] = ex * __builtin_amdgcn_rcpf(sum);
     }
     const float x0 = __shfl_xor(dist[0], 32), x1 = __shfl_xor(dist[1], 32);
     const float d0 = h ? x0 : dist[0], d1 = h ? dist[0] : x0, d2 = h ? x1 : dist[1], d3 = h ? dist[1] : x1;
@@ -414,7 +466,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
     for (int i = 0; i < 16; ++i) {
       sc[i] = 0.f;
       if (16 * h + i < a.nc) {   // (nc = 1: one lane half evaluates one sigmoid)
-        sc[i] = 1.f / (1.f + __expf(-(float)(half_t)oc[i]));
+        sc[i] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(oc[i] * -1.4426950408889634f));
         if (sc[i] > best) { best = sc[i]; best_c = 16 * h + i; }
       }
     }
@@ -441,7 +493,6 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
   }
   HD_STAMP(9)
   HD_STAMP(15)
-#undef HD_CHUNK_BEGIN
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -494,6 +545,7 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   const int RT = 2 + C3T, CM = 32 * C3T;
   // chunks hold at most 24 fragments (one ring slot): stage A KSA K steps x RT row tiles, stage B box 12 x 2, class 18 x 1
   // (12 x 2 for two class row tiles), projections 10 (12)
+  LP_CHECK(KSA % 2 != 0 || 9 * KPT / KSA >= 2, LP_ERR_STATE, "Detect head %s: stage A needs two chunks", name.c_str());
   LP_CHECK(lds_bytes <= 160 * 1024 && ((TW + 4) * (2 * KPT + 1) + 63) / 64 == NPC && (9 * KPT) % KSA == 0 && RT * KSA <= 24 && TH + 4 <= 20 &&
                (TH + 2) * (TW + 2) <= 128 * PA && TH * TW <= 128 * PB, LP_ERR_STATE, "Detect head %s: inconsistent configuration", name.c_str());
   (void)batch_hint;
