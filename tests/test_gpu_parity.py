@@ -646,6 +646,32 @@ def test_bench_configuration_fp16_capacity64(tmp_path, preset):
     assert st["boxes"] >= 64 and st["stable"] >= 32
 
 
+def test_fused_head_wide_towers_v2(tmp_path, monkeypatch):
+    """The fused Detect-head kernel's configurations for two class row tiles (48-channel class towers, v2 widths) are opt-in
+    (LITEPI_HEADFUSE=all, see Detector::load): run them through the same every-image oracle check as the default plan."""
+    from litepi import HybridPipeline, ncnn_export
+    from oracle import ncnn_ref, shufflenet_ref as S
+    monkeypatch.setenv("LITEPI_HEADFUSE", "all")
+    p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    ncnn_export.export_detector(p, b, "v2", seed=1234, cls_bias=0.0)
+    imgs = np.random.default_rng(5).integers(0, 256, (16, 640, 640, 3), dtype=np.uint8)
+    _calibrate(p, b, imgs[:8], 8)
+    sd = S.seeded_state_dict(91)
+    cls_path = str(tmp_path / "cls.pth")
+    torch.save(sd, cls_path)
+    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=16, max_det=300)
+    try:
+        pipe.engine.profile_next(True)
+        pipe.engine.detect_raw(imgs)
+        names = [r["name"] for r in pipe.engine.profile_read()]
+        st = _check_fp16_against_oracle(pipe, ncnn_ref.load_model(p, b), S.build(91, sd), imgs)
+    finally:
+        pipe.engine.close()
+    print(f"v2 fused head fp16: {st}")
+    assert any("head_fused" in n for n in names), names
+    assert st["boxes"] >= 16 and st["stable"] >= 8
+
+
 def test_every_roi_is_classified_beyond_64_per_image(tmp_path):
     """The reference classifies EVERY kept box (e2e.py:493-497).  Two images with far more than 64 ROIs each through one
     B = 2 call: no cls_class == -1, counts agree with the oracle on the device's out0, and a max_rois that is too small

@@ -9,6 +9,7 @@
 // Channel counts that are not multiples of 8 (v2: 12-channel C2f halves) are padded per
 // segment; padding channels carry zero weights on both sides and stay zero.
 #include "detector.h"
+#include <cstring>
 
 #include <algorithm>
 #include <functional>
@@ -843,7 +844,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   //      has exactly this shape, each (A, B, C) triple becomes one HEAD op (head_fused_kernel) that also decodes and filters,
   //      and the stand-alone decode launch disappears.
   if (!getenv("LITEPI_NO_HEADFUSE") && prec_ == LP_FP16 && impl_ == IMPL_MFMA && reg_max_ == 16) {
-    struct Trip { int a, b, c, c3; };
+    struct Trip { int a, b, c, c3, proj; };   // proj: the class tower's 1x1 projection when it is a launch of its own (else -1)
     std::vector<Trip> trips;
     auto producer_of = [&](int tensor) {
       for (size_t q = 0; q < ops_.size(); ++q)
@@ -852,19 +853,29 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     };
     bool all = true;
     for (auto& lv : levels_) {
-      const int ob = producer_of(lv.box), oc = producer_of(lv.cls);
+      const int ob = producer_of(lv.box);
+      int oc = producer_of(lv.cls), oproj = -1;
       if (ob < 0 || oc < 0) { all = false; break; }
+      // class tower: second 3x3 with the projection as its fused tail, or (48-channel towers: no tail kernel for three
+      // channel tiles) the 3x3 and the 1x1 as two launches
+      if (convs_[ops_[oc].conv]->k == 1) {
+        const ConvLayer& cp = *convs_[ops_[oc].conv];
+        oproj = oc;
+        oc = producer_of(ops_[oproj].in);
+        if (oc < 0 || cp.T2 != 0 || cp.act != ACT_NONE || ops_[oproj].res >= 0 || ops_[oproj].in2 >= 0 || cp.Cin != convs_[ops_[oc].conv]->Cout ||
+            convs_[ops_[oc].conv]->T2 != 0 || cp.b_host.empty()) { all = false; break; }
+      }
       const ConvLayer& cb = *convs_[ops_[ob].conv];
       const ConvLayer& cc = *convs_[ops_[oc].conv];
       const Tensor& tb = tensors_[ops_[ob].in];
       const Tensor& tc = tensors_[ops_[oc].in];
       bool ok = cb.k == 3 && cb.stride == 1 && cb.T2 > 0 && cb.act == ACT_SILU && cb.act2 == ACT_NONE && cb.Cin == 64 && cb.Cout == 64 &&
-                cb.Cout2 == 64 && cc.k == 3 && cc.stride == 1 && cc.T2 > 0 && cc.act == ACT_SILU && cc.act2 == ACT_NONE && cc.Cin == cc.Cout &&
+                cb.Cout2 == 64 && cc.k == 3 && cc.stride == 1 && (oproj >= 0 || (cc.T2 > 0 && cc.act2 == ACT_NONE)) && cc.act == ACT_SILU && cc.Cin == cc.Cout &&
                 ops_[ob].res < 0 && ops_[oc].res < 0 && tb.buf >= 0 && tb.buf == tc.buf && tb.parent < 0 && tc.parent < 0 && tb.off == 0 &&
                 tc.off == tb.Cp && tb.Cp == 64 && tc.Cp == cc.Cin && buffers_[tb.buf].Cp == 64 + cc.Cin;
       int oa = -1;
       for (size_t q = 0; ok && q < ops_.size(); ++q)
-        if (ops_[q].kind == DetOp::CONV && ops_[q].out >= 0 && tensors_[ops_[q].out].buf == tb.buf && (int)q != ob && (int)q != oc) oa = (int)q;
+        if (ops_[q].kind == DetOp::CONV && ops_[q].out >= 0 && tensors_[ops_[q].out].buf == tb.buf && (int)q != ob && (int)q != oc && (int)q != oproj) oa = (int)q;
       ok = ok && oa >= 0 && oa < ob && oa < oc;
       if (ok) {
         const ConvLayer& ca = *convs_[ops_[oa].conv];
@@ -874,7 +885,14 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
              HeadLayer::supported(ca.Cin, 64, cc.Cin, nc_, reg_max_, lv.H, lv.W);
       }
       if (!ok) { all = false; break; }
-      trips.push_back({oa, ob, oc, cc.Cin});
+      trips.push_back({oa, ob, oc, cc.Cin, oproj});
+    }
+    // Two class row tiles (48-channel class towers, v2): the head kernel's tile shapes for these widths are correct
+    // (tests/test_gpu_parity.py runs them) but not yet faster end to end than the three-launch plan -- the kernel owns a
+    // CU's whole LDS, which costs the overlap with the other batches in flight -- so they are opt-in: LITEPI_HEADFUSE=all
+    if (all && !trips.empty() && trips[0].c3 > 32) {
+      const char* hf = getenv("LITEPI_HEADFUSE");
+      if (!hf || strcmp(hf, "all") != 0) all = false;
     }
     if (all && trips.size() == levels_.size()) {
       std::vector<char> dead(ops_.size(), 0);
@@ -888,15 +906,20 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         src.wbb = &cb.w_host; src.bbb = &cb.b_host; src.wpb = &cb.w2_host; src.bpb = &cb.b2_host;
         src.wbc = &cc.w_host; src.bbc = &cc.b_host; src.wpc = &cc.w2_host; src.bpc = &cc.b2_host;
         src.ncp = cc.Cout2;
+        if (t.proj >= 0) {
+          const ConvLayer& cp = *convs_[ops_[t.proj].conv];
+          src.wpc = &cp.w_host; src.bpc = &cp.b_host; src.ncp = cp.Cout;
+        }
         heads_.emplace_back(new HeadLayer());
         heads_.back()->name = ops_[t.a].layer + "+" + ops_[t.b].layer + "+" + ops_[t.c].layer + "+decode";
         heads_.back()->build(ca.Cin, t.c3, nc_, levels_[q].H, levels_[q].W, maxB_, src);
         DetOp& op = ops_[t.a];
         op.kind = DetOp::HEAD; op.conv = (int)heads_.size() - 1; op.in2 = (int)q; op.out = -1;
         op.layer = heads_.back()->name;
-        op.flops = ops_[t.a].flops + ops_[t.b].flops + ops_[t.c].flops;
+        op.flops = ops_[t.a].flops + ops_[t.b].flops + ops_[t.c].flops + (t.proj >= 0 ? ops_[t.proj].flops : 0.0);
         op.bytes = (double)tensors_[op.in].C * levels_[q].H * levels_[q].W * esd;
         dead[t.b] = dead[t.c] = 1;
+        if (t.proj >= 0) dead[t.proj] = 1;
       }
       std::vector<DetOp> kept;
       for (size_t q = 0; q < ops_.size(); ++q)
