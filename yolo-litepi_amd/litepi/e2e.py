@@ -49,8 +49,16 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--batch_images", type=int, default=1, help="images per GPU call")
     p.add_argument("--precision", type=str, choices=["fp16", "fp32"], default="fp16")
     p.add_argument("--hip_device", type=int, default=0)
-    p.add_argument("--max_det", type=int, default=300, help="detections kept per image (the reference keeps all)")
+    p.add_argument("--max_det", type=int, default=0,
+                   help="detections kept per image; 0 = one slot per anchor, i.e. nothing is ever dropped (what the reference does: "
+                        "e2e.py:280-296 keeps every NMS survivor, and the evaluation pass at --yolo_conf 0.001 produces thousands)")
+    p.add_argument("--max_rois", type=int, default=0, help="classifier capacity per call; 0 = batch_images x max_det")
     return p
+
+
+def num_anchors(det_input_size: int) -> int:
+    """Anchor points of the Detect head on a square input: one per cell of the stride-8/16/32 grids (8400 at 640)."""
+    return sum(((det_input_size + s - 1) // s) ** 2 for s in (8, 16, 32))
 
 
 def load_class_names(path: str) -> List[str]:
@@ -201,22 +209,23 @@ def evaluate_predictions(all_preds, all_gts, num_classes, iou_threshold=0.5, iou
 
 
 # ------------------------------------------------------------------------------------------------
-def main(argv=None) -> int:
-    import pandas as pd
-
+def run_evaluation(args) -> Dict:
+    """The reference's main loop (e2e.py:1090-1130) over image CHUNKS of --batch_images: per chunk one benchmark pass at
+    --benchmark_conf (its wall time feeds the FPS figure) and, unless the two thresholds are equal, one evaluation pass at
+    --yolo_conf whose detections feed the metric (process_image, e2e.py:953-1011).  Returns everything main() prints/writes."""
     from .backend import HybridPipeline
 
-    args = build_parser().parse_args(argv)
     class_names = load_class_names(args.classes)
     num_classes = len(class_names)
     detector_name = Path(args.detector_param).stem
     combo = f"{detector_name}+{args.clf_arch}"
     print(f"\n{'=' * 60}\nMODEL COMBINATION: {combo}\n{'=' * 60}")
     nb = max(1, args.batch_images)
+    max_det = args.max_det if args.max_det > 0 else num_anchors(args.det_input_size)
     pipeline = HybridPipeline(args.detector_param, args.detector_bin, args.classifier, args.clf_arch, num_classes,
                               args.det_input_size, args.cls_input_size, False, args.detector_threads, args.device,
-                              args.batch_size, precision=args.precision, max_batch=nb, max_det=args.max_det,
-                              device=args.hip_device)
+                              args.batch_size, precision=args.precision, max_batch=nb, max_det=max_det,
+                              device=args.hip_device, max_rois=args.max_rois)
     out_dir = Path(args.output) / combo
     out_dir.mkdir(parents=True, exist_ok=True)
 
@@ -231,30 +240,42 @@ def main(argv=None) -> int:
             files = sample_images(files, args.num_samples, args.seed)
     print(f"\nFound {len(files)} images for processing")
 
-    all_preds, all_gts, bench_time = [], [], 0.0
-    for i in range(0, len(files), nb):
-        chunk, imgs = [], []
-        for f in files[i:i + nb]:
-            im = read_image_bgr(f)
-            if im is None:
-                print(f"\nSkipping {f.name}")
+    all_preds, all_gts, bench_time, names = [], [], 0.0, []
+    try:
+        for i in range(0, len(files), nb):
+            chunk, imgs = [], []
+            for f in files[i:i + nb]:
+                im = read_image_bgr(f)
+                if im is None:
+                    print(f"\nSkipping {f.name}")
+                    continue
+                chunk.append(f)
+                imgs.append(im)
+            if not imgs:
                 continue
-            chunk.append(f)
-            imgs.append(im)
-        if not imgs:
-            continue
-        bench = pipeline.run_batch(imgs, args.benchmark_conf, args.iou_threshold, args.min_area)
-        bench_time += sum(m.t_total for _, m in bench) / 1000.0
-        ev = bench if args.yolo_conf == args.benchmark_conf else pipeline.run_batch(imgs, args.yolo_conf, args.iou_threshold, args.min_area)
-        for f, im, (res, _) in zip(chunk, imgs, ev):
-            lp = (label_dir / f"{f.stem}.txt") if label_dir else f.parent / "labels" / f"{f.stem}.txt"
-            all_gts.append(parse_yolo_label(lp, im.shape[1], im.shape[0]))
-            all_preds.append([{"bbox": r["bbox"], "conf": r.get("det_conf", 0.0), "cls_class": r.get("cls_class", -1)} for r in res])
-
-    print("\n" + "=" * 80 + f"\nEVALUATION RESULTS - {combo}\n" + "=" * 80)
+            bench = pipeline.run_batch(imgs, args.benchmark_conf, args.iou_threshold, args.min_area)
+            bench_time += sum(m.t_total for _, m in bench) / 1000.0
+            ev = bench if args.yolo_conf == args.benchmark_conf else pipeline.run_batch(imgs, args.yolo_conf, args.iou_threshold, args.min_area)
+            for f, im, (res, _) in zip(chunk, imgs, ev):
+                lp = (label_dir / f"{f.stem}.txt") if label_dir else f.parent / "labels" / f"{f.stem}.txt"
+                all_gts.append(parse_yolo_label(lp, im.shape[1], im.shape[0]))
+                all_preds.append([{"bbox": r["bbox"], "conf": r.get("det_conf", 0.0), "cls_class": r.get("cls_class", -1)} for r in res])
+                names.append(f.name)
+    finally:
+        pipeline.engine.close()
     m = evaluate_predictions(all_preds, all_gts, num_classes, args.iou_threshold)
     avg = bench_time / len(all_preds) if all_preds else 0.0
-    fps = 1.0 / avg if avg > 0 else 0.0
+    return {"combo": combo, "detector": detector_name, "class_names": class_names, "metrics": m, "avg_time": avg,
+            "fps": 1.0 / avg if avg > 0 else 0.0, "all_preds": all_preds, "all_gts": all_gts, "files": names, "max_det": max_det}
+
+
+def main(argv=None) -> int:
+    import pandas as pd
+
+    args = build_parser().parse_args(argv)
+    r = run_evaluation(args)
+    combo, m, class_names, fps, avg = r["combo"], r["metrics"], r["class_names"], r["fps"], r["avg_time"]
+    print("\n" + "=" * 80 + f"\nEVALUATION RESULTS - {combo}\n" + "=" * 80)
     print(f"\nPerformance Metrics (at conf={args.benchmark_conf}):\n  Avg Inference Time: {avg * 1000:.2f} ms\n  Real FPS:           {fps:.2f} FPS")
     print(f"\nAccuracy Metrics (at conf={args.yolo_conf}):")
     print(f"{'Class':<20} {'Precision':>10} {'Recall':>10} {'F1':>10} {'TP':>6} {'FP':>6} {'FN':>6}\n" + "-" * 80)
@@ -266,15 +287,14 @@ def main(argv=None) -> int:
     mean = lambda k: float(np.mean(m[k][valid])) if valid.any() else 0.0  # noqa: E731
     print("-" * 80 + f"\n{'MEAN':<20} {mean('precision'):>10.3f} {mean('recall'):>10.3f} {mean('f1'):>10.3f}")
     print(f"{'mAP@0.5':<20} {m['mAP50']:>10.3f}\n{'mAP@0.5:0.95':<20} {m['mAP50_95']:>10.3f}")
-    row = pd.DataFrame([{"model_combination": combo, "detector": detector_name, "classifier": args.clf_arch,
-                         "num_test_images": len(all_preds), "mean_precision": mean("precision"), "mean_recall": mean("recall"),
+    row = pd.DataFrame([{"model_combination": combo, "detector": r["detector"], "classifier": args.clf_arch,
+                         "num_test_images": len(r["all_preds"]), "mean_precision": mean("precision"), "mean_recall": mean("recall"),
                          "mean_f1": mean("f1"), "fps": fps, "mAP50": m["mAP50"], "mAP50-95": m["mAP50_95"]}])
     summary = Path(args.output) / "comparison_summary.csv"
     if summary.exists():
         row = pd.concat([pd.read_csv(summary), row], ignore_index=True)
     row.to_csv(summary, index=False)
     print(f"Updated comparison summary at {summary}")
-    pipeline.engine.close()
     return 0
 
 
