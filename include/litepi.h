@@ -37,6 +37,8 @@ enum lp_status {
 };
 
 enum lp_precision { LP_FP32 = 0, LP_FP16 = 1 };
+enum lp_numerics { LP_NUMERICS_E2E = 0, LP_NUMERICS_E2E_OPTIMIZE = 1 };
+enum lp_cls_arch { LP_CLS_SHUFFLENETV2 = 0, LP_CLS_RESNET18 = 1 };
 
 typedef struct lp_config {
   int device;        /* HIP device ordinal */
@@ -52,7 +54,13 @@ typedef struct lp_config {
                         (e2e.py:493-497).  A smaller value that a batch exceeds makes lp_run_batch fail with
                         LP_ERR_STATE instead of leaving detections unclassified silently */
   int conv_impl;     /* 0 = MFMA kernels (product), 1 = naive direct kernels (GPU debug aid) */
-  int reserved[7];
+  int numerics;      /* which of the reference's two pipelines the ROI stage follows:
+                        0 = HybridPipeline (src/tt100k/pipeline/e2e.py:460-485, 366-370): clip x1<=w-1, x2>=x1+1 ..., PIL
+                            antialiased bilinear resize;
+                        1 = HybridPipelineOptimized (e2e_optimize.py:480-497, 386-390): clip to [0,w] x [0,h], drop empty
+                            rectangles, cv2.resize INTER_LINEAR (no antialias).  PARITY UNPINNED (cv2 absent, no fixtures) */
+  int cls_arch;      /* lp_cls_arch: classifier architecture (e2e.py:320-333 --clf_arch) */
+  int reserved[5];
 } lp_config;
 
 /* One detection, 32 bytes.  Mirrors one result dict of HybridPipeline.run

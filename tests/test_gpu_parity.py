@@ -930,3 +930,91 @@ def test_detect_non_square_images_fp32(tmp_path, hw):
         assert d[j] <= 0.05 and abs(gs[j] - sc) <= 1e-3, (box, gb[j])
     if len(gb):
         assert gb[:, [0, 2]].max() <= hw[1] and gb[:, [1, 3]].max() <= hw[0] and gb.min() >= 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# e2e_optimize numerics (lp_config::numerics = 1): the reference's second pipeline, src/tt100k/pipeline/e2e_optimize.py.
+# PARITY UNPINNED by the reference (cv2 absent, no fixtures): the checker is oracle/optimize_ref.py.
+# ---------------------------------------------------------------------------------------------------------------------
+def test_optimize_numerics_roi_rule_and_linear_resize():
+    """ROI rectangles (e2e_optimize.py:480-497) through lp_test_postprocess and the cv2-linear ROI resize
+    (e2e_optimize.py:386-390) through lp_test_roi_resize: bit-equal to the oracle."""
+    from litepi import Engine
+    from oracle import optimize_ref as O, postprocess_ref as P
+    rng = np.random.default_rng(21)
+    e = Engine(precision="fp32", max_batch=1, numerics="e2e_optimize")
+    try:
+        # --- rectangles: boxes hugging the borders so that the two clip rules disagree
+        A = 8400
+        out0 = np.zeros((5, A), np.float32)
+        n = 400
+        idx = rng.choice(A, n, replace=False)
+        cx = rng.uniform(-10, 650, n); cy = rng.uniform(-10, 650, n)
+        cx[:60] = rng.choice([0.0, 639.6, 640.0], 60); cy[60:120] = rng.choice([0.0, 639.7, 640.0], 60)
+        out0[0, idx], out0[1, idx] = cx, cy
+        out0[2, idx], out0[3, idx] = rng.uniform(0.0, 90, n), rng.uniform(0.0, 90, n)
+        out0[2, idx[:40]] = 0.0   # zero-width boxes: e2e.py widens them to one pixel, e2e_optimize drops them
+        out0[4, idx] = rng.uniform(0.3, 0.99, n)
+        for hw, ratio, pad in (((640, 640), 1.0, (0.0, 0.0)), ((681, 1198), 640 / 1198, (0.0, 138.0))):
+            dets, rects, num = e.test_postprocess(out0, hw, ratio, pad, 0.25, 0.45, min_area=50, with_rects=True)
+            cnt = len(dets)
+            eb, es, ec = P.postprocess(out0, hw, ratio, pad, 0.25, 0.45)
+            er, valid = O.roi_rects(eb, hw[0], hw[1], 50)
+            e0, v0 = P.roi_rects(eb, hw[0], hw[1], 50)
+            assert num == len(eb) and cnt == len(valid)
+            assert np.array_equal(rects[:cnt], er.astype(np.int32))
+            assert np.array_equal(np.stack([dets["x1"], dets["y1"], dets["x2"], dets["y2"]], 1)[:cnt], eb[valid])
+            print(f"optimize ROI rule {hw}: {len(eb)} boxes, {len(valid)} kept (e2e.py rule keeps {len(v0)})")
+            assert hw != (640, 640) or len(valid) != len(v0), "the scenario must separate the two rules"
+        # --- resize
+        crops = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in
+                 ((64, 64), (5, 7), (1, 1), (17, 130), (300, 200), (64, 20), (333, 64), (91, 77), (513, 700))]
+        got = e.test_roi_resize(crops)
+        want = O.preprocess_rois(crops, 64)
+        assert got.shape == want.shape
+        bad = int((got != want).sum())
+        assert bad == 0, f"{bad} bytes differ from the cv2-linear oracle"
+    finally:
+        e.close()
+
+
+def test_optimize_numerics_pipeline(tmp_path):
+    """Full pipeline under the e2e_optimize numerics: decisions exact on the device's own out0 (optimize ROI rule), and the
+    classifier evaluated by the oracle on the cv2-linear crops of the same rectangles."""
+    from litepi import HybridPipeline, ncnn_export
+    from oracle import optimize_ref as O, postprocess_ref as P, shufflenet_ref as S
+    p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    ncnn_export.export_detector(p, b, "v1", seed=1234, cls_bias=0.0)
+    imgs = np.random.default_rng(3).integers(0, 256, (6, 640, 640, 3), dtype=np.uint8)
+    _calibrate(p, b, imgs, 10)
+    sd = S.seeded_state_dict(33)
+    cls_path = str(tmp_path / "cls.pth")
+    torch.save(sd, cls_path)
+    model = S.build(33, sd)
+    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=33, precision="fp32", max_batch=6, max_det=300,
+                          numerics="e2e_optimize")
+    try:
+        got0 = pipe.engine.detect_raw(imgs)
+        outs = pipe.run_batch(list(imgs), 0.25, 0.45, 50)
+        nbox, perr = 0, 0.0
+        for i in range(len(imgs)):
+            res, met = outs[i]
+            eb, es, ec = P.postprocess(got0[i], (640, 640), 1.0, (0.0, 0.0), 0.25, 0.45)
+            rects, valid = O.roi_rects(eb, 640, 640, 50)
+            assert met.num_detections == len(eb) and len(res) == len(valid)
+            if not len(valid):
+                continue
+            crops = [imgs[i][y1:y2, x1:x2] for x1, y1, x2, y2 in rects]
+            x = torch.from_numpy(O.normalize(O.preprocess_rois(crops, 64)))
+            with torch.no_grad():
+                probs = torch.softmax(model(x), 1).numpy()
+            for r, k, pr in zip(res, valid, probs):
+                assert r["bbox"] == tuple(eb[k].astype(int)) and r["det_conf"] == float(es[k])
+                perr = max(perr, abs(r["cls_conf"] - float(pr[r["cls_class"]])))
+                top2 = np.sort(pr)[-2:]
+                assert r["cls_class"] == int(np.argmax(pr)) or top2[1] - top2[0] < 1e-3
+                nbox += 1
+        print(f"optimize numerics fp32 pipeline: {nbox} boxes, max prob err {perr:.2e}")
+        assert nbox >= 6 and perr <= 1e-3
+    finally:
+        pipe.engine.close()

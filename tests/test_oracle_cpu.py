@@ -187,3 +187,44 @@ def test_oracle_runs_reference_baseline_graphs(tmp_path):
         ran += 1
     if ran == 0:
         pytest.skip("reference graph files not staged")
+
+
+def test_cv2_linear_resize_restatement_properties():
+    """oracle.postprocess_ref.resize_linear_u8 (cv2.resize INTER_LINEAR, used by letterbox and by the e2e_optimize ROI stage).
+    PARITY UNPINNED (cv2 absent, no fixtures in the reference): pinned by properties and a hand-computed case only."""
+    from oracle import postprocess_ref as P
+    rng = np.random.default_rng(0)
+    const = np.full((37, 23, 3), 91, np.uint8)
+    assert (P.resize_linear_u8(const, 64, 64) == 91).all()
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    assert (P.resize_linear_u8(img, 64, 64) == img).all()          # all weights land on one source pixel
+    tiny = np.array([[0, 100], [200, 50]], np.uint8)[:, :, None].repeat(3, 2)
+    up = P.resize_linear_u8(tiny, 4, 4)[:, :, 0]
+    # half-pixel centres: destination columns sample at -0.25, 0.25, 0.75, 1.25 (clamped at the ends); 11-bit coefficients,
+    # ((b0*(h0>>4))>>16 + (b1*(h1>>4))>>16 + 2) >> 2 worked by hand for row 1
+    assert up[0].tolist() == [0, 25, 75, 100] and up[1].tolist() == [50, 59, 78, 88] and up[3].tolist() == [200, 163, 88, 50], up
+    big = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
+    down = P.resize_linear_u8(big, 64, 64)
+    assert down.shape == (64, 64, 3) and abs(float(down.mean()) - float(big.mean())) < 6.0
+
+
+def test_optimize_roi_rule_differs_from_e2e_where_the_reference_does():
+    """oracle.optimize_ref.roi_rects (e2e_optimize.py:480-497) against oracle.postprocess_ref.roi_rects (e2e.py:465-473)."""
+    from oracle import optimize_ref as O, postprocess_ref as P
+    h, w = 100, 200
+    boxes = np.array([[10.9, 20.2, 60.7, 80.9],      # interior: same rectangle under both rules
+                      [199.6, 10.0, 200.0, 90.0],    # x1 truncates to 199, x2 = 200: both keep a 1-px column
+                      [200.0, 10.0, 200.0, 90.0],    # degenerate at the right edge: e2e.py makes it [199, 200), optimize drops it
+                      [-5.5, -3.2, 30.0, 40.0],      # negative corner: truncation toward zero, then clip
+                      [50.0, 99.5, 120.0, 100.0]],   # one-row strip at the bottom
+                     np.float32)
+    r0, v0 = P.roi_rects(boxes, h, w, 50)
+    r1, v1 = O.roi_rects(boxes, h, w, 50)
+    assert v0 == [0, 1, 2, 3, 4] and v1 == [0, 1, 3, 4]
+    assert r1.tolist() == [[10, 20, 60, 80], [199, 10, 200, 90], [0, 0, 30, 40], [50, 99, 120, 100]]
+    assert [list(map(int, r)) for r in r0][2] == [199, 10, 200, 90]
+    assert O.roi_rects(np.zeros((0, 4), np.float32), h, w)[1] == []
+    crops = O.preprocess_rois([np.zeros((5, 7, 3), np.uint8) + 200, np.arange(64 * 64 * 3, dtype=np.uint8).reshape(64, 64, 3)])
+    assert crops.shape == (2, 64, 64, 3) and (crops[0] == 200).all() and (crops[1] == np.arange(64 * 64 * 3, dtype=np.uint8).reshape(64, 64, 3)[:, :, ::-1]).all()
+    x = O.normalize(crops)
+    assert x.shape == (2, 3, 64, 64) and abs(float(x[0].max()) - (200 / 255 - 0.18) / 0.34) < 1e-6

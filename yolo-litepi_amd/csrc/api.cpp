@@ -201,6 +201,8 @@ int lp_create(const lp_config* cfg, lp_handle** out) {
   LP_CHECK(cfg && out, LP_ERR_ARG, "null argument");
   LP_CHECK(cfg->max_batch >= 1 && cfg->max_batch <= 1024 && cfg->max_det >= 1 && cfg->det_input % 32 == 0 && cfg->det_input >= 64,
            LP_ERR_ARG, "bad config (max_batch %d, max_det %d, det_input %d)", cfg->max_batch, cfg->max_det, cfg->det_input);
+  LP_CHECK((cfg->numerics == 0 || cfg->numerics == 1) && (cfg->cls_arch == 0 || cfg->cls_arch == 1), LP_ERR_ARG,
+           "bad config (numerics %d, cls_arch %d)", cfg->numerics, cfg->cls_arch);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device)
     throw Error(LP_ERR_NODEVICE, fmt("HIP device %d not available (%d visible): liblitepi_hip has no CPU path", cfg->device, ndev));
@@ -365,6 +367,7 @@ void enqueue_nms(lp_handle* h, int B, float iou, int min_area, lp_det* dets, int
   a.A = h->det->num_anchors(); a.max_det = h->cfg.max_det; a.nc = h->det->num_classes(); a.iou = iou; a.min_area = min_area;
   if (with_rois) a.tab = h->roi_table();
   a.max_rois = h->max_rois;
+  a.roi_rule = h->cfg.numerics;
   if (prof) prof->begin(h->stream);
   launch_nms(a, B, h->stream);
   if (prof) prof->end(h->stream, "nms", "nms", 0.0, 0.0);
@@ -375,7 +378,7 @@ void enqueue_classify(lp_handle* h, const uint8_t* src, int B, lp_det* dets, flo
   RoiTable tab = h->roi_table();
   RoiResizeArgs r;
   r.src = src; r.geom = h->d_geom.as<ImgGeom>(); r.rects = h->d_rects.as<int>(); r.tab = tab;
-  r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = h->cfg.max_det; r.S = h->cfg.cls_input;
+  r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = h->cfg.max_det; r.S = h->cfg.cls_input; r.linear = h->cfg.numerics;
   if (prof) prof->begin(h->stream);
   launch_roi_resize(r, std::min(h->max_rois, B * h->cfg.max_det), h->stream);
   if (prof) prof->end(h->stream, "roi_resize_pil", "roi_resize", 0.0, (double)r.S * r.S * 3 * 2, true);
@@ -621,7 +624,7 @@ int lp_classify(lp_handle* h, const uint8_t* const* rois, const int* hs, const i
   RoiTable tab = h->roi_table();
   RoiResizeArgs r;
   r.src = h->d_src.as<uint8_t>(); r.geom = h->d_geom.as<ImgGeom>(); r.rects = d_rects_tmp.as<int>(); r.tab = tab;
-  r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = 1; r.S = h->cfg.cls_input;
+  r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = 1; r.S = h->cfg.cls_input; r.linear = h->cfg.numerics;
   launch_roi_resize(r, R, h->stream);
   Classifier::Post post;
   post.probs = h->d_probs.as<float>(); post.ids = h->d_ids.as<int>();
@@ -747,7 +750,7 @@ int lp_test_postprocess(lp_handle* h, const float* out0, int nc, int A, int orig
   memset(&a, 0, sizeof(a));
   a.cand = d_cand.as<Cand>(); a.cand_count = d_cnt.as<int>(); a.sorted = d_sorted.as<Cand>(); a.dets = d_dets.as<lp_det>();
   a.counts = d_counts.as<int>(); a.rects = d_rects.as<int>(); a.geom = d_geom.as<ImgGeom>(); a.A = A; a.max_det = max_det; a.nc = nc;
-  a.iou = iou; a.min_area = min_area;
+  a.iou = iou; a.min_area = min_area; a.roi_rule = h->cfg.numerics;
   launch_nms(a, 1, h->stream);
   LP_HIP(hipStreamSynchronize(h->stream));
   int cnt[3];
@@ -789,7 +792,7 @@ int lp_test_nms_boxes(lp_handle* h, const float* boxes, const float* scores, con
   memset(&a, 0, sizeof(a));
   a.cand = d_cand.as<Cand>(); a.cand_count = d_cnt.as<int>(); a.sorted = d_sorted.as<Cand>(); a.dets = d_dets.as<lp_det>();
   a.counts = d_counts.as<int>(); a.rects = d_rects.as<int>(); a.geom = d_geom.as<ImgGeom>(); a.A = A; a.max_det = max_det; a.nc = nc;
-  a.iou = iou; a.min_area = min_area;
+  a.iou = iou; a.min_area = min_area; a.roi_rule = h->cfg.numerics;
   launch_nms(a, 1, h->stream);
   LP_HIP(hipStreamSynchronize(h->stream));
   int cnt[3];
@@ -831,7 +834,7 @@ int lp_test_roi_resize(lp_handle* h, const uint8_t* const* rois, const int* hs, 
   RoiResizeArgs r;
   r.src = d_src.as<uint8_t>(); r.geom = d_geom.as<ImgGeom>(); r.rects = d_rects.as<int>();
   r.tab.base = d_base.as<int>(); r.tab.total = d_total.as<int>(); r.tab.img = d_img.as<int>(); r.tab.slot = d_slot.as<int>();
-  r.out = d_out.as<uint8_t>(); r.max_det = 1; r.S = S;
+  r.out = d_out.as<uint8_t>(); r.max_det = 1; r.S = S; r.linear = h->cfg.numerics;
   launch_roi_resize(r, R, h->stream);
   LP_HIP(hipStreamSynchronize(h->stream));
   LP_HIP(hipMemcpy(out_rgb, d_out.p, (size_t)R * S * S * 3, hipMemcpyDeviceToHost));

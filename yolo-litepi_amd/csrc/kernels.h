@@ -84,6 +84,7 @@ struct NmsArgs {
   int min_area;           // < 0: no ROI filter (lp_detect semantics)
   RoiTable tab;           // tab.total == nullptr: no ROI list
   int max_rois;
+  int roi_rule;           // 0: e2e.py:465-473, 1: e2e_optimize.py:480-497 (lp_config::numerics)
 };
 // per-class greedy NMS (e2e.py:89-119,280-296) + ROI clip / area filter (e2e.py:465-473) + the batch's ROI list
 void launch_nms(const NmsArgs& a, int N, hipStream_t st);
@@ -98,6 +99,7 @@ struct RoiResizeArgs {
   RoiTable tab;
   uint8_t* out;             // [max_rois,S,S,3]
   int max_det, S;
+  int linear;               // 0: PIL bilinear with antialias (e2e.py:366-370, 387), 1: cv2.resize INTER_LINEAR (e2e_optimize.py:388-390)
 };
 void launch_roi_resize(const RoiResizeArgs& a, int max_items, hipStream_t st);
 size_t roi_resize_lds_bytes();

@@ -3,6 +3,7 @@
 // (pixel, 8-channel fp16 / 4-channel fp32 group).
 #include "common.h"
 #include "kernels.h"
+#include "post_dev.h"
 
 namespace lp {
 
@@ -22,19 +23,6 @@ template <> struct VecT<float> { typedef floatx4 type; static constexpr int G = 
 //   ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
 // cv2 is absent from the build container: only the identity and pad-only cases are pinned.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void lin_coeff(int d, int dst, int src, int& s0, int& a0, int& a1) {
-  const double inv_scale = (double)dst / (double)src;
-  const double scale = 1.0 / inv_scale;
-  float f = (float)((d + 0.5) * scale - 0.5);
-  int s = (int)floorf(f);
-  f -= (float)s;
-  if (s < 0) { f = 0.f; s = 0; }
-  if (s >= src - 1) { f = 0.f; s = src - 1; }
-  s0 = s;
-  a1 = __float2int_rn(f * 2048.f);
-  a0 = __float2int_rn((1.f - f) * 2048.f);
-}
-
 __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, const ImgGeom* __restrict__ geom,
                                                         uint8_t* __restrict__ dst, int S) {
   const int n = blockIdx.y;

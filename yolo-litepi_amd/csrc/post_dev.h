@@ -28,5 +28,22 @@ __device__ __forceinline__ void emit_candidate(float cx, float cy, float w, floa
   cand[slot] = c;
 }
 
+// ------------------------------------------------------------------------------------
+// One axis of cv2.resize(INTER_LINEAR) on uint8: source index and the 11-bit coefficient pair of destination index d
+// (OpenCV's published fixed-point algorithm: half-pixel centres, cvRound(f * 2048)).  Used by the letterbox kernel
+// (e2e.py:80) and by the ROI resize of the e2e_optimize numerics (e2e_optimize.py:388-390).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void lin_coeff(int d, int dst, int src, int& s0, int& a0, int& a1) {
+  const double inv_scale = (double)dst / (double)src;
+  const double scale = 1.0 / inv_scale;
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.f; s = 0; }
+  if (s >= src - 1) { f = 0.f; s = src - 1; }
+  s0 = s;
+  a1 = __float2int_rn(f * 2048.f);
+  a0 = __float2int_rn((1.f - f) * 2048.f);
+}
 
 }  // namespace lp

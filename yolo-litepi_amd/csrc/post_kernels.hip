@@ -196,6 +196,21 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave /*[17]*/,
   return r;
 }
 
+// ROI rectangle of a kept box (int truncation + clip) and the area filter.  rule 0 = HybridPipeline.run, e2e.py:465-473:
+// x1 in [0, w-1], y1 in [0, h-1], x2 in [x1+1, w], y2 in [y1+1, h]; rule 1 = HybridPipelineOptimized.run,
+// e2e_optimize.py:480-497: all four clipped to [0, w] / [0, h], empty rectangles dropped.  min_area < 0: no filter.
+__device__ __forceinline__ bool roi_rect(const Cand& c, const ImgGeom& gm, int rule, int min_area, int& x1, int& y1, int& x2, int& y2) {
+  x1 = (int)c.x1; y1 = (int)c.y1; x2 = (int)c.x2; y2 = (int)c.y2;
+  if (rule == 0) {
+    x1 = min(max(x1, 0), gm.w - 1); y1 = min(max(y1, 0), gm.h - 1);
+    x2 = min(max(x2, x1 + 1), gm.w); y2 = min(max(y2, y1 + 1), gm.h);
+  } else {
+    x1 = min(max(x1, 0), gm.w); x2 = min(max(x2, 0), gm.w);
+    y1 = min(max(y1, 0), gm.h); y2 = min(max(y2, 0), gm.h);
+  }
+  return min_area < 0 || (((x2 - x1) * (y2 - y1) >= min_area) && x2 > x1 && y2 > y1);
+}
+
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_wave[NMS_THREADS / 64 + 1];
@@ -333,14 +348,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
     const Cand c = sorted[keep[k]];
     if (by_key && nms_score_key(c) < T) continue;
     ssum += (double)c.score;
-    bool ok = true;
-    if (a.min_area >= 0) {
-      int x1 = (int)c.x1, y1 = (int)c.y1, x2 = (int)c.x2, y2 = (int)c.y2;
-      x1 = min(max(x1, 0), gm.w - 1); y1 = min(max(y1, 0), gm.h - 1);
-      x2 = min(max(x2, x1 + 1), gm.w); y2 = min(max(y2, y1 + 1), gm.h);
-      ok = ((x2 - x1) * (y2 - y1) >= a.min_area) && x2 > x1 && y2 > y1;
-    }
-    nvalid += ok ? 1 : 0;
+    int x1, y1, x2, y2;
+    nvalid += roi_rect(c, gm, a.roi_rule, a.min_area, x1, y1, x2, y2) ? 1 : 0;
   }
   int run;
   int o = block_exclusive_scan(nvalid, s_wave, &run);
@@ -380,11 +389,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   for (int k = k0; k < k1; ++k) {
     const Cand c = sorted[keep[k]];
     if (by_key && nms_score_key(c) < T) continue;
-    int x1 = (int)c.x1, y1 = (int)c.y1, x2 = (int)c.x2, y2 = (int)c.y2;
-    x1 = min(max(x1, 0), gm.w - 1); y1 = min(max(y1, 0), gm.h - 1);
-    x2 = min(max(x2, x1 + 1), gm.w); y2 = min(max(y2, y1 + 1), gm.h);
-    const bool ok = a.min_area < 0 || (((x2 - x1) * (y2 - y1) >= a.min_area) && x2 > x1 && y2 > y1);
-    if (!ok) continue;
+    int x1, y1, x2, y2;
+    if (!roi_rect(c, gm, a.roi_rule, a.min_area, x1, y1, x2, y2)) continue;
     lp_det d;
     d.x1 = c.x1; d.y1 = c.y1; d.x2 = c.x2; d.y2 = c.y2; d.det_conf = c.score; d.det_class = c.cls;
     d.cls_class = -1; d.cls_conf = 0.f;
@@ -604,6 +610,55 @@ __device__ __forceinline__ void roi_resize_one(const RoiResizeArgs& a, int r, ch
   }
 }
 
+// cv2.resize(roi_rgb, (S, S), interpolation=cv2.INTER_LINEAR) (e2e_optimize.py:386-390): no antialiasing, two source rows
+// and columns per output pixel whatever the ROI's size; BGR -> RGB on the way.  The 2 x S coefficient triples go through
+// LDS, the pixels are gathered from global memory (4 taps x 3 bytes per output pixel).
+__device__ __forceinline__ void roi_resize_linear(const RoiResizeArgs& a, int r, char* smem) {
+  const int S = a.S;
+  int* cx = reinterpret_cast<int*>(smem);   // [S][3]: source index, a0, a1
+  int* cy = cx + 3 * 64;
+  const int tid = threadIdx.x;
+  const int img = a.tab.img[r], slot = a.tab.slot[r];
+  const ImgGeom gm = a.geom[img];
+  const int* rc = a.rects + ((long)img * a.max_det + slot) * 4;
+  const int rx = rc[0], ry = rc[1];
+  const int in_w = rc[2] - rx, in_h = rc[3] - ry;
+  const uint8_t* src = a.src + gm.src_off;
+  uint8_t* out = a.out + (long)r * S * S * 3;
+  __syncthreads();
+  if (tid < 2 * S) {
+    const int axis = tid >= S, d = tid - axis * S;
+    int s0, a0, a1;
+    lin_coeff(d, S, axis ? in_h : in_w, s0, a0, a1);
+    int* c = (axis ? cy : cx) + 3 * d;
+    c[0] = s0; c[1] = a0; c[2] = a1;
+  }
+  __syncthreads();
+  for (int i = tid; i < S * S; i += RR_THREADS) {
+    const int oy = i / S, ox = i - oy * S;
+    const int sx = cx[3 * ox], ax0 = cx[3 * ox + 1], ax1 = cx[3 * ox + 2];
+    const int sy = cy[3 * oy], ay0 = cy[3 * oy + 1], ay1 = cy[3 * oy + 2];
+    const int sx1 = sx + 1 < in_w ? sx + 1 : in_w - 1;
+    const int sy1 = sy + 1 < in_h ? sy + 1 : in_h - 1;
+    const uint8_t* r0 = src + ((long)(ry + sy) * gm.w + rx) * 3;
+    const uint8_t* r1 = src + ((long)(ry + sy1) * gm.w + rx) * 3;
+    uint8_t* o = out + i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int v;
+      if (in_w == S && in_h == S) {
+        v = r0[sx * 3 + c];   // cv2.resize returns a copy when the size already matches
+      } else {
+        const int h0 = r0[sx * 3 + c] * ax0 + r0[sx1 * 3 + c] * ax1;
+        const int h1 = r1[sx * 3 + c] * ax0 + r1[sx1 * 3 + c] * ax1;
+        v = (((ay0 * (h0 >> 4)) >> 16) + ((ay1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      }
+      o[2 - c] = (uint8_t)v;   // BGR -> RGB
+    }
+  }
+}
+
 // One launch for every ROI of the batch: a workgroup takes ROIs round-robin and picks the variant by the ROI's size
 // (three launches, two of them usually empty, cost more than the resampling of a typical batch).
 __global__ __launch_bounds__(RR_THREADS) void roi_resize_kernel(const RoiResizeArgs a) {
@@ -613,7 +668,8 @@ __global__ __launch_bounds__(RR_THREADS) void roi_resize_kernel(const RoiResizeA
     const int img = a.tab.img[r], slot = a.tab.slot[r];
     const int* rc = a.rects + ((long)img * a.max_det + slot) * 4;
     const int mode = rr_mode(rc[2] - rc[0], rc[3] - rc[1]);
-    if (mode == RR_MODE_TINY) roi_resize_one<RR_SMALL_K, RR_MODE_TINY>(a, r, smem);
+    if (a.linear) roi_resize_linear(a, r, smem);
+    else if (mode == RR_MODE_TINY) roi_resize_one<RR_SMALL_K, RR_MODE_TINY>(a, r, smem);
     else if (mode == RR_MODE_SMALL) roi_resize_one<RR_SMALL_K, RR_MODE_SMALL>(a, r, smem);
     else roi_resize_one<RR_LARGE_K, RR_MODE_LARGE>(a, r, smem);
     __syncthreads();

@@ -19,7 +19,7 @@ LP_OK, LP_ERR_ARG, LP_ERR_IO, LP_ERR_GRAPH, LP_ERR_HIP, LP_ERR_STATE, LP_ERR_NOD
 class LpConfig(C.Structure):
     _fields_ = [("device", C.c_int), ("precision", C.c_int), ("max_batch", C.c_int), ("max_det", C.c_int),
                 ("num_classes", C.c_int), ("det_input", C.c_int), ("cls_input", C.c_int), ("max_rois", C.c_int),
-                ("conv_impl", C.c_int), ("reserved", C.c_int * 7)]
+                ("conv_impl", C.c_int), ("numerics", C.c_int), ("cls_arch", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class LpDet(C.Structure):

@@ -33,12 +33,18 @@ class Engine:
     """One GPU pipeline handle (not thread-safe; one per GPU)."""
 
     def __init__(self, precision: str = "fp16", max_batch: int = 1, max_det: int = 300, num_classes: int = 58,
-                 det_input: int = 640, cls_input: int = 64, device: int = 0, max_rois: int = 0, conv_impl: int = 0):
+                 det_input: int = 640, cls_input: int = 64, device: int = 0, max_rois: int = 0, conv_impl: int = 0,
+                 numerics: str = "e2e", cls_arch: str = "shufflenetv2"):
+        """numerics: "e2e" = HybridPipeline of e2e.py (default), "e2e_optimize" = HybridPipelineOptimized of e2e_optimize.py
+        (other ROI clip rule, cv2-linear ROI resize).  cls_arch: "shufflenetv2" | "resnet18" (e2e.py:320-333)."""
         self.lib = _ffi.load_library()
         cfg = LpConfig()
         self.lib.lp_default_config(C.byref(cfg))
         cfg.device, cfg.precision, cfg.max_batch, cfg.max_det = device, _PREC[precision], max_batch, max_det
         cfg.num_classes, cfg.det_input, cfg.cls_input, cfg.max_rois, cfg.conv_impl = num_classes, det_input, cls_input, max_rois, conv_impl
+        cfg.numerics = {"e2e": 0, "e2e_optimize": 1}[numerics]
+        cfg.cls_arch = {"shufflenetv2": 0, "resnet18": 1}[cls_arch]
+        self.numerics, self.cls_arch = numerics, cls_arch
         self.cfg = cfg
         self.precision = precision
         self._h = C.c_void_p()
@@ -411,12 +417,13 @@ class HybridPipeline:
     def __init__(self, detector_param: str, detector_bin: str, classifier_path: str, classifier_arch: str,
                  num_classes: int = 58, det_input_size: int = 640, cls_input_size: int = 64, use_gpu_detector: bool = False,
                  detector_threads: int = 4, classifier_device: str = "cpu", batch_size: int = 8, *, precision: str = "fp16",
-                 max_batch: int = 1, max_det: int = 300, device: int = 0, max_rois: int = 0):
+                 max_batch: int = 1, max_det: int = 300, device: int = 0, max_rois: int = 0, numerics: str = "e2e"):
         print("\n" + "=" * 70)
         print("HYBRID PIPELINE: HIP Detector + HIP Classifier (MI355X)")
         print("=" * 70)
         self.engine = Engine(precision=precision, max_batch=max_batch, max_det=max_det, num_classes=num_classes,
-                             det_input=det_input_size, cls_input=cls_input_size, device=device, max_rois=max_rois)
+                             det_input=det_input_size, cls_input=cls_input_size, device=device, max_rois=max_rois,
+                             numerics=numerics, cls_arch=classifier_arch if classifier_arch in ("shufflenetv2", "resnet18") else "shufflenetv2")
         self.detector = NCNNDetector(detector_param, detector_bin, det_input_size, use_gpu_detector, detector_threads,
                                      _engine=self.engine)
         self.classifier = PyTorchClassifier(classifier_path, classifier_arch, num_classes, cls_input_size, classifier_device,

@@ -53,6 +53,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="detections kept per image; 0 = one slot per anchor, i.e. nothing is ever dropped (what the reference does: "
                         "e2e.py:280-296 keeps every NMS survivor, and the evaluation pass at --yolo_conf 0.001 produces thousands)")
     p.add_argument("--max_rois", type=int, default=0, help="classifier capacity per call; 0 = batch_images x max_det")
+    p.add_argument("--numerics", type=str, choices=["e2e", "e2e_optimize"], default="e2e",
+                   help="which reference pipeline's ROI stage to follow: e2e.py (PIL antialiased resize) or e2e_optimize.py "
+                        "(cv2-linear resize, its own clip rule)")
     return p
 
 
@@ -225,7 +228,7 @@ def run_evaluation(args) -> Dict:
     pipeline = HybridPipeline(args.detector_param, args.detector_bin, args.classifier, args.clf_arch, num_classes,
                               args.det_input_size, args.cls_input_size, False, args.detector_threads, args.device,
                               args.batch_size, precision=args.precision, max_batch=nb, max_det=max_det,
-                              device=args.hip_device, max_rois=args.max_rois)
+                              device=args.hip_device, max_rois=args.max_rois, numerics=args.numerics)
     out_dir = Path(args.output) / combo
     out_dir.mkdir(parents=True, exist_ok=True)
 
