@@ -1018,3 +1018,72 @@ def test_optimize_numerics_pipeline(tmp_path):
         assert nbox >= 6 and perr <= 1e-3
     finally:
         pipe.engine.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ResNet18 classifier (--clf_arch resnet18, e2e.py:320-323).  PARITY UNPINNED by the reference (no weights or outputs for it;
+# torchvision absent): the checker is oracle/resnet_ref.py on seeded synthetic weights.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_resnet18_classifier_matches_oracle(tmp_path, precision):
+    from litepi import PyTorchClassifier
+    from oracle import resnet_ref as R
+    ncls = 58
+    sd = R.seeded_state_dict(ncls)
+    path = str(tmp_path / "resnet18.pth")
+    torch.save(sd, path)
+    model = R.build(ncls, sd)
+    rng = np.random.default_rng(8)
+    rois = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in
+            ((64, 64), (31, 47), (12, 9), (90, 120), (200, 150), (64, 33), (17, 17), (75, 64), (40, 40), (128, 96), (55, 21))]
+    clf = PyTorchClassifier(path, "resnet18", ncls, precision=precision, max_rois=64)
+    try:
+        ids, probs = clf.predict_batch(rois)
+        assert clf.weights_loaded
+    finally:
+        clf.engine.close()
+    eids, eprobs = R.predict_batch(model, rois)
+    err = float(np.abs(probs - eprobs).max())
+    print(f"resnet18 {precision}: max prob err {err:.2e}")
+    tol = 1e-4 if precision == "fp32" else 3e-2
+    assert probs.shape == eprobs.shape and err <= tol
+    for i in range(len(rois)):
+        top2 = np.sort(eprobs[i])[-2:]
+        assert ids[i] == eids[i] or top2[1] - top2[0] < 2 * tol
+
+
+def test_resnet18_pipeline_end_to_end(tmp_path):
+    """HybridPipeline(classifier_arch='resnet18'), fp32: decisions exact on the device's own out0, classifier evaluated by the
+    oracle on the crops of the same rectangles."""
+    from litepi import HybridPipeline, ncnn_export
+    from oracle import postprocess_ref as P, resnet_ref as R
+    p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    ncnn_export.export_detector(p, b, "v1", seed=1234, cls_bias=0.0)
+    imgs = np.random.default_rng(4).integers(0, 256, (4, 640, 640, 3), dtype=np.uint8)
+    _calibrate(p, b, imgs, 10)
+    sd = R.seeded_state_dict(20)
+    cls_path = str(tmp_path / "r18.pth")
+    torch.save(sd, cls_path)
+    model = R.build(20, sd)
+    pipe = HybridPipeline(p, b, cls_path, "resnet18", num_classes=20, precision="fp32", max_batch=4, max_det=300)
+    try:
+        got0 = pipe.engine.detect_raw(imgs)
+        outs = pipe.run_batch(list(imgs), 0.25, 0.45, 50)
+        nbox, perr = 0, 0.0
+        for i in range(len(imgs)):
+            res, met = outs[i]
+            eb, es, ec = P.postprocess(got0[i], (640, 640), 1.0, (0.0, 0.0), 0.25, 0.45)
+            rects, valid = P.roi_rects(eb, 640, 640, 50)
+            assert met.num_detections == len(eb) and len(res) == len(valid)
+            if not len(valid):
+                continue
+            ids, probs = R.predict_batch(model, [imgs[i][y1:y2, x1:x2] for x1, y1, x2, y2 in rects])
+            for r, pr in zip(res, probs):
+                perr = max(perr, abs(r["cls_conf"] - float(pr[r["cls_class"]])))
+                top2 = np.sort(pr)[-2:]
+                assert r["cls_class"] == int(np.argmax(pr)) or top2[1] - top2[0] < 1e-3
+                nbox += 1
+        print(f"resnet18 fp32 pipeline: {nbox} boxes, max prob err {perr:.2e}")
+        assert nbox >= 4 and perr <= 1e-3
+    finally:
+        pipe.engine.close()

@@ -228,3 +228,26 @@ def test_optimize_roi_rule_differs_from_e2e_where_the_reference_does():
     assert crops.shape == (2, 64, 64, 3) and (crops[0] == 200).all() and (crops[1] == np.arange(64 * 64 * 3, dtype=np.uint8).reshape(64, 64, 3)[:, :, ::-1]).all()
     x = O.normalize(crops)
     assert x.shape == (2, 3, 64, 64) and abs(float(x[0].max()) - (200 / 255 - 0.18) / 0.34) < 1e-6
+
+
+def test_resnet18_oracle_shapes_and_param_count():
+    """oracle.resnet_ref: torchvision resnet18 restated (e2e.py:320-323).  11 176 512 backbone parameters + 513 per class
+    (torchvision's published count for resnet18 is 11 689 512 at 1000 classes), torchvision's state_dict keys, 64x64 input."""
+    import torch
+    from oracle import resnet_ref as R
+    m = R.build(58, R.seeded_state_dict(58))
+    n = sum(p.numel() for p in m.parameters())
+    assert n == 11_176_512 + 513 * 58
+    assert sum(p.numel() for p in R.ResNet18(1000).parameters()) == 11_689_512
+    keys = set(m.state_dict().keys())
+    for k in ("conv1.weight", "bn1.running_var", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight", "layer2.0.downsample.1.running_mean",
+              "layer4.1.bn2.bias", "fc.weight", "fc.bias"):
+        assert k in keys, k
+    assert "layer1.0.downsample.0.weight" not in keys
+    x = torch.randn(3, 3, 64, 64)
+    with torch.no_grad():
+        y = m(x)
+        f = m.layer4(m.layer3(m.layer2(m.layer1(m.maxpool(m.relu(m.bn1(m.conv1(x))))))))
+    assert y.shape == (3, 58) and f.shape == (3, 512, 2, 2) and torch.isfinite(y).all()
+    ids, probs = R.predict_batch(m, [np.random.default_rng(0).integers(0, 256, (40, 30, 3), dtype=np.uint8)])
+    assert probs.shape == (1, 58) and abs(float(probs.sum()) - 1.0) < 1e-5

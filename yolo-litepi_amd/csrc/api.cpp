@@ -8,6 +8,7 @@
 #include <set>
 
 #include "classifier.h"
+#include "resnet.h"
 #include "common.h"
 #include "detector.h"
 #include "kernels.h"
@@ -106,7 +107,7 @@ struct lp_handle {
   lp_config cfg;
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::unique_ptr<Detector> det;
-  std::unique_ptr<Classifier> cls;
+  std::unique_ptr<ClassifierBase> cls;
   Profiler prof;
   bool prof_next = false;
   int max_rois = 0;
@@ -270,7 +271,9 @@ int lp_load_classifier_tensors(lp_handle* h, int n, const char* const* names, co
     t.shape.assign(shapes[i], shapes[i] + ndims[i]);
     sd[names[i]] = t;
   }
-  std::unique_ptr<Classifier> c(new Classifier(h->cfg.precision, h->cfg.conv_impl, h->max_rois, h->cfg.num_classes, h->cfg.cls_input));
+  std::unique_ptr<ClassifierBase> c;
+  if (h->cfg.cls_arch == LP_CLS_RESNET18) c.reset(new ResNet18Classifier(h->cfg.precision, h->cfg.conv_impl, h->max_rois, h->cfg.num_classes, h->cfg.cls_input));
+  else c.reset(new Classifier(h->cfg.precision, h->cfg.conv_impl, h->max_rois, h->cfg.num_classes, h->cfg.cls_input));
   c->load(sd);
   h->drop_graphs();
   h->cls = std::move(c);
@@ -382,7 +385,7 @@ void enqueue_classify(lp_handle* h, const uint8_t* src, int B, lp_det* dets, flo
   if (prof) prof->begin(h->stream);
   launch_roi_resize(r, std::min(h->max_rois, B * h->cfg.max_det), h->stream);
   if (prof) prof->end(h->stream, "roi_resize_pil", "roi_resize", 0.0, (double)r.S * r.S * 3 * 2, true);
-  Classifier::Post post;
+  ClsPost post;
   post.probs = probs; post.ids = ids; post.dets = dets; post.max_det = h->cfg.max_det; post.roi_img = tab.img; post.roi_slot = tab.slot;
   h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof, &post);
   if (!h->cls->fused_head()) {
@@ -626,7 +629,7 @@ int lp_classify(lp_handle* h, const uint8_t* const* rois, const int* hs, const i
   r.src = h->d_src.as<uint8_t>(); r.geom = h->d_geom.as<ImgGeom>(); r.rects = d_rects_tmp.as<int>(); r.tab = tab;
   r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = 1; r.S = h->cfg.cls_input; r.linear = h->cfg.numerics;
   launch_roi_resize(r, R, h->stream);
-  Classifier::Post post;
+  ClsPost post;
   post.probs = h->d_probs.as<float>(); post.ids = h->d_ids.as<int>();
   h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof, &post);
   if (!h->cls->fused_head())

@@ -16,21 +16,37 @@ struct NamedTensor {
   size_t numel() const { size_t n = 1; for (auto d : shape) n *= (size_t)d; return n; }
 };
 
-class Classifier {
+// where a classifier that finishes with softmax / arg-max itself (fused head) puts the results
+struct ClsPost { float* probs = nullptr; int* ids = nullptr; lp_det* dets = nullptr; int max_det = 0; const int* roi_img = nullptr; const int* roi_slot = nullptr; };
+
+// What the pipeline needs from a classifier architecture (build_classifier(arch, ..), e2e.py:320-333)
+class ClassifierBase {
+ public:
+  typedef ClsPost Post;
+  virtual ~ClassifierBase() {}
+  virtual void load(const std::map<std::string, NamedTensor>& sd) = 0;   // torchvision state_dict of the architecture
+  virtual bool loaded() const = 0;
+  virtual int num_classes() const = 0;
+  virtual int logits_pitch() const = 0;
+  virtual const float* logits() const = 0;
+  // rgb: device uint8 [R,S,S,3]; d_R: device ROI count.  Leaves fp32 logits [R, logits_pitch()].
+  // With a fused head softmax/arg-max/scatter happen inside forward(); post describes where the results go.
+  // fused_head() tells the caller whether it still has to run softmax itself.
+  virtual bool fused_head() const = 0;
+  virtual void forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Profiler* prof, const Post* post = nullptr) = 0;
+};
+
+class Classifier : public ClassifierBase {
  public:
   Classifier(int prec, int impl, int max_rois, int num_classes, int input_size);
   // torchvision shufflenet_v2_x1_0 state_dict (fc replaced by Linear(1024, num_classes))
-  void load(const std::map<std::string, NamedTensor>& sd);
-  bool loaded() const { return loaded_; }
-  int num_classes() const { return ncls_; }
-  int logits_pitch() const { return lpitch_; }
-  const float* logits() const { return d_logits_.as<float>(); }
-  // rgb: device uint8 [R,S,S,3]; d_R: device ROI count.  Leaves fp32 logits [R, logits_pitch()].
-  // With the fused head (fp16) softmax/arg-max/scatter happen inside forward(); post describes where
-  // the results go.  fused_head() tells the caller whether it still has to run softmax itself.
-  struct Post { float* probs = nullptr; int* ids = nullptr; lp_det* dets = nullptr; int max_det = 0; const int* roi_img = nullptr; const int* roi_slot = nullptr; };
-  bool fused_head() const { return use_fused_; }
-  void forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Profiler* prof, const Post* post = nullptr);
+  void load(const std::map<std::string, NamedTensor>& sd) override;
+  bool loaded() const override { return loaded_; }
+  int num_classes() const override { return ncls_; }
+  int logits_pitch() const override { return lpitch_; }
+  const float* logits() const override { return d_logits_.as<float>(); }
+  bool fused_head() const override { return use_fused_; }
+  void forward(const uint8_t* rgb, const int* d_R, hipStream_t st, Profiler* prof, const Post* post = nullptr) override;
 
  private:
   struct DwLayer { DevBuf w, b; int C = 0, stride = 1; std::string name; };

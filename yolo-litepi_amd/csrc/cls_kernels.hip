@@ -73,6 +73,77 @@ void launch_cls_stem(int prec, const uint8_t* rgb, const float* w, const float* 
 }
 
 // ------------------------------------------------------------------------------------
+// ResNet18 conv1: 7x7 stride 2 pad 3, 3 -> 64, + folded BN + ReLU, on t = (x/255 - 0.18)/0.34 (torchvision resnet.py;
+// e2e.py:320-323 build_classifier('resnet18'), transform e2e.py:366-370); zero padding applies to t.
+// One workgroup per (ROI, output row): the 7 input rows (normalised, fp32, padded by 3 columns) and the 147 x 64 weights
+// live in LDS; a thread owns one output pixel x 8 channels.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cls_stem7_kernel(const uint8_t* __restrict__ rgb, T* __restrict__ out,
+                                                        const float* __restrict__ w /*[147][64]*/, const float* __restrict__ bias,
+                                                        int S, int out_pitch, const int* __restrict__ m_dyn) {
+  extern __shared__ __attribute__((aligned(16))) char smem7[];
+  float* lw = reinterpret_cast<float*>(smem7);          // [147][64]
+  float* rows = lw + 147 * 64;                           // [7][(S + 6) * 3]
+  const int So = S / 2, RW = (S + 6) * 3;
+  const int R = *m_dyn;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 147 * 64; i += 256) lw[i] = w[i];
+  const int ox = tid >> 3, cg = tid & 7;   // 32 output pixels x 8 channel groups (S = 64)
+  float b8[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) b8[c] = bias[cg * 8 + c];
+  for (long item = blockIdx.x; item < (long)R * So; item += gridDim.x) {
+    const long r = item / So;
+    const int oy = (int)(item - r * So);
+    __syncthreads();
+    for (int i = tid; i < 7 * RW; i += 256) {
+      const int ky = i / RW, j = i - ky * RW;
+      const int ix = j / 3 - 3, c = j - (j / 3) * 3;
+      const int iy = oy * 2 - 3 + ky;
+      float t = 0.f;
+      if (iy >= 0 && iy < S && ix >= 0 && ix < S)
+        t = __fdiv_rn(__fsub_rn(__fdiv_rn((float)rgb[((r * S + iy) * S + ix) * 3 + c], 255.f), 0.18f), 0.34f);
+      rows[i] = t;
+    }
+    __syncthreads();
+    if (ox < So) {
+      float acc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+      for (int ky = 0; ky < 7; ++ky) {
+        const float* rp = rows + ky * RW + ox * 2 * 3;   // window columns ox*2 - 3 .. ox*2 + 3 -> padded index ox*2 ..
+        const float* wp = lw + (ky * 21) * 64 + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 21; ++j) {
+          const float t = rp[j];
+          const floatx4 w0 = *reinterpret_cast<const floatx4*>(wp + j * 64);
+          const floatx4 w1 = *reinterpret_cast<const floatx4*>(wp + j * 64 + 4);
+          acc[0] = fmaf(t, w0[0], acc[0]); acc[1] = fmaf(t, w0[1], acc[1]); acc[2] = fmaf(t, w0[2], acc[2]); acc[3] = fmaf(t, w0[3], acc[3]);
+          acc[4] = fmaf(t, w1[0], acc[4]); acc[5] = fmaf(t, w1[1], acc[5]); acc[6] = fmaf(t, w1[2], acc[6]); acc[7] = fmaf(t, w1[3], acc[7]);
+        }
+      }
+      T* o = out + ((r * So + oy) * So + ox) * out_pitch + cg * 8;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = (T)fmaxf(acc[c] + b8[c], 0.f);
+    }
+  }
+}
+
+void launch_cls_stem7(int prec, const uint8_t* rgb, const float* w, const float* bias, const View& out, int S, const int* m_dyn,
+                      int max_items, hipStream_t st) {
+  LP_CHECK(S == 64 && out.C >= 64, LP_ERR_STATE, "ResNet stem: 64x64 input, 64 output channels");
+  const size_t lds = (size_t)147 * 64 * 4 + (size_t)7 * (S + 6) * 3 * 4;
+  long items = (long)max_items * (S / 2);
+  dim3 grid((unsigned)(items < 1 ? 1 : (items > 4096 ? 4096 : items)));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(cls_stem7_kernel<half_t>, grid, dim3(256), lds, st, rgb, (half_t*)out.base, w, bias, S, out.pitch, m_dyn);
+  else
+    hipLaunchKernelGGL(cls_stem7_kernel<float>, grid, dim3(256), lds, st, rgb, (float*)out.base, w, bias, S, out.pitch, m_dyn);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int CG,
                                                            int in_pitch, int out_pitch, const int* __restrict__ m_dyn) {

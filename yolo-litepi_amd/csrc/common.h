@@ -120,6 +120,7 @@ struct ConvArgs {
   int up_pitch, up_cg;
   int tile_major;              // 0: grid = (image, tile, split) (XCD-aware, default); 1: (tile, image, split)
   unsigned rcp_tx, rcp_cg, rcp_ps, rcp_pcs;  // 3x3 kernel: 16-bit reciprocals of tiles_x, CGc, PS/16, pieces per tile row
+  int res_first;               // 1: out = act(conv + bias + res) (ResNet BasicBlock); 0: out = act(conv + bias) + res (C2f shortcut)
   unsigned magic_hw, magic_w;  // floor(2^32 / pix_per_item), floor(2^32 / Wout): flat pixel index -> (image, row, column) (fast_div)
   const void* zeros;           // >= 16 zero bytes (source of the 3x3 kernel's padding slots)
   unsigned long long* stamps;  // diagnostic only (lp_test_conv + LITEPI_STAMPS): 16 clock stamps per workgroup

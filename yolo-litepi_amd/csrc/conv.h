@@ -11,6 +11,7 @@ struct ConvIO {
   const int* m_dyn = nullptr;  // device scalar item count (classifier); M = *m_dyn * out.H * out.W
   int half_c = 0, half_cp = 0; // shuffle epilogue geometry (x1.base != nullptr)
   int out_f32 = 0;
+  int res_first = 0;           // residual added BEFORE the activation (ResNet) instead of after it (C2f)
   unsigned long long* stamps = nullptr;  // diagnostic (see ConvArgs::stamps)
 };
 

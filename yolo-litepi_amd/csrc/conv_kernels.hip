@@ -177,19 +177,36 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0,
 // registers (hoisted out of the epilogue: 20 dependent global loads per lane otherwise), fp16
 // results leave as 16-byte stores (two channel quads at a time).
 template <typename T, int NT, int ACT>
-__device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int Cout, const floatx4 (&v)[NT], const floatx4 (&bias)[NT]);
+__device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int Cout, const floatx4 (&v)[NT], const floatx4 (&bias)[NT],
+                                              bool res_first = false);
 
 template <typename T, int NT, int ACT>
 __device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chbase, const floatx4 (&v)[NT],
                                            const floatx4 (&bias)[NT]) {
   T* o = reinterpret_cast<T*>(a.out) + eoff(pix, a.out_pitch) + chbase;
   const T* r = a.res ? reinterpret_cast<const T*>(a.res) + eoff(pix, a.res_pitch) + chbase : nullptr;
-  store_lane_at<T, NT, ACT>(o, r, chbase, a.Cout, v, bias);
+  store_lane_at<T, NT, ACT>(o, r, chbase, a.Cout, v, bias, a.res_first != 0);
 }
 
 // o / r already point at this lane's first channel of the pixel
 template <typename T, int NT, int ACT>
-__device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int Cout, const floatx4 (&v)[NT], const floatx4 (&bias)[NT]) {
+__device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int Cout, const floatx4 (&v)[NT], const floatx4 (&bias)[NT],
+                                              bool res_first) {
+  if (res_first && r) {
+    // ResNet BasicBlock: out = act(conv + bias + identity) (torchvision resnet.py BasicBlock.forward), the sum in fp32
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (chbase + t * 4 < Cout) {
+        const typename Tr<T>::quad rr = *reinterpret_cast<const typename Tr<T>::quad*>(r + t * 4);
+        const floatx4 y = act4<T, ACT>(v[t] + floatx4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]}, bias[t]);
+        typename Tr<T>::quad q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = (T)y[i];
+        *reinterpret_cast<typename Tr<T>::quad*>(o + t * 4) = q;
+      }
+    }
+    return;
+  }
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int t = 0; t + 1 < NT; t += 2) {
@@ -315,7 +332,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const floatx4 (
       floatx4 v[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) v[t] = acc[t][p];
-      store_lane_at<T, NT, ACT>(o + p * ostep, r ? r + p * rstep : nullptr, chbase, a.Cout, v, bias);
+      store_lane_at<T, NT, ACT>(o + p * ostep, r ? r + p * rstep : nullptr, chbase, a.Cout, v, bias, a.res_first != 0);
     }
   }
 }
@@ -375,6 +392,7 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
   const int tile_id = a.tile_major ? blockIdx.x : blockIdx.y;
   const int ty = (int)((tile_id * a.rcp_tx) >> 16), tx = tile_id - ty * a.tiles_x;
   const int n = a.tile_major ? blockIdx.y : blockIdx.x, ns = blockIdx.z;
+  if (a.m_dyn && n >= *a.m_dyn) return;   // classifier layers: the grid is sized for the ROI capacity (block-uniform exit)
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
   const int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
@@ -929,7 +947,7 @@ __global__ __launch_bounds__(256) void conv3x3s2_direct_kernel(const ConvArgs a)
   const int ns = blockIdx.y;
   const int S = a.steps;
   const int CG = a.Cin / G;
-  const long M = (long)a.M;
+  const long M = a.m_dyn ? (long)(*a.m_dyn) * a.pix_per_item : (long)a.M;
   const long ntiles = (M + 64 * NP - 1) / (64 * NP);
   if ((long)blockIdx.x >= ntiles) return;
 
@@ -1763,7 +1781,8 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
            "conv %s: a tensor of batch %d exceeds 2^31 elements", name.c_str(), io.N);
   a.CK = CK; a.nchunks = nchunks; a.steps_per_chunk = steps; a.CGc = CGc; a.LW = LW; a.PS = PS;
   a.bwh = bwh; a.bww = bww; a.steps = steps; a.nsplit_tiles = NT;
-  a.half_c = io.half_c; a.half_cp = io.half_cp; a.out_f32 = io.out_f32; a.stamps = io.stamps;
+  a.half_c = io.half_c; a.half_cp = io.half_cp; a.out_f32 = io.out_f32; a.stamps = io.stamps; a.res_first = io.res_first;
+  LP_CHECK(!io.res_first || (io.res.base && !io.x1.base && !io.out_f32 && T2 == 0), LP_ERR_STATE, "conv %s: residual-before-activation needs a plain epilogue", name.c_str());
   a.w2 = d_w2.p; a.bias2 = d_bias2.as<float>(); a.act2 = act2; a.Cout2 = Cout2;
   a.zeros = d_bias.as<float>() + round_up(Cout, 64);  // the bias buffer ends in 64 zero floats
   LP_CHECK(io.in.C + (io.up.base ? io.up.C : 0) == Cin, LP_ERR_STATE, "conv input view has %d channels, layer expects %d", io.in.C, Cin);
@@ -1789,7 +1808,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
   }
 
   if (direct) {
-    LP_CHECK(!io.m_dyn && !io.x1.base && !io.out_f32, LP_ERR_STATE, "conv3x3/s2: unsupported epilogue");
+    LP_CHECK(!io.x1.base && !io.out_f32, LP_ERR_STATE, "conv3x3/s2: unsupported epilogue");
     const long ntiles = ((long)a.M + 255) / 256;
     dim3 grid((unsigned)(ntiles < 4096 ? (ntiles > 0 ? ntiles : 1) : 4096), nsplits);
 #define LP_LD(TT)                                                                                      \
@@ -1819,7 +1838,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
     } else if (f16) { LP_LD(half_t) } else { LP_LD(float) }
 #undef LP_LD
   } else if (k == 3) {
-    LP_CHECK(!io.m_dyn && !io.x1.base && !io.out_f32, LP_ERR_STATE, "conv3x3: unsupported epilogue");
+    LP_CHECK(!io.x1.base && !io.out_f32, LP_ERR_STATE, "conv3x3: unsupported epilogue");
     const int TH = 4 * bwh, TW = 20 * bww;
     a.tiles_x = ceil_div(a.Wout, TW);
     a.tiles_y = ceil_div(a.Hout, TH);

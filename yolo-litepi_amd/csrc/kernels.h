@@ -108,6 +108,9 @@ size_t roi_resize_lds_bytes();
 // conv1 3x3/s2 (3->CO) + folded BN + ReLU on (x/255 - mean)/std of the uint8 RGB crops
 void launch_cls_stem(int prec, const uint8_t* rgb, const float* w /*[27][CO]*/, const float* bias, int CO,
                      const View& out, int S, const int* m_dyn, int max_items, hipStream_t st);
+// ResNet18 conv1 7x7/s2 (3 -> 64) + folded BN + ReLU on the normalised crops; w fp32 [147][64] in (ky, kx, rgb) order
+void launch_cls_stem7(int prec, const uint8_t* rgb, const float* w, const float* bias, const View& out, int S, const int* m_dyn,
+                      int max_items, hipStream_t st);
 void launch_maxpool3x3s2(int prec, const View& in, const View& out, const int* m_dyn, int max_items, hipStream_t st);
 // depthwise 3x3 pad 1 stride 1|2 + folded BN (no activation); w fp32 [9][C], bias fp32 [C]
 void launch_dwconv3x3(int prec, const View& in, const View& out, const float* w, const float* bias, int stride,

@@ -325,7 +325,7 @@ class NCNNDetector:
         return self.detect_batch([image], conf_threshold, iou_threshold)[0]
 
 
-def load_classifier_state(model_path: Optional[str], num_classes: int):
+def load_classifier_state(model_path: Optional[str], num_classes: int, arch: str = "shufflenetv2"):
     """torch is used only to READ the checkpoint (weights_only: nothing from the file is executed).
     Returns (state_dict, loaded_flag); a missing/unreadable file gives seeded random weights and a
     warning, like the reference's silent random-init fallback (e2e.py:337-343)."""
@@ -342,7 +342,7 @@ def load_classifier_state(model_path: Optional[str], num_classes: int):
             print(f"WARNING: could not load classifier weights ({e}); the classifier stays RANDOM-INIT")
     else:
         print(f"WARNING: classifier weights {model_path!r} not found; the classifier stays RANDOM-INIT")
-    return random_shufflenet_state(num_classes), False
+    return (random_resnet18_state(num_classes) if arch == "resnet18" else random_shufflenet_state(num_classes)), False
 
 
 def random_shufflenet_state(num_classes: int, seed: int = 0) -> Dict[str, np.ndarray]:
@@ -383,21 +383,55 @@ def random_shufflenet_state(num_classes: int, seed: int = 0) -> Dict[str, np.nda
     return sd
 
 
+def random_resnet18_state(num_classes: int, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded random resnet18 state_dict with torchvision's key names and shapes."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = (rng.standard_normal((co, ci, k, k)) * (1.4 / (ci * k * k)) ** 0.5).astype(np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = rng.uniform(0.75, 1.25, c).astype(np.float32)
+        sd[name + ".bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_mean"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_var"] = rng.uniform(0.75, 1.25, c).astype(np.float32)
+
+    conv("conv1", 64, 3, 7)
+    bn("bn1", 64)
+    cin = 64
+    for L, width in enumerate((64, 128, 256, 512)):
+        for r in range(2):
+            p = f"layer{L + 1}.{r}"
+            stride = 2 if (L > 0 and r == 0) else 1
+            conv(p + ".conv1", width, cin, 3); bn(p + ".bn1", width)
+            conv(p + ".conv2", width, width, 3); bn(p + ".bn2", width)
+            if stride != 1 or cin != width:
+                conv(p + ".downsample.0", width, cin, 1); bn(p + ".downsample.1", width)
+            cin = width
+    sd["fc.weight"] = (rng.standard_normal((num_classes, 512)) * (1.0 / 512) ** 0.5).astype(np.float32)
+    sd["fc.bias"] = (rng.standard_normal(num_classes) * 0.1).astype(np.float32)
+    return sd
+
+
 class PyTorchClassifier:
     """e2e.py:350-396 (name kept for drop-in use; the model runs in HIP, not torch)."""
 
     def __init__(self, model_path: str, arch: str, num_classes: int = 58, input_size: int = 64, device: str = "cpu", *,
                  precision: str = "fp16", max_rois: int = 1024, _engine: Optional[Engine] = None):
-        if arch != "shufflenetv2":
-            raise ValueError(f"Unknown architecture for the HIP backend: {arch} (only shufflenetv2 is accelerated)")
+        if arch not in ("shufflenetv2", "resnet18"):
+            raise ValueError(f"Unknown architecture for the HIP backend: {arch} (shufflenetv2 and resnet18 are accelerated; "
+                             "efficientnet / mobilenetv2 of e2e.py:324-329 are not)")
         self.input_size = input_size
         self.num_classes = num_classes
         self.arch = arch
         print(f"[HIP Classifier] Loading {arch} model...")
         print(f"  Model: {model_path}")
         self.engine = _engine or Engine(precision=precision, max_batch=1, max_det=max_rois, num_classes=num_classes,
-                                        cls_input=input_size, max_rois=max_rois)
-        sd, self.weights_loaded = load_classifier_state(model_path, num_classes)
+                                        cls_input=input_size, max_rois=max_rois, cls_arch=arch)
+        if self.engine.cls_arch != arch:
+            raise ValueError(f"the engine was created for {self.engine.cls_arch}, not {arch}")
+        sd, self.weights_loaded = load_classifier_state(model_path, num_classes, arch)
         self.engine.load_classifier(sd)
         print(f"  Architecture: {arch}")
         print(f"  Input size: {input_size}x{input_size}")

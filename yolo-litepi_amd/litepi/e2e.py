@@ -8,7 +8,7 @@ Ultralytics-style metric (e2e.py:656-824) and the same appended ``comparison_sum
 
 Differences, on purpose: images are decoded with Pillow (cv2 is not a dependency);
 ``--detector_threads`` and ``--device`` are accepted and ignored (everything runs on the GPU);
-only ``--clf_arch shufflenetv2`` is accelerated; ``--save_viz`` is accepted and ignored.
+``--clf_arch`` shufflenetv2 and resnet18 are accelerated (efficientnet / mobilenetv2 raise); ``--save_viz`` is accepted and ignored.
 """
 from __future__ import annotations
 
