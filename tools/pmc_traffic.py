@@ -30,7 +30,9 @@ def family(name):
     if "stem_mfma_kernel" in name or "stem_conv" in name:
         return "stem_conv_f16" if "stem_mfma" in name else "stem_conv" + f16
     for key, fam in (("stem_block_kernel", "stem_block_f16"), ("roi_resize_kernel", "roi_resize_pil"), ("shuffle_stage_kernel", "shuffle_stage_fused_f16"),
-                     ("cls_head_kernel", "cls_head_fused_f16"), ("nms_kernel", "nms"), ("roi_index_kernel", "roi_index")):
+                     ("cls_head_kernel", "cls_head_fused_f16"), ("nms_kernel", "nms"), ("roi_index_kernel", "roi_index"),
+                     ("head_fused_kernel", "head_fused_f16"), ("cls_front_kernel", "cls_front_f16"), ("cls_back_kernel", "cls_back_f16"),
+                     ("sppf_pool", "sppf_pool_f16")):
         if key in name:
             return fam
     m = re.search(r"lp::(\w+)|_ZN2lp\d+([a-z0-9_]+?)I", name)
