@@ -758,14 +758,17 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
     auto request = [&](int i, u32x4 (&dst)[SGN]) {
       bool valid;
       const int pix = tile_pixel(i, valid);
-      const T* catp = reinterpret_cast<const T*>(a.cat) + eoff(pix, a.cat_pitch) + g * G;
+      const T* catpix = reinterpret_cast<const T*>(a.cat) + eoff(pix, a.cat_pitch);
 #pragma unroll
       for (int s = 0; s < SGN; ++s) {
+        const int grp = 4 * s + g;   // K group = 8 (4) stored concat channels of the pixel
         if (FLAT) {
-          dst[s] = *reinterpret_cast<const u32x4*>(catp + (4 * s + g < a.kg ? 4 * s * G : 0));
+          // lanes whose group lies past the stored segments re-read group 0 of the SAME pixel (masked where used): the address
+          // stays inside the pixel -- group `grp` of the last pixel of the last image would lie past the end of the buffer
+          dst[s] = *reinterpret_cast<const u32x4*>(catpix + (grp < a.kg ? grp * G : 0));
         } else {
           dst[s] = u32x4{0u, 0u, 0u, 0u};
-          if (s < a.sg && valid && 4 * s + g < a.kg) dst[s] = *reinterpret_cast<const u32x4*>(catp + 4 * s * G);
+          if (s < a.sg && valid && grp < a.kg) dst[s] = *reinterpret_cast<const u32x4*>(catpix + grp * G);
         }
       }
     };
