@@ -825,6 +825,9 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     A_ += B.H * B.W;
     levels_.push_back(lv);
   }
+  // the NMS kernel packs the anchor index into 14 bits of its sort key and keeps every candidate of an image in one
+  // workgroup's LDS: reject larger heads here, at load time, not on every call (a 1024x1024 input has 21504 anchors)
+  LP_CHECK(A_ <= 16384, LP_ERR_GRAPH, "Detect head with %d anchors: at most 16384 are supported (input size %d is too large)", A_, S_);
   LP_CHECK((int)anchors->data.size() == 2 * A_ && (int)strides->data.size() == A_, LP_ERR_GRAPH,
            "anchor tables (%zu, %zu) do not match %d anchors", anchors->data.size(), strides->data.size(), A_);
   for (auto& lv : levels_) {
