@@ -257,7 +257,7 @@ def main():
                "note": "batch starts in pinned host memory: hipMemcpyAsync of 78.6 MB per step on the handle's stream, then the "
                        "same pipeline; copies of one handle overlap the kernels of the others"}
 
-    # ---- roofline of the dominant conv kernel family: profiled passes of the same step ---------------
+    # ---- roofline of the dominant conv kernel (one template instantiation): profiled passes of the same step ----
     roofline, families = None, {}
     if rank == 0 and args.profile_steps > 0:
         torch.cuda.synchronize()
@@ -308,7 +308,13 @@ def main():
         roofline["detector_conv_tflops_in_conv_kernels"] = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None
         roofline["profiled_step_ms"] = step_ms
         roofline["profiled_launches"] = sum(v["launches"] for v in families.values())
-        roofline["families_ms"] = {k: round(v["ms"], 4) for k, v in sorted(families.items(), key=lambda kv: -kv[1]["ms"])}
+        # per kernel instantiation (the profiler's names carry the template arguments, as rocprofv3 lists them) and per family
+        roofline["kernels_ms"] = {k: round(v["ms"], 4) for k, v in sorted(families.items(), key=lambda kv: -kv[1]["ms"])}
+        fam_ms = {}
+        for k, v in families.items():
+            base = k.split("<")[0] + (k[k.rindex("_f"):] if "<" in k and "_f" in k else "")
+            fam_ms[base] = fam_ms.get(base, 0.0) + v["ms"]
+        roofline["families_ms"] = {k: round(v, 4) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])}
         if args.dump_profile:
             with open(args.dump_profile, "w") as fh:
                 json.dump({"families": families, "launches": launches[-1]}, fh, indent=1)

@@ -19,19 +19,26 @@ import sys
 def family(name):
     f16 = "_f16" if "DF16_" in name or "<f16" in name else "_f32"
     ints = [int(v) for v in re.findall(r"Li(\d+)E", name)]
-    if "bottleneck_mfma_kernel" in name:
-        return "bottleneck3x3x2" + f16
-    if "conv3x3s2_direct_kernel" in name:
-        return "conv3x3s2_direct" + ("+1x1" if len(ints) > 2 and ints[2] > 0 else "") + f16
-    if "conv3x3_mfma_kernel" in name:
-        return "conv3x3_mfma" + ("+1x1" if len(ints) > 2 and ints[2] > 0 else "") + f16
-    if "conv1x1_mfma_kernel" in name:
-        return "conv1x1_mfma" + f16
+    if "bottleneck_mfma_kernel" in name:   # <T, NT, P1, P2, SEP, T2, SG>: the profiler's name carries <NT,P1,P2,T2,SG>
+        v = (ints + [0, 0, 0, 0, 0])[:5]
+        return "bottleneck3x3x2<%d,%d,%d,%d,%d>" % tuple(v) + f16
+    if "head_fused_kernel" in name:
+        t = [int(x) for x in re.findall(r"\d+", name.split("head_fused_kernel", 1)[1].split(">", 1)[0])] if "<" in name else ints
+        return "head_fused<%s>_f16" % ",".join(str(x) for x in t[:5])
+    if "conv3x3s2_direct_kernel" in name:   # <T, NT, NP, T2, U>
+        t2 = ints[2] if len(ints) > 2 else 0
+        return ("conv3x3s2_direct+1x1<%d,%d>" % (ints[0], t2) if t2 else "conv3x3s2_direct<%d>" % ints[0]) + f16
+    if "conv3x3_mfma_kernel" in name:       # <T, NT, STRIDE, T2>
+        t2 = ints[2] if len(ints) > 2 else 0
+        return ("conv3x3_mfma+1x1<%d,%d>" % (ints[0], t2) if t2 else "conv3x3_mfma<%d>" % ints[0]) + f16
+    if "conv1x1_mfma_kernel" in name:       # <T, NT, NP, EPI, UPS>
+        ups = "Lb1E" in name or ", true>" in name
+        return ("conv1x1_mfma<%d,up>" % ints[0] if ups else "conv1x1_mfma<%d>" % ints[0]) + f16
     if "stem_mfma_kernel" in name or "stem_conv" in name:
         return "stem_conv_f16" if "stem_mfma" in name else "stem_conv" + f16
     for key, fam in (("stem_block_kernel", "stem_block_f16"), ("roi_resize_kernel", "roi_resize_pil"), ("shuffle_stage_kernel", "shuffle_stage_fused_f16"),
                      ("cls_head_kernel", "cls_head_fused_f16"), ("nms_kernel", "nms"), ("roi_index_kernel", "roi_index"),
-                     ("head_fused_kernel", "head_fused_f16"), ("cls_front_kernel", "cls_front_f16"), ("cls_back_kernel", "cls_back_f16"),
+                     ("cls_front_kernel", "cls_front_f16"), ("cls_back_kernel", "cls_back_f16"),
                      ("sppf_pool", "sppf_pool_f16")):
         if key in name:
             return fam

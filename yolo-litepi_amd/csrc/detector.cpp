@@ -962,7 +962,10 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
           io.in.C -= io.up.C;
         }
         c.launch(io, st);
-        kname = std::string(c.impl == IMPL_NAIVE ? "conv_naive" : (c.direct ? "conv3x3s2_direct" : (c.k == 3 ? "conv3x3_mfma" : "conv1x1_mfma"))) + (c.T2 ? "+1x1" : "") + sfx;
+        kname = std::string(c.impl == IMPL_NAIVE ? "conv_naive" : (c.direct ? "conv3x3s2_direct" : (c.k == 3 ? "conv3x3_mfma" : "conv1x1_mfma"))) + (c.T2 ? "+1x1" : "");
+        // one name per kernel instantiation (channel tiles NT, tail tiles T2, fused-upsample variant), as rocprofv3 lists them
+        if (c.impl != IMPL_NAIVE) kname += c.T2 ? fmt("<%d,%d>", c.NT, c.T2) : (op.in2 >= 0 ? fmt("<%d,up>", c.NT) : fmt("<%d>", c.NT));
+        kname += sfx;
         break;
       }
       case DetOp::BNECK:
@@ -972,7 +975,11 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         } else {
           bnecks_[op.conv]->launch(view(op.in), view(op.out), B, st);
         }
-        kname = std::string("bottleneck3x3x2") + sfx;
+        {  // one name per kernel instantiation <NT, P1, P2, T2, SG> (what rocprofv3 lists as separate kernels)
+          const BottleneckPair& bp = *bnecks_[op.conv];
+          const int p1 = bp.TH == 16 ? 12 : (bp.TW == 40 ? 7 : (bp.TH == 8 ? 4 : 3)), p2 = bp.TH == 16 ? 10 : (bp.TW == 40 ? 5 : (bp.TH == 8 ? 3 : 2));
+          kname = fmt("bottleneck3x3x2<%d,%d,%d,%d,%d>", bp.NT, p1, p2, bp.T2, (bp.T2 > 0 && prec_ == LP_FP16) ? bp.sg : 0) + sfx;
+        }
         break;
       case DetOp::DWCONV:
         launch_dwconv3x3_act(prec_, view(op.in), view(op.out), dws_[op.conv].w.as<float>(), dws_[op.conv].b.as<float>(), dws_[op.conv].act, B, st);
@@ -1003,7 +1010,8 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
       case DetOp::HEAD:
         heads_[op.conv]->launch(view(op.in), B, levels_[op.in2].off, A_, d_anchors_.as<float>(), d_strides_.as<float>(), d_dfl_.as<float>(), out0,
                                 geom, cand, cand_count, conf, st);
-        kname = std::string("head_fused") + sfx;
+        kname = fmt("head_fused<%d,%d,%d,%d,%d>", heads_[op.conv]->C3T, heads_[op.conv]->PA, heads_[op.conv]->PB, heads_[op.conv]->NPC,
+                    heads_[op.conv]->KSA) + sfx;   // = the template arguments of head_fused_kernel
         break;
     }
     if (prof) prof->end(st, kname, op.layer, op.flops * B, op.bytes * B);
