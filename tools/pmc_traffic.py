@@ -24,7 +24,7 @@ def family(name):
         return "bottleneck3x3x2<%d,%d,%d,%d,%d>" % tuple(v) + f16
     if "head_fused_kernel" in name:
         t = [int(x) for x in re.findall(r"\d+", name.split("head_fused_kernel", 1)[1].split(">", 1)[0])] if "<" in name else ints
-        return "head_fused<%s>_f16" % ",".join(str(x) for x in t[:5])
+        return "head_fused<%s>_f16" % ",".join(str(x) for x in t[:6])
     if "conv3x3s2_direct_kernel" in name:   # <T, NT, NP, T2, U>
         t2 = ints[2] if len(ints) > 2 else 0
         return ("conv3x3s2_direct+1x1<%d,%d>" % (ints[0], t2) if t2 else "conv3x3s2_direct<%d>" % ints[0]) + f16

@@ -35,7 +35,6 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-#define HD_SLOT 24576  /* bytes per ring slot = 24 fragments */
 
 // diagnostic phase stamps (never enabled on the product path: a.stamps is null)
 #define HD_STAMP(k)                                                                                    \
@@ -79,6 +78,13 @@ __device__ __forceinline__ floatx16 bias16(const float* __restrict__ b) {
   return v;
 }
 
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // all of this wave's LDS traffic done, then the workgroup barrier -- NOT __syncthreads(): that also waits for the global
 // loads in flight (vmcnt(0)), i.e. for the ring pieces requested a few hundred cycles ago
 __device__ __forceinline__ void lds_barrier() {
@@ -97,14 +103,16 @@ __device__ __forceinline__ void lds_barrier() {
 //    once -- and requests step 0 of chunk c+1 before its own MFMAs.  A barrier at the chunk boundary instead drained the
 //    pipeline: ~500 idle matrix-pipe cycles per chunk, 3-12 chunks per stage.  (KS odd: the register sets would swap roles
 //    from chunk to chunk; such chunks run stand-alone, FIRST && LAST.)
-//  * side(j), j < 6: the weight ring's store + reload of piece j (see the kernel).
-template <int NA, int NB, int KS, bool FIRST, bool LAST, typename F, typename G>
+//  * side(j), j < SLOTF / 4: the weight ring's store + reload of piece j (see the kernel).
+//  * SLOTF: fragments (KiB) per ring slot, 24 or 12; a wave owns SLOTF / 4 pieces of every chunk.
+template <int NA, int NB, int KS, bool FIRST, bool LAST, int SLOTF, typename F, typename G>
 __device__ __forceinline__ void kchunk(const char* ring, int c, int lane16, const char* img, const int (&pix)[NB], F&& next_boff, G&& side,
                                        floatx16 (&acc)[NA][NB], half8 (&af)[2][NA], half8 (&bf)[2][NB]) {
   static_assert(KS % 2 == 0 || (FIRST && LAST), "an odd chunk cannot hand its register sets to the next one");
-  static_assert(KS >= 3, "six ring pieces ride on steps 0 .. KS-2");
-  const char* wb = ring + (c & 1) * HD_SLOT + lane16;
-  const char* wbn = ring + ((c + 1) & 1) * HD_SLOT + lane16;
+  static_assert(KS >= 2 && NA * KS <= SLOTF, "the ring pieces ride on steps 0 .. KS-2; a chunk fits one slot");
+  constexpr int SLOT = SLOTF * 1024, NPW = SLOTF / 4;
+  const char* wb = ring + (c & 1) * SLOT + lane16;
+  const char* wbn = ring + ((c + 1) & 1) * SLOT + lane16;
   auto ld = [&](int set, const char* w, int s) {
     const int boff = next_boff();
 #pragma unroll
@@ -112,7 +120,7 @@ __device__ __forceinline__ void kchunk(const char* ring, int c, int lane16, cons
 #pragma unroll
     for (int p = 0; p < NB; ++p) bf[set][p] = lds_h8(img + pix[p] + boff);
   };
-  constexpr int PPS = (6 + KS - 2) / (KS - 1);   // ring pieces per step
+  constexpr int PPS = (NPW + KS - 2) / (KS - 1);   // ring pieces per step
   if (FIRST) {
     lds_barrier();
     ld(0, wb, 0);
@@ -133,14 +141,16 @@ __device__ __forceinline__ void kchunk(const char* ring, int c, int lane16, cons
 #pragma unroll
       for (int p = 0; p < NB; ++p) acc[rt][p] = mfma32(af[s & 1][rt], bf[s & 1][p], acc[rt][p]);
 #pragma unroll
-    for (int j = s * PPS; j < (s + 1) * PPS && j < 6; ++j) side(j);
+    for (int j = s * PPS; j < (s + 1) * PPS && j < NPW; ++j) side(j);
   }
 }
 
 // NPC: 64-slot pieces per input-tile row, KSA: K steps per stage-A chunk (both fixed by the level's tile shape, see host)
-template <int C3T, int PA, int PB, int NPC, int KSA>
-__global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
+// SLOTF: fragments per weight-ring slot (24; 12 for the two-workgroups-per-CU shape), NRW: input-tile rows per wave = ceil((TH+4)/4)
+template <int C3T, int PA, int PB, int NPC, int KSA, int SLOTF, int NRW>
+__global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(const HeadArgs a) {
   constexpr int RT = 2 + C3T;       // row tiles (32 channels) of the merged first convs: box 2 | class C3T
+  constexpr int SLOT = SLOTF * 1024, NPW = SLOTF / 4;   // ring slot bytes; 1 KiB pieces per wave and chunk
   constexpr int SPM = 4 * RT + 1;   // 16-byte slots per MID pixel, one of them padding (odd: conflict-free pixel stride)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -169,14 +179,14 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
   //      wave could not hide behind its MFMAs; a global load + ds_write pair costs ~25.)  Piece indices past a chunk's end
   //      re-read its last fragment into the slot's unused tail: no control flow around the loads (see cls_net.hip for what
   //      that does to the register allocator).
-  u32x4 wreg[6];
+  u32x4 wreg[NPW];
   // (every chunk occupies a whole 24 KiB slot image in the stream, two zero chunks follow the last one: the source of
   //  piece j of chunk c is wstream + c * 24 KiB + (wave + 4j) KiB -- no chunk table, no clamping, no scalar loads in the K loop)
   const char* wsrc = wstream;
-  auto wsource = [&](int c) { wsrc = wstream + (size_t)c * HD_SLOT + wave * 1024; };
+  auto wsource = [&](int c) { wsrc = wstream + (size_t)c * SLOT + wave * 1024; };
   auto wload1 = [&](int j) { wreg[j] = *reinterpret_cast<const u32x4*>(wsrc + j * 4096); };
   auto wstore1 = [&](int c, int j) {
-    *reinterpret_cast<u32x4*>(RING + (c & 1) * HD_SLOT + lane * 16 + (wave + 4 * j) * 1024) = wreg[j];
+    *reinterpret_cast<u32x4*>(RING + (c & 1) * SLOT + lane * 16 + (wave + 4 * j) * 1024) = wreg[j];
   };
   // ---- input tile (halo 2) -> IN through registers: rows of RSin 16-byte slots = (pixel, channel group); pad slots, pixels
   //      outside the image and the row's tail are zeros (= the conv's zero padding).  A wave takes rows wave, wave + 4, ..;
@@ -194,9 +204,9 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
       voff[pc] = xok[pc] ? (ix * a.in_pitch + cgs * 8) * 2 : (ox0 >= 2 ? 0 : (2 - ox0) * a.in_pitch * 2);
     }
     const char* in_n = reinterpret_cast<const char*>(a.in) + ((long)n * a.H * a.W) * a.in_pitch * 2;
-    u32x4 v[5][NPC];
+    u32x4 v[NRW][NPC];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < NRW; ++j) {
       const int iy = wave + 4 * j;
       const int gy = oy0 - 2 + iy;
       const bool rok = iy < IHin && gy >= 0 && gy < a.H;
@@ -208,14 +218,14 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
         v[j][pc] = (rok && xok[pc]) ? x : u32x4{0u, 0u, 0u, 0u};
       }
     }
-    u32x4 w0[6];   // chunk 0 goes through a register set of its own so that chunk 1 can be requested in the same breath
+    u32x4 w0[NPW];   // chunk 0 goes through a register set of its own so that chunk 1 can be requested in the same breath
 #pragma unroll
-    for (int j = 0; j < 6; ++j) w0[j] = *reinterpret_cast<const u32x4*>(wstream + (wave + 4 * j) * 1024);
+    for (int j = 0; j < NPW; ++j) w0[j] = *reinterpret_cast<const u32x4*>(wstream + (wave + 4 * j) * 1024);
     wsource(1);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) wload1(j);
+    for (int j = 0; j < NPW; ++j) wload1(j);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < NRW; ++j) {
       const int iy = wave + 4 * j;
 #pragma unroll
       for (int pc = 0; pc < NPC; ++pc) {
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4*>(RING + lane * 16 + (wave + 4 * j) * 1024) = w0[j];
+    for (int j = 0; j < NPW; ++j) *reinterpret_cast<u32x4*>(RING + lane * 16 + (wave + 4 * j) * 1024) = w0[j];
   }
   HD_STAMP(2)
 
@@ -288,23 +298,24 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
       }
       return boff;
     };
-    const int ncA = nch - (C3T == 2 ? 7 : 5);   // stream = A chunks | 3 box-B | 1 class-B (3 with two class row tiles) | 1 C
+    // stream = A chunks | box-B chunks | class-B chunks | 1 C
+    const int ncA = nch - (36 / (SLOTF / 2)) - (C3T == 2 ? 36 / (SLOTF / 2) : 18 / (SLOTF >= 18 ? 18 : 6)) - 1;
     half8 af[2][RT], bf[2][PA];
     if constexpr (KSA % 2 == 0) {   // one operand pipeline over all of stage A (ncA >= 2, host-checked)
       wsource(c + 2);
-      kchunk<RT, PA, KSA, true, false>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+      kchunk<RT, PA, KSA, true, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
       HD_STAMP(3)
       for (++c; c < ncA - 1; ++c) {
         wsource(c + 2);
-        kchunk<RT, PA, KSA, false, false>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+        kchunk<RT, PA, KSA, false, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
       }
       wsource(c + 2);
-      kchunk<RT, PA, KSA, false, true>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+      kchunk<RT, PA, KSA, false, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
       ++c;
     } else {
       for (; c < ncA; ++c) {
         wsource(c + 2);
-        kchunk<RT, PA, KSA, true, true>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+        kchunk<RT, PA, KSA, true, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
         if (c == 0) { HD_STAMP(3) }
       }
     }
@@ -362,15 +373,13 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
       return boff;
     };
     half8 af[2][2], bf[2][PB];
-    wsource(c + 2);
-    kchunk<2, PB, 12, true, false>(RING, c, lane16, MID, pixB, next_boff, ring_side, accB, af, bf);
-    ++c;
-    wsource(c + 2);
-    kchunk<2, PB, 12, false, false>(RING, c, lane16, MID, pixB, next_boff, ring_side, accB, af, bf);
-    ++c;
-    wsource(c + 2);
-    kchunk<2, PB, 12, false, true>(RING, c, lane16, MID, pixB, next_boff, ring_side, accB, af, bf);
-    ++c;
+    constexpr int KSB = SLOTF / 2, NCB = 36 / KSB;   // 36 K steps (9 taps x 4 channel groups), two row tiles: SLOTF / 2 steps per chunk
+    static_for<0, NCB>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      wsource(c + 2);
+      kchunk<2, PB, KSB, i == 0, i == NCB - 1, SLOTF>(RING, c, lane16, MID, pixB, next_boff, ring_side, accB, af, bf);
+      ++c;
+    });
   }
   HD_STAMP(6)
   // ======================= stage B, class tower: (32*C3T) x (9 * 32*C3T) x tile pixels =======================
@@ -389,28 +398,22 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
       return tapB[tap] + (8 + 2 * cg) * 16;
     };
     half8 af[2][C3T], bf[2][PB];
-    if constexpr (C3T == 2) {
+    // 18 (one class row tile) or 36 (two; K padded to 64 channels) K steps; steps per chunk: what fits a slot, even
+    constexpr int KST = C3T == 2 ? 36 : 18;
+    constexpr int KSC = C3T == 2 ? SLOTF / 2 : (SLOTF >= 18 ? 18 : 6), NCC = KST / KSC;
+    static_for<0, NCC>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
       wsource(c + 2);
-      kchunk<C3T, PB, 12, true, false>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
+      kchunk<C3T, PB, KSC, i == 0, i == NCC - 1, SLOTF>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
       ++c;
-      wsource(c + 2);
-      kchunk<C3T, PB, 12, false, false>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
-      ++c;
-      wsource(c + 2);
-      kchunk<C3T, PB, 12, false, true>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
-      ++c;
-    } else {
-      wsource(c + 2);
-      kchunk<C3T, PB, 18, true, true>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
-      ++c;
-    }
+    });
   }
   // ======================= stage C: the 1x1 projections from the accumulators, then decode =======================
   HD_STAMP(7)
   half8 wcb[2][4], wcc[2 * C3T];
   {
     lds_barrier();   // the projection chunk was stored behind the class tower's steps
-    const char* wb = RING + (c & 1) * HD_SLOT + lane16;
+    const char* wb = RING + (c & 1) * SLOT + lane16;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -458,28 +461,28 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
     }
     const float x0 = __shfl_xor(dist[0], 32), x1 = __shfl_xor(dist[1], 32);
     const float d0 = h ? x0 : dist[0], d1 = h ? dist[0] : x0, d2 = h ? x1 : dist[1], d3 = h ? dist[1] : x1;
-    // class scores: this lane holds classes 16*h .. 16*h + 15
-    float best = -1.f;
+    // class scores: this lane holds the logits of classes 16*h .. 16*h + 15.  The sigmoid is monotonic: the best class is the
+    // arg-max of the LOGITS (selects, no branches, no transcendentals), and one sigmoid gives its score.
+    float bl = -INFINITY;
     int best_c = 0;
-    float sc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      sc[i] = 0.f;
-      if (16 * h + i < a.nc) {   // (nc = 1: one lane half evaluates one sigmoid)
-        sc[i] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(oc[i] * -1.4426950408889634f));
-        if (sc[i] > best) { best = sc[i]; best_c = 16 * h + i; }
-      }
+      const float v = (16 * h + i < a.nc) ? oc[i] : -INFINITY;
+      const bool up = v > bl;   // strict: the first maximum in class order stays
+      bl = up ? v : bl;
+      best_c = up ? 16 * h + i : best_c;
     }
-    const float ob_ = __shfl_xor(best, 32);
+    const float obl = __shfl_xor(bl, 32);
     const int oc_ = __shfl_xor(best_c, 32);
-    if (h == 0 && ob_ > best) { best = ob_; best_c = oc_; }   // first maximum in class order: the upper half wins only if larger
+    if (h == 0 && obl > bl) { bl = obl; best_c = oc_; }   // the upper half wins only if larger
+    const float best = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(bl * -1.4426950408889634f));
     if (pvalid[p]) {
       const int anchor = anchor_i[p];
       float* o = a.out0 ? a.out0 + (long)n * (4 + a.nc) * a.A + anchor : nullptr;
-      if (o) {
+      if (o) {   // parity hook only (lp_detect_raw): the whole score rows
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (16 * h + i < a.nc) o[(long)(4 + 16 * h + i) * a.A] = sc[i];
+          if (16 * h + i < a.nc) o[(long)(4 + 16 * h + i) * a.A] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(oc[i] * -1.4426950408889634f));
       }
       if (h == 0) {
         const float ax = anc_x[p], ay = anc_y[p], s = anc_s[p];
@@ -502,28 +505,34 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const HeadArgs a) {
 // half h then holds channels 16*h .. 16*h+15 in its 16 registers
 static inline int row_channel(int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); }
 
-static size_t head_lds(int th, int tw, int kpt, int c3t) {
+static size_t head_lds(int th, int tw, int kpt, int c3t, int slotf) {
   const size_t in = ((size_t)(th + 4) * (tw + 4) * (2 * kpt + 1) * 16 + 1023) & ~(size_t)1023;
   const size_t mid = ((size_t)(th + 2) * (tw + 2) * (4 * (2 + c3t) + 1) * 16 + 1023) & ~(size_t)1023;
-  return in + mid + 2 * (size_t)HD_SLOT;
+  return in + mid + 2 * (size_t)slotf * 1024;
 }
 
 // One kernel configuration per (class row tiles, K steps per tap = Cin / 16): tile shape TH x TW, pixel tiles per wave in stage
 // A / B (ceil((TH+2)(TW+2)/32) <= 4*PA, ceil(TH*TW/32) <= 4*PB), 64-slot pieces per input-tile row, K steps per stage-A chunk
 // (a divisor of 9*KPT with (2+C3T)*KSA <= 24 fragments).  Chosen for LDS (input tile + first-conv image + 48 KiB ring <= 160
 // KiB) and for whole tiles on the 80 / 40 / 20 maps of a 640 input; other map sizes run the same shapes with masked edges.
-struct HeadCfg { int c3t, kpt, th, tw, pa, pb, npc, ksa; };
+// slotf: fragments per weight-ring slot.  The first v1 P3 entry is the TWO-WORKGROUPS-PER-CU shape: an 8 x 16 tile, 12-fragment
+// slots and one pixel tile per wave in stage B make the kernel fit 80 KiB of LDS and 256 registers, so that two workgroups share
+// a CU and the VALU phases (SiLU epilogues, decode: two thirds of a tile's cycles, transcendental-bound) of one overlap the MFMA
+// phases of the other -- with one workgroup per CU the matrix pipe idles through them.  LITEPI_HEAD_1WG=1: the 16 x 16 shape.
+struct HeadCfg { int c3t, kpt, th, tw, pa, pb, npc, ksa, slotf; };
 static const HeadCfg kHeadCfg[] = {
-    {1, 2, 16, 16, 3, 2, 2, 6},   // v1 P3: Cin 32
-    {1, 4, 10, 20, 3, 2, 4, 6},   // v1 P4: Cin 64
-    {1, 8, 10, 10, 2, 1, 4, 8},   // v1 P5: Cin 128
-    {2, 3, 10, 20, 3, 2, 3, 3},   // v2 P3: Cin 48
-    {2, 6, 10, 10, 2, 1, 3, 6},   // v2 P4: Cin 96
-    {2, 12, 8, 8, 1, 1, 5, 6},    // v2 P5: Cin 192
+    {1, 2, 8, 16, 2, 1, 2, 2, 12},    // v1 P3: Cin 32, two workgroups per CU
+    {1, 2, 16, 16, 3, 2, 2, 6, 24},   // v1 P3: Cin 32
+    {1, 4, 10, 20, 3, 2, 4, 6, 24},   // v1 P4: Cin 64
+    {1, 8, 10, 10, 2, 1, 4, 8, 24},   // v1 P5: Cin 128
+    {2, 3, 10, 20, 3, 2, 3, 3, 24},   // v2 P3: Cin 48
+    {2, 6, 10, 10, 2, 1, 3, 6, 24},   // v2 P4: Cin 96
+    {2, 12, 8, 8, 1, 1, 5, 6, 24},    // v2 P5: Cin 192
 };
 static const HeadCfg* find_cfg(int c3t, int kpt) {
+  static const bool one_wg = getenv("LITEPI_HEAD_1WG") != nullptr;
   for (auto& c : kHeadCfg)
-    if (c.c3t == c3t && c.kpt == kpt) return &c;
+    if (c.c3t == c3t && c.kpt == kpt && !(one_wg && c.slotf == 12)) return &c;
   return nullptr;
 }
 
@@ -540,13 +549,14 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   KPT = Cin / 16;
   const HeadCfg* cfg = find_cfg(C3T, KPT);
   LP_CHECK(cfg, LP_ERR_STATE, "Detect head %s: no kernel configuration for Cin %d", name.c_str(), Cin);
-  TH = cfg->th; TW = cfg->tw; PA = cfg->pa; PB = cfg->pb; NPC = cfg->npc; KSA = cfg->ksa;
-  lds_bytes = head_lds(TH, TW, KPT, C3T);
+  TH = cfg->th; TW = cfg->tw; PA = cfg->pa; PB = cfg->pb; NPC = cfg->npc; KSA = cfg->ksa; SLOTF = cfg->slotf;
+  lds_bytes = head_lds(TH, TW, KPT, C3T, SLOTF);
   const int RT = 2 + C3T, CM = 32 * C3T;
   // chunks hold at most 24 fragments (one ring slot): stage A KSA K steps x RT row tiles, stage B box 12 x 2, class 18 x 1
   // (12 x 2 for two class row tiles), projections 10 (12)
   LP_CHECK(KSA % 2 != 0 || 9 * KPT / KSA >= 2, LP_ERR_STATE, "Detect head %s: stage A needs two chunks", name.c_str());
-  LP_CHECK(lds_bytes <= 160 * 1024 && ((TW + 4) * (2 * KPT + 1) + 63) / 64 == NPC && (9 * KPT) % KSA == 0 && RT * KSA <= 24 && TH + 4 <= 20 &&
+  LP_CHECK(lds_bytes <= (SLOTF == 12 ? 80 : 160) * 1024 && ((TW + 4) * (2 * KPT + 1) + 63) / 64 == NPC && (9 * KPT) % KSA == 0 && RT * KSA <= SLOTF &&
+               TH + 4 <= (SLOTF == 12 ? 12 : 20) && (SLOTF == 12 || SLOTF == 24) && 8 + 2 * C3T <= SLOTF &&
                (TH + 2) * (TW + 2) <= 128 * PA && TH * TW <= 128 * PB, LP_ERR_STATE, "Detect head %s: inconsistent configuration", name.c_str());
   (void)batch_hint;
   std::vector<uint16_t> stream;
@@ -560,10 +570,10 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   auto begin_chunk = [&]() { coff.push_back((unsigned short)(stream.size() / 512)); };
   auto end_chunk = [&](int ksteps) {
     const size_t nf = stream.size() / 512 - coff.back();
-    LP_CHECK(nf >= 1 && nf <= 24, LP_ERR_STATE, "Detect head: chunk of %zu fragments", nf);
+    LP_CHECK(nf >= 1 && (int)nf <= SLOTF, LP_ERR_STATE, "Detect head: chunk of %zu fragments", nf);
     csz.push_back((unsigned char)nf);
     cks.push_back((unsigned char)ksteps);
-    stream.resize((size_t)(coff.back() + 24) * 512, 0);   // every chunk is a whole 24 KiB slot image
+    stream.resize((size_t)(coff.back() + SLOTF) * 512, 0);   // every chunk is a whole slot image
   };
   const std::vector<float>& wa = *s.wa;  // [64 + c3][9][Cin]
   // ---- stage A: K step (tap, cg): element e = input channel 16*cg + e
@@ -579,16 +589,17 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
     if (ks % KSA == KSA - 1) end_chunk(KSA);
   }
   // ---- stage B box: K step kq = (tap, cg), 4 per tap
+  const int KSB = SLOTF / 2;   // two row tiles per step
   for (int kq = 0; kq < 36; ++kq) {
-    if (kq % 12 == 0) begin_chunk();
+    if (kq % KSB == 0) begin_chunk();
     const int tap = kq >> 2, cg = kq & 3;
     for (int rt = 0; rt < 2; ++rt)
       frag([&](int rho, int e) { return (*s.wbb)[((size_t)(rt * 32 + row_channel(rho)) * 9 + tap) * 64 + 16 * cg + e]; });
-    if (kq % 12 == 11) end_chunk(12);
+    if (kq % KSB == KSB - 1) end_chunk(KSB);
   }
   // ---- stage B class: 2*C3T K steps per tap
   {
-    const int per_tap = 2 * C3T, total = 9 * per_tap, per_chunk = C3T == 2 ? 12 : 18;
+    const int per_tap = 2 * C3T, total = 9 * per_tap, per_chunk = C3T == 2 ? SLOTF / 2 : (SLOTF >= 18 ? 18 : 6);
     for (int kq = 0; kq < total; ++kq) {
       if (kq % per_chunk == 0) begin_chunk();
       const int tap = kq / per_tap, cg = kq % per_tap;
@@ -618,7 +629,7 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   end_chunk(0);
   nchunks = (int)coff.size();
   LP_CHECK(nchunks <= 64 && stream.size() / 512 < 65536, LP_ERR_STATE, "Detect head: weight stream too long (%d chunks)", nchunks);
-  stream.resize(stream.size() + (size_t)2 * 24 * 512, 0);   // the ring requests two chunks past the end
+  stream.resize(stream.size() + (size_t)2 * SLOTF * 512, 0);   // the ring requests two chunks past the end
   nrep = getenv("LITEPI_HEAD_REPL") ? std::max(1, atoi(getenv("LITEPI_HEAD_REPL"))) : 8;
   rep_stride = (stream.size() * 2 + 4096 + 255) & ~(size_t)255;
   d_stream.alloc(rep_stride * nrep + 64);
@@ -660,17 +671,18 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
     d_stamps.alloc((size_t)grid.x * 16 * 8);
     a.stamps = d_stamps.as<unsigned long long>();
   }
-#define LP_HEAD(C3T_, PA_, PB_, NPC_, KSA_)                                                                           \
-  {                                                                                                               \
-    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_>), 160 * 1024); \
-    hipLaunchKernelGGL((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_>), grid, dim3(256), lds_bytes, st, a);         \
+#define LP_HEAD(C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_)                                                                          \
+  {                                                                                                                               \
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_>), 160 * 1024); \
+    hipLaunchKernelGGL((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_>), grid, dim3(256), lds_bytes, st, a);         \
   }
-  if (C3T == 1 && KPT == 2) LP_HEAD(1, 3, 2, 2, 6)
-  else if (C3T == 1 && KPT == 4) LP_HEAD(1, 3, 2, 4, 6)
-  else if (C3T == 1 && KPT == 8) LP_HEAD(1, 2, 1, 4, 8)
-  else if (C3T == 2 && KPT == 3) LP_HEAD(2, 3, 2, 3, 3)
-  else if (C3T == 2 && KPT == 6) LP_HEAD(2, 2, 1, 3, 6)
-  else if (C3T == 2 && KPT == 12) LP_HEAD(2, 1, 1, 5, 6)
+  if (C3T == 1 && KPT == 2 && SLOTF == 12) LP_HEAD(1, 2, 1, 2, 2, 12, 3)
+  else if (C3T == 1 && KPT == 2) LP_HEAD(1, 3, 2, 2, 6, 24, 5)
+  else if (C3T == 1 && KPT == 4) LP_HEAD(1, 3, 2, 4, 6, 24, 5)
+  else if (C3T == 1 && KPT == 8) LP_HEAD(1, 2, 1, 4, 8, 24, 5)
+  else if (C3T == 2 && KPT == 3) LP_HEAD(2, 3, 2, 3, 3, 24, 5)
+  else if (C3T == 2 && KPT == 6) LP_HEAD(2, 2, 1, 3, 6, 24, 5)
+  else if (C3T == 2 && KPT == 12) LP_HEAD(2, 1, 1, 5, 6, 24, 5)
   else throw Error(LP_ERR_STATE, "Detect head: no kernel configuration");
 #undef LP_HEAD
   LP_HIP(hipGetLastError());
