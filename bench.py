@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--nbatches", type=int, default=4, help="distinct input batches the steps rotate over")
     ap.add_argument("--windows", type=int, default=9, help="extra timed windows of --steps steps (median / p95)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (PCIe-inclusive) measurement")
+    ap.add_argument("--conf", type=float, default=None, help="experiment: detector confidence threshold (default 0.25, BASELINE configs[2])")
     ap.add_argument("--dump-profile", default="", help="write the per-launch profile of the roofline pass to this JSON file")
     return ap.parse_args()
 
@@ -136,6 +137,7 @@ def cpu_baseline(param, binf, cls_state, imgs_np, n_images):
 
 def main():
     args = parse_args()
+    run_conf = CONF if args.conf is None else args.conf   # (the calibration always targets CONF)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -189,7 +191,7 @@ def main():
         i, j = k % NH, k % NB
         d, c = outs[i]
         with torch.cuda.stream(streams[i]):
-            engs[i].run_batch_device(imgs[j].data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
+            engs[i].run_batch_device(imgs[j].data_ptr(), B, 640, 640, run_conf, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
             if world > 1:
                 return gatherers[i].gather(outs[i])
         return d, c.view(1, -1)
@@ -246,7 +248,7 @@ def main():
             d, c = outs[i]
             with torch.cuda.stream(streams[i]):
                 stage[i].copy_(host[j], non_blocking=True)
-                engs[i].run_batch_device(stage[i].data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
+                engs[i].run_batch_device(stage[i].data_ptr(), B, 640, 640, run_conf, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
                 if world > 1:
                     return gatherers[i].gather(outs[i])
 
@@ -265,7 +267,7 @@ def main():
         launches = []
         for _ in range(args.profile_steps):
             eng.profile_next(True)
-            eng.run_batch_device(imgs[0].data_ptr(), B, 640, 640, CONF, IOU, MIN_AREA, dets.data_ptr(), counts.data_ptr())
+            eng.run_batch_device(imgs[0].data_ptr(), B, 640, 640, run_conf, IOU, MIN_AREA, dets.data_ptr(), counts.data_ptr())
             torch.cuda.synchronize()
             launches.append(eng.profile_read())
         for run in launches:
@@ -351,7 +353,7 @@ def main():
                 "detector": f"YOLO-LitePi {args.preset} architecture, seeded random weights (LSUV-scaled), "
                             f"{flop_img / 1e9:.3f} GFLOP/image, class bias calibrated to ~{TARGET_CANDIDATES} candidates/image",
                 "classifier": f"ShuffleNetV2 x1.0, {NUM_CLASSES} classes, seeded random weights, 64x64 ROIs",
-                "conf": CONF, "iou": IOU, "min_area": MIN_AREA, "max_det": args.max_det, "steps_in_flight": NH,
+                "conf": run_conf, "iou": IOU, "min_area": MIN_AREA, "max_det": args.max_det, "steps_in_flight": NH,
                 "distinct_input_batches": NB,
                 "host_enqueue_ms_per_step": round(host_enqueue_s * 1e3 / K, 4),
                 "global_batch": world * B,
