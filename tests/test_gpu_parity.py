@@ -830,8 +830,9 @@ def test_empty_and_error_behaviour(synth_models, tmp_path):
         assert ids.shape == (1,) and probs.shape == (1, 49) and abs(probs.sum() - 1) < 1e-3
     finally:
         clf.engine.close()
-    with pytest.raises(ValueError):
-        PyTorchClassifier("x", "resnet18")
+    for arch in ("efficientnet", "mobilenetv2"):   # the two --clf_arch choices of e2e.py:324-329 that are not built
+        with pytest.raises(ValueError):
+            PyTorchClassifier("x", arch)
 
 
 # ---------------------------------------------------------------------------- other graphs of the family (optional)

@@ -755,9 +755,17 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
     // compiler puts s_waitcnt vmcnt(0) three instructions after every request.)  SG == 0 (fp32, up to 6 steps): branches.
     constexpr bool FLAT = SG > 0;
     constexpr int SGN = FLAT ? SG : SGMAX;
-    auto request = [&](int i, u32x4 (&dst)[SGN]) {
+    // (without SEP the shortcut operand x comes from global memory too: requested with the concat segments, 8 bytes per channel
+    //  quad, clamped to quad 0 past the layer's channels and masked by the channel test where it is used)
+    typename Tr<T>::quad xq[LA][NT];
+    auto request = [&](int i, u32x4 (&dst)[SGN], typename Tr<T>::quad (&xdst)[NT]) {
       bool valid;
       const int pix = tile_pixel(i, valid);
+      if (FLAT && !SEP) {
+        const T* xp = reinterpret_cast<const T*>(a.in) + eoff(pix, a.in_pitch);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xdst[t] = *reinterpret_cast<const typename Tr<T>::quad*>(xp + (chbase + t * 4 < a.C ? chbase + t * 4 : 0));
+      }
       const T* catpix = reinterpret_cast<const T*>(a.cat) + eoff(pix, a.cat_pitch);
 #pragma unroll
       for (int s = 0; s < SGN; ++s) {
@@ -774,7 +782,7 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
     };
     u32x4 bgq[LA][SGN];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) request(i, bgq[i]);
+    for (int i = 0; i < LA; ++i) request(i, bgq[i], xq[i]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < P2; ++i) {
@@ -787,8 +795,11 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
         const unsigned m = (!FLAT || (valid && 4 * s + g < a.kg)) ? 0xffffffffu : 0u;
         bg[s] = as_frag<T>(bgq[i % LA][s] & m);
       }
+      typename Tr<T>::quad xqi[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) xqi[t] = xq[i % LA][t];
       if (i + LA < P2) {
-        request(i + LA, bgq[i % LA]);
+        request(i + LA, bgq[i % LA], xq[i % LA]);
         __builtin_amdgcn_sched_barrier(0);   // keep the requests up here (the scheduler sinks loads to their first use)
       }
       // y_last: activation, round to T, add the shortcut, round again (= store_lane_at), kept as the register B operand
@@ -802,6 +813,8 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
         for (int r = 0; r < 4; ++r) xr[r] = (T)0.f;
         if (SEP) {  // x from the preserved LDS tile: always a valid address (the tile's pixel is clamped), masked by the add below
           if (chbase + t * 4 < a.C) xr = *reinterpret_cast<const typename Tr<T>::quad*>(xres + t * 4);
+        } else if (FLAT) {
+          if (valid && chbase + t * 4 < a.C) xr = xqi[t];   // (a select on registers)
         } else if (valid && chbase + t * 4 < a.C) xr = *reinterpret_cast<const typename Tr<T>::quad*>(xres + t * 4);
         const floatx4 y = act4<T, ACT_SILU>(acc2[t][i], bias2[t]);
 #pragma unroll
@@ -1115,6 +1128,32 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const ConvArgs a, int k
     reinterpret_cast<T*>(a.out)[pix * a.out_pitch + co] = (T)v;
 }
 
+// uint8 input tile -> LDS as dwords: `rows` x `roww` dwords, row r = image row iy0 + r, dword c = row dword w0 + c, zeros outside
+// the image.  Every thread requests ALL of its dwords (<= MAXI) before the first store -- unconditional loads from clamped
+// addresses, masked when stored; as a loop of `if (inside) v = load; store v` each iteration was a memory round trip of its own.
+template <int MAXI>
+__device__ __forceinline__ void stage_u8_tile(const uint32_t* __restrict__ im, uint32_t* __restrict__ tile, int rows, int roww, int iy0, int w0,
+                                              int Hin, int row_words, int tid) {
+  const int total = rows * roww;
+  uint32_t v[MAXI];
+  unsigned keep = 0;
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    int i = tid + 256 * k;
+    i = i < total ? i : total - 1;
+    const int r = i / roww, c = i - r * roww;
+    const int iy = iy0 + r, wi = w0 + c;
+    const int iyc = iy < 0 ? 0 : (iy < Hin ? iy : Hin - 1), wic = wi < 0 ? 0 : (wi < row_words ? wi : row_words - 1);
+    v[k] = im[(long)iyc * row_words + wic];
+    keep |= (iy >= 0 && iy < Hin && wi >= 0 && wi < row_words) ? 1u << k : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < MAXI; ++k) {
+    const int i = tid + 256 * k;
+    if (i < total) tile[i] = ((keep >> k) & 1u) ? v[k] : 0u;
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // Stem: 3x3 stride-2 pad-1 conv straight from the uint8 BGR image (the reference's
 // BGR->RGB + x*(1/255) + HWC->CHW preprocessing, e2e.py:222-238, is folded in: the weight
@@ -1181,13 +1220,7 @@ __global__ __launch_bounds__(256) void stem_conv_lds_kernel(const uint8_t* __res
   const int row_words = Win * 3 / 4;
   const int w0 = (6 * ox0 - 3) >> 2;  // first staged dword of a row (arithmetic shift: -1 for the left border tile)
   const uint32_t* im = reinterpret_cast<const uint32_t*>(img + (long)n * Hin * Win * 3);
-  for (int i = tid; i < (2 * STEM_TH + 1) * STEM_ROWW; i += 256) {
-    const int r = i / STEM_ROWW, c = i - r * STEM_ROWW;
-    const int iy = 2 * oy0 - 1 + r, wi = w0 + c;
-    uint32_t v = 0u;
-    if (iy >= 0 && iy < Hin && wi >= 0 && wi < row_words) v = im[(long)iy * row_words + wi];
-    tile[i] = v;
-  }
+  stage_u8_tile<((2 * STEM_TH + 1) * STEM_ROWW + 255) / 256>(im, tile, 2 * STEM_TH + 1, STEM_ROWW, 2 * oy0 - 1, w0, Hin, row_words, tid);
   __syncthreads();
   const int ty = tid >> 5, tx = tid & 31;
   const int oy = oy0 + ty, ox = ox0 + tx;
@@ -1252,13 +1285,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restric
   const int row_words = Win * 3 / 4;
   const int w0 = (6 * ox0 - 3) >> 2;  // first staged dword of a row (tile byte 1 = window byte 0 of column ox0)
   const uint32_t* im = reinterpret_cast<const uint32_t*>(img + (long)n * Hin * Win * 3);
-  for (int i = tid; i < (2 * STEMM_TH + 1) * STEMM_ROWW; i += 256) {
-    const int r = i / STEMM_ROWW, c = i - r * STEMM_ROWW;
-    const int iy = 2 * oy0 - 1 + r, wi = w0 + c;
-    uint32_t v = 0u;
-    if (iy >= 0 && iy < Hin && wi >= 0 && wi < row_words) v = im[(long)iy * row_words + wi];
-    tile[i] = v;
-  }
+  stage_u8_tile<((2 * STEMM_TH + 1) * STEMM_ROWW + 255) / 256>(im, tile, 2 * STEMM_TH + 1, STEMM_ROWW, 2 * oy0 - 1, w0, Hin, row_words, tid);
   const half8 af0 = __builtin_bit_cast(half8, afrag[lane]);
   const half8 af1 = __builtin_bit_cast(half8, afrag[64 + lane]);
   const int c0 = (g & 1) * 4;
@@ -1318,13 +1345,7 @@ __global__ __launch_bounds__(256) void stem_mfma16_kernel(const uint8_t* __restr
   const int row_words = Win * 3 / 4;
   const int w0 = (6 * ox0 - 3) >> 2;
   const uint32_t* im = reinterpret_cast<const uint32_t*>(img + (long)n * Hin * Win * 3);
-  for (int i = tid; i < (2 * STEMM_TH + 1) * STEMM_ROWW; i += 256) {
-    const int r = i / STEMM_ROWW, c = i - r * STEMM_ROWW;
-    const int iy = 2 * oy0 - 1 + r, wi = w0 + c;
-    uint32_t v = 0u;
-    if (iy >= 0 && iy < Hin && wi >= 0 && wi < row_words) v = im[(long)iy * row_words + wi];
-    tile[i] = v;
-  }
+  stage_u8_tile<((2 * STEMM_TH + 1) * STEMM_ROWW + 255) / 256>(im, tile, 2 * STEMM_TH + 1, STEMM_ROWW, 2 * oy0 - 1, w0, Hin, row_words, tid);
   const half8 af = __builtin_bit_cast(half8, afrag[lane]);
   const floatx4 b4 = *reinterpret_cast<const floatx4*>(bias + 4 * g);
   __syncthreads();

@@ -517,19 +517,37 @@ __device__ __forceinline__ void roi_resize_one(const RoiResizeArgs& a, int r, ch
       const int rpb = RR_BAND_BYTES / pitch;  // rows per band (>= 35)
       for (int r0 = 0; r0 < in_h; r0 += rpb) {
         const int nb = in_h - r0 < rpb ? in_h - r0 : rpb;
-        // 1. band -> LDS, aligned dwords
-        for (int i = tid; i < nb * dpr; i += RR_THREADS) {
-          const int row = i / dpr, j = i - row * dpr;
-          const uint8_t* rp = src + ((long)(ry + r0 + row) * gm.w + rx) * 3;
-          const uint8_t* ap = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(rp) & ~(uintptr_t)3) + 4 * j;
-          uint32_t v = 0;
-          if (ap >= src && ap + 4 <= img_end) {
-            v = *reinterpret_cast<const uint32_t*>(ap);
-          } else {  // the image's first / last bytes: never read outside the caller's buffer
-            for (int b = 0; b < 4; ++b)
-              if (ap + b >= src && ap + b < img_end) v |= (uint32_t)ap[b] << (8 * b);
+        // 1. band -> LDS, aligned dwords.  Eight loads per thread are requested before the first store (one workgroup per CU:
+        //    nothing else hides a load, and a loop of load-then-store is one memory round trip per iteration)
+        for (int i0 = 0; i0 < nb * dpr; i0 += RR_THREADS * 8) {
+          uint32_t v[8];
+          const uint8_t* apv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int i = i0 + u * RR_THREADS + tid;
+            i = i < nb * dpr ? i : nb * dpr - 1;
+            const int row = i / dpr, j = i - row * dpr;
+            const uint8_t* rp = src + ((long)(ry + r0 + row) * gm.w + rx) * 3;
+            apv[u] = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(rp) & ~(uintptr_t)3) + 4 * j;
+            const bool whole = apv[u] >= src && apv[u] + 4 <= img_end;
+            // (the image's first / last dword may straddle the caller's buffer: those are re-read byte-wise below)
+            v[u] = *reinterpret_cast<const uint32_t*>(whole ? apv[u] : reinterpret_cast<const uint8_t*>(a.rects));   // (any valid dword)
           }
-          *reinterpret_cast<uint32_t*>(crop + row * pitch + 4 * j) = v;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * RR_THREADS + tid;
+            if (i < nb * dpr) {
+              const int row = i / dpr, j = i - row * dpr;
+              uint32_t x = v[u];
+              const uint8_t* ap = apv[u];
+              if (!(ap >= src && ap + 4 <= img_end)) {  // never read outside the caller's buffer
+                x = 0;
+                for (int b = 0; b < 4; ++b)
+                  if (ap + b >= src && ap + b < img_end) x |= (uint32_t)ap[b] << (8 * b);
+              }
+              *reinterpret_cast<uint32_t*>(crop + row * pitch + 4 * j) = x;
+            }
+          }
         }
         __syncthreads();
         // 2. horizontal pass of the band: one thread per (row, xx), three channels, BGR -> RGB
