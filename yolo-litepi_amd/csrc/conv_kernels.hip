@@ -593,17 +593,47 @@ __global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel
     }
     for (int p = wave_s; p < w3frags; p += 4) LP_GLDS16(reinterpret_cast<const u32x4*>(a.w3) + p * 64 + lane, smem + 512 + 2 * wbytes + p * 1024);
     const char* in_b = reinterpret_cast<const char*>(a.in);
-    const int nitems = IH * pcs;
-    for (int it = wave_s; it < nitems; it += 4) {
-      const int iy = (int)(((unsigned)it * a.rcp_pcs) >> 16), pc = it - iy * pcs;
-      const int gy = iy0 + iy;
-      const char* rowp = in_b + ((long)(n * a.H + gy) * a.W + ix0) * a.in_pitch * (long)sizeof(T);
-      const int sl = pc * 64 + lane;
-      const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
-      const int gx = ix0 + ix;
-      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ix < IW && cgs < CG;
-      const char* src = ok ? rowp + (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : zeros;
-      if (sl < RS) LP_GLDS16(src, tile + (iy * RS + pc * 64) * 16);
+    if (pcs <= 3) {
+      // rows to the waves, the (<= 3) 64-slot pieces of a row unrolled: what depends on the lane only -- pixel, channel group,
+      // validity, byte offset inside the row -- is computed once per piece instead of once per (row, piece); an item is then a
+      // scalar row pointer, one 64-bit select and the DMA (the item loop below spends ~60 instructions per item, 9-11 k issue
+      // cycles per workgroup on the 80x80 maps: tools/bneck_stamps.py)
+      int voff[3];
+      bool lok[3], inrs[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const int sl = pc * 64 + lane;
+        const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
+        const int gx = ix0 + ix;
+        inrs[pc] = sl < RS;
+        lok[pc] = gx >= 0 && gx < a.W && ix < IW && cgs < CG;
+        voff[pc] = (ix * a.in_pitch + cgs * G) * (int)sizeof(T);
+      }
+      for (int iy = wave_s; iy < IH; iy += 4) {
+        const int gy = iy0 + iy;
+        const bool rok = gy >= 0 && gy < a.H;
+        const char* rowp = in_b + ((long)(n * a.H + (rok ? gy : 0)) * a.W + ix0) * a.in_pitch * (long)sizeof(T);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          if (pc < pcs) {   // wave-uniform
+            const char* src = (rok && lok[pc]) ? rowp + voff[pc] : zeros;
+            if (inrs[pc]) LP_GLDS16(src, tile + (iy * RS + pc * 64) * 16);
+          }
+        }
+      }
+    } else {
+      const int nitems = IH * pcs;
+      for (int it = wave_s; it < nitems; it += 4) {
+        const int iy = (int)(((unsigned)it * a.rcp_pcs) >> 16), pc = it - iy * pcs;
+        const int gy = iy0 + iy;
+        const char* rowp = in_b + ((long)(n * a.H + gy) * a.W + ix0) * a.in_pitch * (long)sizeof(T);
+        const int sl = pc * 64 + lane;
+        const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
+        const int gx = ix0 + ix;
+        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ix < IW && cgs < CG;
+        const char* src = ok ? rowp + (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : zeros;
+        if (sl < RS) LP_GLDS16(src, tile + (iy * RS + pc * 64) * 16);
+      }
     }
   }
   BN_STAMP(2)
