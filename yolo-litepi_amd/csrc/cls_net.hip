@@ -138,16 +138,40 @@ __device__ __forceinline__ void dwconv(const char* in, int irow, char* out, int 
 // channel_shuffle(cat(a, b), 2): logical channel 2c = a[c], 2c+1 = b[c]; each half of the stage tensor is padded to bfp
 __device__ __forceinline__ int shuffle_phys(int l, int bf, int bfp) { return l < bf ? l : bfp + (l - bf); }
 
+// pointwise biases of a stage's stride-1 blocks -> LDS [NB][2][BFP] (b1 | b2), once per stage: read from global where they
+// are used (right behind a GEMM) each was an exposed L2 round trip, two per block.  The caller's next barrier publishes them.
+template <int BFP, int NB>
+__device__ __forceinline__ void stage_biases(float* BI, const FusedBlockW* blk, int tid) {
+  constexpr int Q = BFP / 4;   // float4 per vector
+  for (int i = tid; i < NB * 2 * Q; i += CN_THREADS) {
+    const int b = i / (2 * Q), rem = i - b * 2 * Q, which = rem / Q, j = rem - which * Q;
+    const float* src = which ? blk[b].b2 : blk[b].b1;
+    *reinterpret_cast<floatx4*>(BI + (size_t)(b * 2 + which) * BFP + 4 * j) = *reinterpret_cast<const floatx4*>(src + 4 * j);
+  }
+}
+
 // stride-1 InvertedResidual on X[npx pixels][2*bfp] resident in LDS (in place): x_lo passes through, x_hi -> pw1+ReLU ->
 // dw3x3 -> pw2+ReLU, then channel_shuffle.  TT tiles of 16 channels, S K steps, the wave handles tile rounds
 // t = wave, wave + 8, .. with PT pixel tiles from p0.  f1 holds this block's pw1 fragments for the wave's FIRST round on
 // entry (loaded by the caller / the previous block) and the next block's on exit (w1n; nullptr: none).
 template <int BF, int BFP, int W, int PT, int ROUNDS, bool PREF = true>
 __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, int trow, const FusedBlockW& bw, const u32x4_t* w1n, int nroi,
-                                         int p0, int tile0, int tstride, u32x4 (&f1)[ROUNDS][BFP / 32 + ((BFP % 32) ? 1 : 0)], int tid) {
+                                         int p0, int tile0, int tstride, u32x4 (&f1)[ROUNDS][BFP / 32 + ((BFP % 32) ? 1 : 0)], int tid, float* DW, const float* BI) {
   constexpr int TT = BFP / 16, S = BFP / 32 + ((BFP % 32) ? 1 : 0);
   const int lane = tid & 63;
   const int g = lane >> 4, col = lane & 15;
+  // The block's depthwise parameters ([9][BFP] taps + [BFP] bias, fp32) go global -> registers NOW and -> LDS (DW) before the
+  // first barrier: the depthwise phase then reads them from LDS.  (Read from global inside the depthwise loop they were four
+  // dependent L2 round trips per item -- bias, then one per window row -- with one workgroup per CU and nothing to hide them:
+  // most of a block's ~6 us.)
+  constexpr int NDW4 = 10 * BFP / 4, DWPT = (NDW4 + CN_THREADS - 1) / CN_THREADS;
+  floatx4 dwreg[DWPT];
+#pragma unroll
+  for (int k = 0; k < DWPT; ++k) {
+    int idx = tid + k * CN_THREADS;
+    idx = idx < NDW4 ? idx : NDW4 - 1;
+    dwreg[k] = idx < 9 * BFP / 4 ? *reinterpret_cast<const floatx4*>(bw.dw + 4 * idx) : *reinterpret_cast<const floatx4*>(bw.dwb + 4 * (idx - 9 * BFP / 4));
+  }
   u32x4 f2[ROUNDS][S];
   floatx4 acc[ROUNDS][PT];
   // A wave whose round has no tile left (15 tiles over 8 waves) recomputes the last tile and skips the stores: loads and
@@ -177,7 +201,7 @@ __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, 
   for (int r = 0; r < ROUNDS; ++r) {
     zero_acc<PT>(acc[r]);
     gemm_acc<S, PT>(f1[r], S, 0, X + BFP * 2, xrow, BFP, p0, lane, acc[r]);
-    if (live[r]) store_relu<PT>(T1, trow, p0, tc[r], bw.b1, acc[r], lane);
+    if (live[r]) store_relu<PT>(T1, trow, p0, tc[r], BI, acc[r], lane);   // pw1's bias, staged in LDS by stage_biases()
   }
   asm volatile("" ::: "memory");
   if (PREF) {
@@ -189,9 +213,14 @@ __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, 
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) wload<S>(f2[r], bw.w2, tc[r], S, lane);
   }
+#pragma unroll
+  for (int k = 0; k < DWPT; ++k) {
+    const int idx = tid + k * CN_THREADS;
+    if (idx < NDW4) *reinterpret_cast<floatx4*>(DW + 4 * idx) = dwreg[k];
+  }
   __syncthreads();
   // ---- t2 = dw3x3(t1) + bd
-  dwconv<BFP, W, W, 1>(T1, trow, T2, trow, bw.dw, bw.dwb, nroi, tid);
+  dwconv<BFP, W, W, 1>(T1, trow, T2, trow, DW, DW + 9 * BFP, nroi, tid);
   __syncthreads();
   // ---- y = relu(W2 . t2 + b2); X = shuffle(cat(x_lo, y)) in place
   half4 x1v[ROUNDS][PT];
@@ -207,7 +236,7 @@ __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, 
   for (int r = 0; r < ROUNDS; ++r) {
     if (live[r]) {
       const int ch0 = tc[r] * 16 + 4 * g;
-      const floatx4 bias = *reinterpret_cast<const floatx4*>(bw.b2 + ch0);
+      const floatx4 bias = *reinterpret_cast<const floatx4*>(BI + BFP + ch0);
 #pragma unroll
       for (int p = 0; p < PT; ++p) {
 #pragma unroll
@@ -239,6 +268,8 @@ __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, 
 #define CF_POOL (CF_RA + 49152)
 #define CF_X2 (CF_POOL + 16384)
 #define CF_LDS (CF_X2 + 17408)
+#define CF_DW (10 * 64 * 4)      /* depthwise parameters of the running stride-1 block, fp32 [10][64], behind everything else */
+#define CF_BI (3 * 2 * 64 * 4)   /* pointwise biases of the stage's stride-1 blocks, fp32 [3][2][64] */
 #define CF_POOLROW 64
 #define CF_T1ROW 144   /* 64 ch x 2 B + 16 */
 #define CF_X2ROW 272   /* 128 ch x 2 B + 16 */
@@ -257,6 +288,7 @@ __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArg
   // X2's padding channels are never written by the shuffle stores and must read as zero
   for (int i = tid0; i < 64 * CF_X2ROW / 16; i += CN_THREADS) *reinterpret_cast<u32x4*>(X2 + i * 16) = u32x4{0u, 0u, 0u, 0u};
   if (tid0 < 2) *reinterpret_cast<u32x4*>(smem + (tid0 ? CF_IN + 12288 : 0)) = u32x4{0u, 0u, 0u, 0u};  // guards
+  stage_biases<BFP2, 3>(reinterpret_cast<float*>(smem + CF_LDS + CF_DW), a.s2, tid0);   // (published by the first barrier below)
   const half8 sa0 = __builtin_bit_cast(half8, a.stem_w[lane0]), sa1 = __builtin_bit_cast(half8, a.stem_w[64 + lane0]);
 
   for (int r = blockIdx.x; r < R; r += gridDim.x) {
@@ -393,7 +425,7 @@ __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArg
 #pragma unroll 1
     for (int b = 0; b < 3; ++b)
       s1_block<BF2, BFP2, 8, 2, 1>(X2, CF_X2ROW, RA, T2, CF_T1ROW, a.s2[b], b + 1 < 3 ? a.s2[b + 1].w1 : nullptr, 1, (wave >> 2) * 32, wave & 3,
-                                   4, f1, tid);
+                                   4, f1, tid, reinterpret_cast<float*>(smem + CF_LDS), reinterpret_cast<const float*>(smem + CF_LDS + CF_DW) + b * 2 * BFP2);
 
     // ================= stage3.0 (stride 2): 8x8x116 -> 4x4x232 =================
     char* T1c = RA;                         // [64 px][272]
@@ -454,6 +486,9 @@ __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArg
 #define CB_RC (CB_RB + 31744)
 #define CB_X4 (CB_RC + 17408)
 #define CB_LDS (CB_X4 + 15616)
+#define CB_DW (10 * 240 * 4)     /* depthwise parameters of the running stride-1 block, fp32 [10][<= 240] */
+#define CB_BI3 (7 * 2 * 128 * 4) /* pointwise biases of stage 3's stride-1 blocks, fp32 [7][2][128] */
+#define CB_BI (CB_BI3 + 3 * 2 * 240 * 4)  /* + stage 4's, fp32 [3][2][240] */
 #define CB_T3ROW 272   /* 128 ch x 2 + 16 */
 #define CB_T4ROW 496   /* 240 ch x 2 + 16 */
 #define CB_X4ROW 976   /* 480 ch x 2 + 16 */
@@ -471,6 +506,9 @@ __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs 
   char* X4 = smem + CB_X4;
   // X4's padding channels are never written by the shuffle stores and must read as zero
   for (int i = tid0; i < 16 * CB_X4ROW / 16; i += CN_THREADS) *reinterpret_cast<u32x4*>(X4 + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  // pointwise biases of both stages' stride-1 blocks, once per workgroup (published by the first barrier of the loop)
+  stage_biases<BFP3, 7>(reinterpret_cast<float*>(smem + CB_LDS + CB_DW), a.s3, tid0);
+  stage_biases<BFP4, 3>(reinterpret_cast<float*>(smem + CB_LDS + CB_DW + CB_BI3), a.s4, tid0);
 
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     // per-lane addresses must not be hoisted out of this loop: LICM otherwise keeps ~100 loop-invariant address registers
@@ -494,7 +532,8 @@ __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs 
     // ================= stage3.1-7 on 4 x (4x4) pixels =================
 #pragma unroll 1
     for (int b = 0; b < 7; ++b)
-      s1_block<BF3, BFP3, 4, 4, 1>(X3, CF_X3ROW, RB, RC, CB_T3ROW, a.s3[b], b + 1 < 7 ? a.s3[b + 1].w1 : nullptr, 4, 0, wave, 8, f3, tid);
+      s1_block<BF3, BFP3, 4, 4, 1>(X3, CF_X3ROW, RB, RC, CB_T3ROW, a.s3[b], b + 1 < 7 ? a.s3[b + 1].w1 : nullptr, 4, 0, wave, 8, f3, tid,
+                                   reinterpret_cast<float*>(smem + CB_LDS), reinterpret_cast<const float*>(smem + CB_LDS + CB_DW) + b * 2 * BFP3);
 
     // ================= stage4.0 (stride 2): 4 x (4x4x232) -> 4 x (2x2x464) =================
     char* T1 = RB;                       // [64 px][496]
@@ -567,7 +606,8 @@ __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs 
     // ================= stage4.1-3 on 4 x (2x2) pixels =================
 #pragma unroll 1
     for (int b = 0; b < 3; ++b)
-      s1_block<BF4, BFP4, 2, 1, 2, true>(X4, CB_X4ROW, RB, RB + 16 * CB_T4ROW, CB_T4ROW, a.s4[b], b + 1 < 3 ? a.s4[b + 1].w1 : nullptr, 4, 0, wave, 8, f4, tid);
+      s1_block<BF4, BFP4, 2, 1, 2, true>(X4, CB_X4ROW, RB, RB + 16 * CB_T4ROW, CB_T4ROW, a.s4[b], b + 1 < 3 ? a.s4[b + 1].w1 : nullptr, 4, 0, wave, 8, f4, tid,
+                                         reinterpret_cast<float*>(smem + CB_LDS), reinterpret_cast<const float*>(smem + CB_LDS + CB_DW + CB_BI3) + b * 2 * BFP4);
 
     // ================= conv5 1x1 (464 -> 1024) + ReLU, mean over the 2x2 map =================
     char* Mn = RC;                                              // [4 ROIs][1024] fp16
@@ -668,7 +708,7 @@ void launch_cls_front(const ClsFrontArgs& a, int max_items, hipStream_t st) {
   set_max_dynamic_lds(reinterpret_cast<const void*>(cls_front_kernel), 160 * 1024);
   int grid = max_items < 512 ? max_items : 512;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(cls_front_kernel, dim3(grid), dim3(CN_THREADS), CF_LDS, st, a);
+  hipLaunchKernelGGL(cls_front_kernel, dim3(grid), dim3(CN_THREADS), CF_LDS + CF_DW + CF_BI, st, a);
   LP_HIP(hipGetLastError());
 }
 
@@ -679,7 +719,7 @@ void launch_cls_back(const ClsBackArgs& a, int max_items, hipStream_t st) {
   int grid = (max_items + 3) / 4;
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(cls_back_kernel, dim3(grid), dim3(CN_THREADS), CB_LDS, st, a);
+  hipLaunchKernelGGL(cls_back_kernel, dim3(grid), dim3(CN_THREADS), CB_LDS + CB_DW + CB_BI, st, a);
   LP_HIP(hipGetLastError());
 }
 
