@@ -150,6 +150,14 @@ __device__ __forceinline__ void stage_biases(float* BI, const FusedBlockW* blk, 
   }
 }
 
+// depthwise parameters of a stride-2 block ([9][C] taps + [C] bias, fp32) -> LDS [10][C], once per workgroup
+template <int C>
+__device__ __forceinline__ void stage_dw(float* dst, const float* __restrict__ w, const float* __restrict__ b, int tid) {
+  constexpr int Q = 10 * C / 4;
+  for (int i = tid; i < Q; i += CN_THREADS)
+    *reinterpret_cast<floatx4*>(dst + 4 * i) = i < 9 * C / 4 ? *reinterpret_cast<const floatx4*>(w + 4 * i) : *reinterpret_cast<const floatx4*>(b + 4 * (i - 9 * C / 4));
+}
+
 // stride-1 InvertedResidual on X[npx pixels][2*bfp] resident in LDS (in place): x_lo passes through, x_hi -> pw1+ReLU ->
 // dw3x3 -> pw2+ReLU, then channel_shuffle.  TT tiles of 16 channels, S K steps, the wave handles tile rounds
 // t = wave, wave + 8, .. with PT pixel tiles from p0.  f1 holds this block's pw1 fragments for the wave's FIRST round on
@@ -270,6 +278,7 @@ __device__ __forceinline__ void s1_block(char* X, int xrow, char* T1, char* T2, 
 #define CF_LDS (CF_X2 + 17408)
 #define CF_DW (10 * 64 * 4)      /* depthwise parameters of the running stride-1 block, fp32 [10][64], behind everything else */
 #define CF_BI (3 * 2 * 64 * 4)   /* pointwise biases of the stage's stride-1 blocks, fp32 [3][2][64] */
+#define CF_S2 ((10 * 24 + 10 * 64 + 10 * 128 + 10 * 128) * 4)   /* depthwise parameters of stage2.0 (24 | 64 ch) and stage3.0 (128 | 128) */
 #define CF_POOLROW 64
 #define CF_T1ROW 144   /* 64 ch x 2 B + 16 */
 #define CF_X2ROW 272   /* 128 ch x 2 B + 16 */
@@ -289,6 +298,11 @@ __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArg
   for (int i = tid0; i < 64 * CF_X2ROW / 16; i += CN_THREADS) *reinterpret_cast<u32x4*>(X2 + i * 16) = u32x4{0u, 0u, 0u, 0u};
   if (tid0 < 2) *reinterpret_cast<u32x4*>(smem + (tid0 ? CF_IN + 12288 : 0)) = u32x4{0u, 0u, 0u, 0u};  // guards
   stage_biases<BFP2, 3>(reinterpret_cast<float*>(smem + CF_LDS + CF_DW), a.s2, tid0);   // (published by the first barrier below)
+  float* S2P = reinterpret_cast<float*>(smem + CF_LDS + CF_DW + CF_BI);   // stride-2 blocks' depthwise parameters, as above
+  stage_dw<24>(S2P, a.s20.dw1, a.s20.dw1b, tid0);
+  stage_dw<64>(S2P + 240, a.s20.dw2, a.s20.dw2b, tid0);
+  stage_dw<128>(S2P + 240 + 640, a.s30.dw1, a.s30.dw1b, tid0);
+  stage_dw<128>(S2P + 240 + 640 + 1280, a.s30.dw2, a.s30.dw2b, tid0);
   const half8 sa0 = __builtin_bit_cast(half8, a.stem_w[lane0]), sa1 = __builtin_bit_cast(half8, a.stem_w[64 + lane0]);
 
   for (int r = blockIdx.x; r < R; r += gridDim.x) {
@@ -393,10 +407,10 @@ __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArg
       gemm_acc<1, 8>(fpw1, 1, 0, POOL, CF_POOLROW, 24, p0, lane, acc);
       store_relu<8>(T1, CF_T1ROW, p0, t, a.s20.pw1b, acc, lane);
       if (wave < 4) wload<2>(fy, a.s20.pwb1, t, 1, lane); else wload<2>(fy, a.s20.pw2, t, 2, lane);
-      dwconv<24, 16, 8, 2>(POOL, CF_POOLROW, D1, 64, a.s20.dw1, a.s20.dw1b, 1, tid);
+      dwconv<24, 16, 8, 2>(POOL, CF_POOLROW, D1, 64, S2P, S2P + 9 * 24, 1, tid);
     }
     __syncthreads();
-    dwconv<64, 16, 8, 2>(T1, CF_T1ROW, T2, CF_T1ROW, a.s20.dw2, a.s20.dw2b, 1, tid);
+    dwconv<64, 16, 8, 2>(T1, CF_T1ROW, T2, CF_T1ROW, S2P + 240, S2P + 240 + 9 * 64, 1, tid);
     __syncthreads();
     u32x4 f1[1][2];
     {
@@ -442,9 +456,9 @@ __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArg
       zero_acc<4>(acc);
       gemm_acc<4, 4>(fa, 4, 0, X2, CF_X2ROW, 128, 0, lane, acc);
       store_relu<4>(T1c, CF_X2ROW, 0, wave, a.s30.pw1b, acc, lane);
-      dwconv<128, 8, 4, 2>(X2, CF_X2ROW, D1c, CF_X2ROW, a.s30.dw1, a.s30.dw1b, 1, tid);
+      dwconv<128, 8, 4, 2>(X2, CF_X2ROW, D1c, CF_X2ROW, S2P + 880, S2P + 880 + 9 * 128, 1, tid);
       __syncthreads();
-      dwconv<128, 8, 4, 2>(T1c, CF_X2ROW, T2c, CF_X2ROW, a.s30.dw2, a.s30.dw2b, 1, tid);
+      dwconv<128, 8, 4, 2>(T1c, CF_X2ROW, T2c, CF_X2ROW, S2P + 2160, S2P + 2160 + 9 * 128, 1, tid);
       __syncthreads();
       floatx4 y1[1], y2[1];
       zero_acc<1>(y1);
@@ -489,6 +503,7 @@ __global__ __launch_bounds__(CN_THREADS) void cls_front_kernel(const ClsFrontArg
 #define CB_DW (10 * 240 * 4)     /* depthwise parameters of the running stride-1 block, fp32 [10][<= 240] */
 #define CB_BI3 (7 * 2 * 128 * 4) /* pointwise biases of stage 3's stride-1 blocks, fp32 [7][2][128] */
 #define CB_BI (CB_BI3 + 3 * 2 * 240 * 4)  /* + stage 4's, fp32 [3][2][240] */
+#define CB_S2 ((10 * 256 + 10 * 240) * 4)  /* depthwise parameters of stage4.0: branch1 over 256 physical channels | branch2 over 240 */
 #define CB_T3ROW 272   /* 128 ch x 2 + 16 */
 #define CB_T4ROW 496   /* 240 ch x 2 + 16 */
 #define CB_X4ROW 976   /* 480 ch x 2 + 16 */
@@ -509,6 +524,9 @@ __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs 
   // pointwise biases of both stages' stride-1 blocks, once per workgroup (published by the first barrier of the loop)
   stage_biases<BFP3, 7>(reinterpret_cast<float*>(smem + CB_LDS + CB_DW), a.s3, tid0);
   stage_biases<BFP4, 3>(reinterpret_cast<float*>(smem + CB_LDS + CB_DW + CB_BI3), a.s4, tid0);
+  float* S2P = reinterpret_cast<float*>(smem + CB_LDS + CB_DW + CB_BI);   // stage4.0's depthwise parameters
+  stage_dw<256>(S2P, a.s40.dw1, a.s40.dw1b, tid0);
+  stage_dw<240>(S2P + 2560, a.s40.dw2, a.s40.dw2b, tid0);
 
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     // per-lane addresses must not be hoisted out of this loop: LICM otherwise keeps ~100 loop-invariant address registers
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs 
         u32x4 fb[2][8];
         wload<8>(fb[0], a.s40.pwb1, t0, 8, lane);
         wload<8>(fb[1], a.s40.pwb1, t1, 8, lane);
-        dwconv<256, 4, 2, 2>(X3, CF_X3ROW, D1, CF_X3ROW, a.s40.dw1, a.s40.dw1b, 4, tid);
+        dwconv<256, 4, 2, 2>(X3, CF_X3ROW, D1, CF_X3ROW, S2P, S2P + 9 * 256, 4, tid);
         __syncthreads();
         zero_acc<1>(y1[0]);
         zero_acc<1>(y1[1]);
@@ -575,7 +593,7 @@ __global__ __launch_bounds__(CN_THREADS) void cls_back_kernel(const ClsBackArgs 
       wload<8>(fc[0], a.s40.pw2, t0, 8, lane);
       wload<8>(fc[1], a.s40.pw2, t1, 8, lane);
       __syncthreads();
-      dwconv<240, 4, 2, 2>(T1, CB_T4ROW, T2, CB_T4ROW, a.s40.dw2, a.s40.dw2b, 4, tid);
+      dwconv<240, 4, 2, 2>(T1, CB_T4ROW, T2, CB_T4ROW, S2P + 2560, S2P + 2560 + 9 * 240, 4, tid);
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -708,7 +726,7 @@ void launch_cls_front(const ClsFrontArgs& a, int max_items, hipStream_t st) {
   set_max_dynamic_lds(reinterpret_cast<const void*>(cls_front_kernel), 160 * 1024);
   int grid = max_items < 512 ? max_items : 512;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(cls_front_kernel, dim3(grid), dim3(CN_THREADS), CF_LDS + CF_DW + CF_BI, st, a);
+  hipLaunchKernelGGL(cls_front_kernel, dim3(grid), dim3(CN_THREADS), CF_LDS + CF_DW + CF_BI + CF_S2, st, a);
   LP_HIP(hipGetLastError());
 }
 
@@ -719,7 +737,7 @@ void launch_cls_back(const ClsBackArgs& a, int max_items, hipStream_t st) {
   int grid = (max_items + 3) / 4;
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(cls_back_kernel, dim3(grid), dim3(CN_THREADS), CB_LDS + CB_DW + CB_BI, st, a);
+  hipLaunchKernelGGL(cls_back_kernel, dim3(grid), dim3(CN_THREADS), CB_LDS + CB_DW + CB_BI + CB_S2, st, a);
   LP_HIP(hipGetLastError());
 }
 
