@@ -178,7 +178,7 @@ __device__ __forceinline__ void store_quad(const ConvArgs& a, long pix, int ch0,
 // results leave as 16-byte stores (two channel quads at a time).
 template <typename T, int NT, int ACT>
 __device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int Cout, const floatx4 (&v)[NT], const floatx4 (&bias)[NT],
-                                              bool res_first = false);
+                                              bool res_first = false, const typename Tr<T>::quad* rq = nullptr);
 
 template <typename T, int NT, int ACT>
 __device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chbase, const floatx4 (&v)[NT],
@@ -191,13 +191,14 @@ __device__ __forceinline__ void store_lane(const ConvArgs& a, long pix, int chba
 // o / r already point at this lane's first channel of the pixel
 template <typename T, int NT, int ACT>
 __device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int Cout, const floatx4 (&v)[NT], const floatx4 (&bias)[NT],
-                                              bool res_first) {
+                                              bool res_first, const typename Tr<T>::quad* rq) {
+  // rq != nullptr: the residual quads were loaded by the caller (registers, rq[t] = channels chbase + 4t ..); r only says "there is one"
   if (res_first && r) {
     // ResNet BasicBlock: out = act(conv + bias + identity) (torchvision resnet.py BasicBlock.forward), the sum in fp32
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (chbase + t * 4 < Cout) {
-        const typename Tr<T>::quad rr = *reinterpret_cast<const typename Tr<T>::quad*>(r + t * 4);
+        const typename Tr<T>::quad rr = rq ? rq[t] : *reinterpret_cast<const typename Tr<T>::quad*>(r + t * 4);
         const floatx4 y = act4<T, ACT>(v[t] + floatx4{(float)rr[0], (float)rr[1], (float)rr[2], (float)rr[3]}, bias[t]);
         typename Tr<T>::quad q;
 #pragma unroll
@@ -219,7 +220,13 @@ __device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int 
           q[4 + i] = (half_t)y1[i];
         }
         if (r) {
-          const half8 rr = *reinterpret_cast<const half8*>(r + t * 4);
+          half8 rr;
+          if (rq) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { rr[i] = rq[t][i]; rr[4 + i] = rq[t + 1][i]; }
+          } else {
+            rr = *reinterpret_cast<const half8*>(r + t * 4);
+          }
 #pragma unroll
           for (int i = 0; i < 8; ++i) q[i] = (half_t)((float)q[i] + (float)rr[i]);
         }
@@ -234,7 +241,7 @@ __device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int 
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = (half_t)y0[i];
         if (r) {
-          const half4 rr = *reinterpret_cast<const half4*>(r + t * 4);
+          const half4 rr = rq ? rq[t] : *reinterpret_cast<const half4*>(r + t * 4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) q[i] = (half_t)((float)q[i] + (float)rr[i]);
         }
@@ -247,7 +254,7 @@ __device__ __forceinline__ void store_lane_at(T* o, const T* r, int chbase, int 
       if (chbase + t * 4 < Cout) {
         floatx4 q = act4<T, ACT>(v[t], bias[t]);
         if (r) {
-          const floatx4 rr = *reinterpret_cast<const floatx4*>(r + t * 4);
+          const floatx4 rr = rq ? rq[t] : *reinterpret_cast<const floatx4*>(r + t * 4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) q[i] += rr[i];
         }
@@ -326,13 +333,35 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, const floatx4 (
   T* o = reinterpret_cast<T*>(a.out) + eoff(pix0, a.out_pitch) + chbase;
   const T* r = a.res ? reinterpret_cast<const T*>(a.res) + eoff(pix0, a.res_pitch) + chbase : nullptr;
   const int ostep = 4 * a.out_pitch, rstep = 4 * a.res_pitch;
+  if (r) {
+    // the residual quads of all five patches are requested before the first is used (unconditional, from clamped addresses:
+    // patch 0 / quad 0 stand in for what lies outside): as `if (r) load` inside the patch loop they were five dependent
+    // memory round trips in a kernel whose grids are a single round of workgroups
+    typename Tr<T>::quad rq[5][NT];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      const T* rp = r - chbase + (oxb + p * 4 < a.Wout ? p * rstep : 0);   // channel 0 of the patch's pixel
+#pragma unroll
+      for (int t = 0; t < NT; ++t) rq[p][t] = *reinterpret_cast<const typename Tr<T>::quad*>(rp + (chbase + t * 4 < a.Cout ? chbase + t * 4 : 0));
+    }
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      if (oxb + p * 4 < a.Wout) {
+        floatx4 v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = acc[t][p];
+        store_lane_at<T, NT, ACT>(o + p * ostep, r, chbase, a.Cout, v, bias, a.res_first != 0, rq[p]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int p = 0; p < 5; ++p) {
     if (oxb + p * 4 < a.Wout) {
       floatx4 v[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) v[t] = acc[t][p];
-      store_lane_at<T, NT, ACT>(o + p * ostep, r ? r + p * rstep : nullptr, chbase, a.Cout, v, bias, a.res_first != 0);
+      store_lane_at<T, NT, ACT>(o + p * ostep, nullptr, chbase, a.Cout, v, bias, a.res_first != 0);
     }
   }
 }
