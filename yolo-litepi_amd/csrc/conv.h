@@ -65,6 +65,9 @@ struct BottleneckPair {
     const std::vector<float>* bias = nullptr;
   };
   int T2 = 0, C3 = 0, act3 = ACT_NONE, kg = 0, sg = 0;
+  // pixel tiles (of 16) per wave in conv_a / conv_b = the kernel's P1 / P2 template arguments
+  int p1() const { return (((TH + 2) * (TW + 2) + 15) / 16 + 3) / 4; }
+  int p2() const { return ((TH * TW + 15) / 16 + 3) / 4; }
   DevBuf d_w3, d_b3;
   // can a C->C bottleneck on an h x w map (batch_hint images) run fused?  (LDS capacity, tile limits); cv2 = nullptr: without tail
   static bool supported(int prec, int impl, int c_phys, int h, int w, int batch_hint, const Cv2* cv2 = nullptr);

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
   if (a.stamps && threadIdx.x == 0)                                                                                 \
     a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = ((k) == 0 || (k) == 15) ? wall_clock64() : clock64();
 template <typename T, int NT, int P1, int P2, bool SEP, int T2 = 0, int SG = 0>
-__global__ __launch_bounds__(256, (NT >= 4 ? 2 : 3)) void bottleneck_mfma_kernel(const BneckArgs a) {
+__global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5)) ? 2 : 3)) void bottleneck_mfma_kernel(const BneckArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2009,14 +2009,21 @@ bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, size_t 
   const int steps = ceil_div(9 * cg, 4);
   if (steps * 4 > 128) return false;
   const int pss = lds_pixel_slots(cg);
-  const int cand[4][2] = {{16, 40}, {8, 40}, {8, 20}, {4, 20}};
+  // 20x40 / 10x20: 8 tiles on an 80x80 / 40x40 map -- 512 workgroups for a batch of 64, exactly two per CU, instead of 640 (2.5
+  // per CU: the CUs that get three decide the kernel time of these single-round grids)
+  const int cand[6][2] = {{20, 40}, {16, 40}, {10, 20}, {8, 40}, {8, 20}, {4, 20}};
   const int B = batch_hint > 0 ? batch_hint : 1;
   const bool sep = nt == 1;  // separate LDS region for the intermediate (see the kernel's SEP)
   long best = -1;
   for (auto& cd : cand) {
     const int TH = cd[0], TW = cd[1];
     static const bool no_big = getenv("LITEPI_BNECK_SMALL") != nullptr;  // A/B switch
-    if (TH == 16 && (nt != 1 || no_big)) continue;  // 12 + 10 pixel tiles per wave: only the single-channel-tile variant has the registers
+    if (TH >= 16 && (nt != 1 || no_big)) continue;  // 12 + 10 (15 + 13) pixel tiles per wave: only the single-channel-tile variant has the registers
+    if (TH == 10 && nt > 2) continue;               // 5 + 4 pixel tiles per wave: instantiated for one and two channel tiles
+    // the balanced shapes pay only where they turn the grid into ONE full round (two workgroups on each of the 256 CUs of an
+    // MI355X); on larger grids the smaller tiles' extra rounds overlap better (160x160: 50 us with 16x40, 57 us with 20x40)
+    static const bool no_balanced = getenv("LITEPI_BNECK_NO_BALANCED") != nullptr;  // A/B switch
+    if ((TH == 20 || TH == 10) && (no_balanced || (long)ceil_div(h, TH) * ceil_div(w, TW) * B > 512)) continue;
     if (tail && TH == 4) continue;                  // no cv2 instantiation for the smallest tile
     int l = TW + 4;
     if (cg <= 1) while (l % 16 != 2) ++l;  // one K group per pixel: 16 consecutive pixels x 4 taps conflict-free
@@ -2072,7 +2079,7 @@ void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, 
   rcp_pcs = rcp16(ceil_div(LW * (PS / 16), 64), 1024);
   rcp_w1 = rcp16(TW + 2, 1024);
   rcp_tw = rcp16(TW, 1024);
-  LP_CHECK((TH + 2) * (TW + 2) <= 12 * 4 * 16 && TH * TW <= 10 * 4 * 16, LP_ERR_STATE, "bottleneck tile exceeds the kernel's pixel-tile budget");
+  LP_CHECK((TH + 2) * (TW + 2) <= p1() * 4 * 16 && TH * TW <= p2() * 4 * 16, LP_ERR_STATE, "bottleneck tile exceeds the kernel's pixel-tile budget");
   if (cv2) {
     // cv2 fragments [T2][sg + SR][lane][G]: K steps 0..sg-1 walk the stored concat channels (group q = 4s+g), the
     // last SR steps the channels this lane's accumulators hold (same mapping as ConvLayer::attach_tail)
@@ -2145,9 +2152,15 @@ static void launch_bneck_t(const BneckArgs& a, int t2, dim3 grid, size_t lds, hi
 // pixel tiles per wave = ceil(ceil(region / 16) / 4 waves) for the tile shapes of plan()
 template <typename T, int NT>
 static void launch_bneck(const BneckArgs& a, int t2, dim3 grid, size_t lds, hipStream_t st) {
-  if (a.TH == 16 && a.TW == 40) {                                                        // 18x42 = 48 tiles, 16x40 = 40
+  if (a.TH == 20 && a.TW == 40) {                                                        // 22x42 = 58 tiles, 20x40 = 50
+    if constexpr (NT == 1) launch_bneck_t<T, 1, 15, 13>(a, t2, grid, lds, st);
+    else throw Error(LP_ERR_STATE, "bottleneck: 20x40 tiles need NT == 1");
+  } else if (a.TH == 16 && a.TW == 40) {                                                 // 18x42 = 48 tiles, 16x40 = 40
     if constexpr (NT == 1) launch_bneck_t<T, 1, 12, 10>(a, t2, grid, lds, st);
     else throw Error(LP_ERR_STATE, "bottleneck: 16x40 tiles need NT == 1");
+  } else if (a.TH == 10 && a.TW == 20) {                                                 // 12x22 = 17 tiles, 10x20 = 13
+    if constexpr (NT <= 2) launch_bneck_t<T, NT, 5, 4>(a, t2, grid, lds, st);
+    else throw Error(LP_ERR_STATE, "bottleneck: 10x20 tiles need NT <= 2");
   } else if (a.TH == 8 && a.TW == 40) launch_bneck_t<T, NT, 7, 5>(a, t2, grid, lds, st);  // 10x42 = 27 tiles, 8x40 = 20
   else if (a.TH == 8 && a.TW == 20) launch_bneck_t<T, NT, 4, 3>(a, t2, grid, lds, st);    // 10x22 = 14 tiles, 8x20 = 10
   else if (a.TH == 4 && a.TW == 20) launch_bneck_t<T, NT, 3, 2>(a, t2, grid, lds, st);    //  6x22 =  9 tiles, 4x20 = 5

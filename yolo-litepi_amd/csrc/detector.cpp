@@ -977,8 +977,7 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         }
         {  // one name per kernel instantiation <NT, P1, P2, T2, SG> (what rocprofv3 lists as separate kernels)
           const BottleneckPair& bp = *bnecks_[op.conv];
-          const int p1 = bp.TH == 16 ? 12 : (bp.TW == 40 ? 7 : (bp.TH == 8 ? 4 : 3)), p2 = bp.TH == 16 ? 10 : (bp.TW == 40 ? 5 : (bp.TH == 8 ? 3 : 2));
-          kname = fmt("bottleneck3x3x2<%d,%d,%d,%d,%d>", bp.NT, p1, p2, bp.T2, (bp.T2 > 0 && prec_ == LP_FP16) ? bp.sg : 0) + sfx;
+          kname = fmt("bottleneck3x3x2<%d,%d,%d,%d,%d>", bp.NT, bp.p1(), bp.p2(), bp.T2, (bp.T2 > 0 && prec_ == LP_FP16) ? bp.sg : 0) + sfx;
         }
         break;
       case DetOp::DWCONV:
