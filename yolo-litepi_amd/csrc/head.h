@@ -28,12 +28,7 @@ struct HeadArgs {
   int KPT;                 // K steps (of 16 channels) per 3x3 tap of the first convs = Cin / 16
   int nchunks;             // weight-stream chunks
   int A, nc, anchor_off;
-  int nrep;                // copies of the weight stream
-  unsigned rep_stride;     // bytes between copies
   unsigned long long* stamps;  // diagnostic only (LITEPI_HEAD_STAMPS=<file>): 16 clock stamps per workgroup
-  unsigned short coff[64]; // first fragment of chunk c in the stream
-  unsigned char csz[64];   // fragments in chunk c (<= 12 = one ring slot)
-  unsigned char cks[64];   // K steps in chunk c (a multiple of 3)
 };
 
 // One level's weights re-packed for head_fused_kernel.
@@ -43,8 +38,6 @@ struct HeadLayer {
   std::vector<unsigned short> coff;
   std::vector<unsigned char> csz, cks;
   DevBuf d_stream, d_biasA, d_biasB, d_biasC;
-  int nrep = 1;
-  size_t rep_stride = 0;
   size_t lds_bytes = 0;
   std::string name;
   double macs_per_image = 0;

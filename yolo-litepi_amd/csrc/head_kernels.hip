@@ -630,11 +630,8 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   nchunks = (int)coff.size();
   LP_CHECK(nchunks <= 64 && stream.size() / 512 < 65536, LP_ERR_STATE, "Detect head: weight stream too long (%d chunks)", nchunks);
   stream.resize(stream.size() + (size_t)2 * SLOTF * 512, 0);   // the ring requests two chunks past the end
-  nrep = getenv("LITEPI_HEAD_REPL") ? std::max(1, atoi(getenv("LITEPI_HEAD_REPL"))) : 8;
-  rep_stride = (stream.size() * 2 + 4096 + 255) & ~(size_t)255;
-  d_stream.alloc(rep_stride * nrep + 64);
-  for (int j = 0; j < nrep; ++j)
-    LP_HIP(hipMemcpy(d_stream.as<char>() + (size_t)j * rep_stride, stream.data(), stream.size() * 2, hipMemcpyHostToDevice));
+  d_stream.alloc(stream.size() * 2 + 64);   // (one copy: replicating the stream per XCD changed nothing -- it is L2-resident)
+  LP_HIP(hipMemcpy(d_stream.p, stream.data(), stream.size() * 2, hipMemcpyHostToDevice));
   std::vector<float> bA(32 * RT + 16, 0.f), bB(32 * RT + 16, 0.f), bC(64 + 32 + 16, 0.f);
   for (int c = 0; c < 64; ++c) { bA[c] = (*s.ba)[c]; bB[c] = s.bbb->empty() ? 0.f : (*s.bbb)[c]; bC[c] = s.bpb->empty() ? 0.f : (*s.bpb)[c]; }
   for (int c = 0; c < c3; ++c) { bA[64 + c] = (*s.ba)[64 + c]; bB[64 + c] = s.bbc->empty() ? 0.f : (*s.bbc)[c]; }
@@ -660,10 +657,8 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
   a.N = N; a.H = in.H; a.W = in.W; a.Cin = Cin;
   a.TH = TH; a.TW = TW; a.tiles_x = ceil_div(in.W, TW); a.ntiles = a.tiles_x * ceil_div(in.H, TH);
   a.KPT = KPT; a.nchunks = nchunks; a.A = A; a.nc = nc; a.anchor_off = anchor_off;
-  a.nrep = nrep; a.rep_stride = (unsigned)rep_stride;
   LP_CHECK(in.C == Cin && in.H == H && in.W == W && (int)coff.size() <= 64, LP_ERR_STATE,
            "Detect head %s: view does not match the plan", name.c_str());
-  for (size_t i = 0; i < coff.size(); ++i) { a.coff[i] = coff[i]; a.csz[i] = csz[i]; a.cks[i] = cks[i]; }
   const dim3 grid((unsigned)(a.ntiles * N));
   static const char* stamp_path = getenv("LITEPI_HEAD_STAMPS");
   DevBuf d_stamps;
