@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Per-phase cycle medians of the whole-C2f launches from a LITEPI_C2F_STAMPS=<file> dump (c2f_kernels.hip, C2F_STAMP):
+stamp 1 start, 2 after the entry conv, 3 after cv1, 4 after the bottlenecks, 5 after cv2, 6 after the SPPF pools, 7 end
+(clock64 cycles); 0 / 15 wall clock (100 MHz ticks)."""
+import sys
+import numpy as np
+
+name, rows, out = None, [], {}
+for ln in open(sys.argv[1]):
+    if ln.startswith("#"):
+        if name and rows:
+            out.setdefault(name, []).append(np.array(rows, dtype=np.int64))
+        name, rows = ln.split()[1], []
+    else:
+        rows.append([int(x) for x in ln.split()])
+if name and rows:
+    out.setdefault(name, []).append(np.array(rows, dtype=np.int64))
+labels = ["s2", "cv1", "bnecks", "cv2", "pools", "tail"]
+for k, runs in out.items():
+    a = runs[-1]
+    d = [np.median(a[:, i + 1] - a[:, i]) for i in range(1, 7)]
+    wall = np.median(a[:, 15] - a[:, 0]) / 100.0
+    span = (a[:, 15].max() - a[:, 0].min()) / 100.0
+    order = np.argsort(a[:, 0])
+    dur = (a[:, 15] - a[:, 0]) / 100.0
+    first, rest = dur[order[:256]], dur[order[256:]]
+    extra = f"  first-256 wall {np.median(first):6.1f}" + (f" later {np.median(rest):6.1f}" if len(rest) else "")
+    print(f"{k:<44} wgs {len(a):5d}  " + "  ".join(f"{l} {v:8.0f}" for l, v in zip(labels, d)) + f"   wg wall {wall:6.1f} us, launch span {span:6.1f} us" + extra)

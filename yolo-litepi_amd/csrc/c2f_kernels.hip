@@ -1,0 +1,871 @@
+// Whole-C2f launches for gfx950 (fp16 storage, fp32 accumulate).  One workgroup (8 waves) owns a 20x20 tile of one image
+// -- the whole image on the 20x20 level -- and runs every layer of a C2f module of the reference graph
+// (model.ncnn.param: cv1 -> Slice -> n x [3x3 -> 3x3 -> add] -> Concat -> cv2) back to back:
+//
+//   [s2]   3x3 stride-2 conv + SiLU in front of the module            (whole-image configurations only)
+//   cv1    1x1 + SiLU over concat(src0 [nearest-x2 upsampled], src1)  -> y0 | y1
+//   a_k    3x3 + SiLU on y_{k+1}                                     -> mid          (LDS -> LDS)
+//   b_k    3x3 + SiLU on mid, + y_{k+1}                              -> y_{k+2}      (LDS -> LDS, in place of y_{k+1})
+//   cv2    1x1 + SiLU over concat(y0 .. y_{n+1})                     -> out
+//   [sppf] cv1 -> 5x5 max pool x3 -> cv2                              (whole-image configuration of the backbone's last stage)
+//
+// Data movement rule: ONLY what a 3x3 stride-1 conv (or a pool) reads lives in LDS -- two planes of c channels over the
+// tile + halo frame.  Every 1x1 conv takes its pixel operand straight from global memory / L2 (16 B per lane = the MFMA B
+// fragment of one pixel's 8 channels), including tensors this workgroup stored a phase earlier (y0 .. y_{n+1} go through the
+// module's concat buffer, which exists anyway): the concat is an address, never a copy, and the LDS budget does not depend
+// on the module's width.  Weights never touch LDS either: each wave streams the A fragments of its channel block from L2
+// one K step ahead of the MFMAs.
+//
+// MFMA: v_mfma_f32_16x16x32_f16, D[out-channel][pixel] = W . X, a wave owns NT channel tiles x PT pixel tiles.  A pixel tile
+// is 16 consecutive pixels of the phase's (image-clipped) region, row-major.  LDS pixel pitch = 2c + 16 bytes (an odd number
+// of 16-byte slots); column `col` of the tile holds pixel offset sig(col) with sig = even offsets for the lanes
+// {0-3, 12-15} and odd offsets for {4-11}, and K group g reads channel group gam(g) = {0, 2, 1, 3}: inside every
+// ds_read_b128 lane group ({0-3,12-15,20-27}, ..) the 16 lanes then hit 16 distinct 16-byte slots -- conflict-free
+// fragment reads without padding rows (MI355X guide, LDS).
+#include "c2f.h"
+
+#include <cstdlib>
+
+namespace lp {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
+constexpr int min_c(int a, int b) { return a < b ? a : b; }
+
+template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_>
+struct C2fCfg {
+  static constexpr int C = C_, NB = NB_, KA = KA_, KB = KB_, COUT = COUT_, MODE = MODE_, KS2 = KS2_;
+  static constexpr bool UP = UP_;
+  static constexpr bool PERIMG = MODE_ >= 1;   // the tile is the whole image: no halo recompute, a 1-pixel zero ring
+  static constexpr int NW = 8;                 // waves per workgroup
+  static constexpr int TH = 20, TW = 20;
+  static constexpr int F = PERIMG ? 1 : 2 * NB;  // frame margin around the tile
+  static constexpr int LW = TW + 2 * F, LH = TH + 2 * F;
+  static constexpr int PS = 2 * C + 16;          // bytes per LDS pixel
+  static constexpr int PLANE = LW * LH * PS;
+  static constexpr int XC = 2 * C;               // output channels of the entry conv
+  // how far each phase's region extends beyond the tile
+  static constexpr int e_cv1 = PERIMG ? 0 : 2 * NB;
+  static constexpr int e_a(int k) { return PERIMG ? 0 : 2 * (NB - k) - 1; }
+  static constexpr int e_b(int k) { return PERIMG ? 0 : 2 * (NB - k) - 2; }
+  static constexpr int npt(int e) { return cdiv_c((TH + 2 * e) * (TW + 2 * e), 16); }
+  // block shapes (NT channel tiles x PT pixel tiles per wave, CB channel blocks): one round of blocks per phase
+  static constexpr int cap_pt(int nt, int pt) { return nt * pt > 20 ? cdiv_c(pt, 2) : pt; }   // two rounds of blocks rather than spills
+  static constexpr int CT1 = 2 * C / 16, NT1 = min_c(CT1, 4), CB1 = CT1 / NT1, PT1 = cap_pt(NT1, cdiv_c(npt(e_cv1), NW / CB1));
+  static constexpr int CTM = C / 16, NTM = min_c(CTM, 2), CBM = CTM / NTM;
+  static constexpr int ptm(int e) { return cdiv_c(npt(e), NW / CBM); }
+  static constexpr int CT2 = COUT / 16, NT2 = CT2 >= 2 ? CT2 / 2 : 1, CB2 = CT2 / NT2, PT2 = cap_pt(NT2, cdiv_c(npt(0), NW / CB2));
+  static constexpr int WPS = C >= 32 ? 2 : 4;   // waves per SIMD the register allocation must allow (c = 16: two workgroups per CU)
+  static constexpr int NTS = min_c(C / 16, 2), CBS = (C / 16) / NTS, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
+  static C2fShape shape() {
+    C2fShape s;
+    s.C = C; s.NB = NB; s.KA = KA; s.KB = KB; s.UP = UP ? 1 : 0; s.COUT = COUT; s.MODE = MODE; s.KS2 = KS2;
+    return s;
+  }
+};
+
+struct Ctx {
+  int n, oy0, ox0, H, W;
+  int lane, wave, g, sig, gam;
+};
+struct Rg {
+  int gy0, gx0, fy0, fx0, rh, rw, R;
+  unsigned magic;
+};
+
+#define C2F_STAMP(k) \
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = ((k) == 0 || (k) == 15) ? wall_clock64() : clock64();
+
+__device__ __forceinline__ floatx4 mma16(half8 a, half8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ half8 as_h8(u32x4 v) { return __builtin_bit_cast(half8, v); }
+
+// x * sigmoid(x) of (v + b), the arithmetic of act4<T, ACT_SILU> in conv_kernels.hip (hardware exp2 / rcp, two-wide multiplies)
+__device__ __forceinline__ floatx4 silu4(floatx4 v, floatx4 b) {
+  v = v + b;
+  const floatx4 t = v * -1.4426950408889634f;
+  floatx4 e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(t[i]);
+  e = e + 1.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+  return v * e;
+}
+
+template <class CFG> __device__ __forceinline__ Rg make_region(const Ctx& cx, int E) {
+  Rg r;
+  const int y0 = max(cx.oy0 - E, 0), y1 = min(cx.oy0 + CFG::TH + E, cx.H);
+  const int x0 = max(cx.ox0 - E, 0), x1 = min(cx.ox0 + CFG::TW + E, cx.W);
+  r.gy0 = y0; r.gx0 = x0;
+  r.rh = y1 - y0; r.rw = x1 - x0;
+  r.R = r.rh * r.rw;
+  r.fy0 = y0 - (cx.oy0 - CFG::F);
+  r.fx0 = x0 - (cx.ox0 - CFG::F);
+  r.magic = 0xFFFFFFFFu / (unsigned)r.rw + 1u;   // rw >= 20 (host-checked): p / rw == umulhi(p, magic) for p < 2^16
+  return r;
+}
+// linear region pixel -> (row, column); p is clamped into the region by the caller
+__device__ __forceinline__ void pix_of(const Rg& r, int p, int& py, int& px) {
+  py = (int)__umulhi((unsigned)p, r.magic);
+  px = p - py * r.rw;
+}
+
+// 4*NT consecutive halfs (this lane's channels of one pixel) -> memory
+template <int NT> __device__ __forceinline__ void store_h(char* dst, const half_t (&h)[4 * NT]) {
+  if constexpr (NT == 1) {
+    half4 q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = h[i];
+    *reinterpret_cast<half4*>(dst) = q;
+  } else {
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) {
+      half8 q;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = h[8 * j + i];
+      *reinterpret_cast<half8*>(dst + 16 * j) = q;
+    }
+  }
+}
+template <int NT> __device__ __forceinline__ void load_h(const char* src, half_t (&h)[4 * NT]) {
+  if constexpr (NT == 1) {
+    const half4 q = *reinterpret_cast<const half4*>(src);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = q[i];
+  } else {
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) {
+      const half8 q = *reinterpret_cast<const half8*>(src + 16 * j);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[8 * j + i] = q[i];
+    }
+  }
+}
+
+// K loop of one block: acc[t][i] += A(step s, tile t) . B(step s, pixel tile i).  The operand fragments of step s+1 are
+// requested before the MFMAs of step s (two register sets, static indices after unrolling); fix() runs on a step's B
+// fragments right before they are consumed (border masks of the stride-2 gather: applied at the load they would make the
+// wave wait for it at once).
+template <int S, int DA, int DB, int NT, int PT, class LA, class LB, class FX>
+__device__ __forceinline__ void kloop(floatx4 (&acc)[NT][PT], LA&& la, LB&& lb, FX&& fix) {
+  // DA / DB register sets for the A / B fragments: step s + D - 1 is requested before the MFMAs of step s
+  half8 af[DA][NT], bf[DB][PT];
+#pragma unroll
+  for (int s = 0; s < DA - 1; ++s)
+    if (s < S) la(s, af[s]);
+#pragma unroll
+  for (int s = 0; s < DB - 1; ++s)
+    if (s < S) lb(s, bf[s]);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    if (s + DA - 1 < S) la(s + DA - 1, af[(s + DA - 1) % DA]);
+    if (s + DB - 1 < S) lb(s + DB - 1, bf[(s + DB - 1) % DB]);
+    __builtin_amdgcn_sched_barrier(0);
+    fix(s, bf[s % DB]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < PT; ++i) acc[t][i] = mma16(af[s % DA][t], bf[s % DB][i], acc[t][i]);
+  }
+}
+struct NoFix {
+  template <int PT> __device__ __forceinline__ void operator()(int, half8 (&)[PT]) const {}
+};
+
+// ---- 1x1 conv + SiLU, pixel operand from global memory: K = SA steps of 32 channels from srcA, then SB steps from srcB.
+//      UP: srcA is a half-resolution tensor read at (y/2, x/2) (Interp nearest x2 fused, as conv1x1_mfma_kernel's UPS).
+//      epi(cb, ok, py, px, v): this lane's 4*NT activated channels (block cb) of region pixel (py, px); ok = a real pixel.
+template <class CFG, int NT, int CB, int PT, int KA, int KB, bool UP, class EPI>
+__device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char* __restrict__ srcA, int pitchA, const char* __restrict__ srcB,
+                                         int pitchB, const u32x4* __restrict__ w, const float* __restrict__ bias, EPI&& epi) {
+  static_assert(KA % 32 == 0 && KB % 8 == 0, "K segments: whole steps from srcA, whole 8-channel groups from srcB");
+  constexpr int SA = KA / 32, SB = cdiv_c(KB, 32), S = SA + SB;
+  // a last K step that is not full (KB % 32 != 0): lanes whose channel group lies past the pixel's channels re-read group 0
+  // of the same pixel (their weights are zero) -- the address stays inside the pixel
+  const int tail_off = (4 * (SB - 1) + cx.gam < KB / 8) ? (SB - 1) * 64 : -cx.gam * 16;
+  const int npt = (rg.R + 15) >> 4;
+  const int nblk = ((npt + PT - 1) / PT) * CB;
+  for (int blk = cx.wave; blk < nblk; blk += CFG::NW) {
+    const int cb = blk % CB, pbk = blk / CB;
+    unsigned offA[SA > 0 ? PT : 1], offB[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      int p = (pbk * PT + i) * 16 + cx.sig;
+      p = p < rg.R ? p : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      const int gy = rg.gy0 + py, gx = rg.gx0 + px;
+      if constexpr (SA > 0) {
+        const int ya = UP ? (gy >> 1) : gy, xa = UP ? (gx >> 1) : gx;
+        const int HA = UP ? (cx.H >> 1) : cx.H, WA = UP ? (cx.W >> 1) : cx.W;
+        offA[i] = (unsigned)(((cx.n * HA + ya) * WA + xa) * pitchA) * 2u + (unsigned)cx.gam * 16u;
+      }
+      offB[i] = (unsigned)(((cx.n * cx.H + gy) * cx.W + gx) * pitchB) * 2u + (unsigned)cx.gam * 16u;
+    }
+    floatx4 acc[NT][PT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // (laundered: the fragment addresses are loop-invariant when CB == 1, and LICM then hoists EVERY weight load of the
+    //  phase to the top of the kernel, where they are spilled one by one behind s_waitcnt vmcnt(0))
+    unsigned woff = (unsigned)(cb * S * NT * 64 + cx.lane) * 16u;
+    asm volatile("" : "+v"(woff));
+    const u32x4* wb = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w) + woff);
+    constexpr int D = (NT * PT <= 20 && CFG::C >= 32) ? 3 : 2;
+    kloop<S, D, D, NT, PT>(
+        acc,
+        [&](int s, half8(&af)[NT]) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) af[t] = as_h8(wb[(s * NT + t) * 64]);
+        },
+        [&](int s, half8(&bf)[PT]) {
+#pragma unroll
+          for (int i = 0; i < PT; ++i) {
+            if (SA > 0 && s < SA) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcA + (size_t)offA[SA > 0 ? i : 0] + s * 64));
+            else if (KB % 32 != 0 && s == S - 1) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcB + (size_t)(offB[i] + (unsigned)tail_off)));
+            else bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcB + (size_t)offB[i] + (s - SA) * 64));
+          }
+        },
+        NoFix{});
+    floatx4 bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int p0 = (pbk * PT + i) * 16 + cx.sig;
+      const bool ok = p0 < rg.R;
+      const int p = ok ? p0 : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      floatx4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
+      epi(cb, ok, py, px, v);
+    }
+  }
+}
+
+// ---- 3x3 stride-1 conv + SiLU, LDS plane -> epilogue.  K walks (tap, 32-channel block); c = 16: a K step covers two taps
+//      (an even number of pixels apart: the conflict-free pairing of the header) x two channel groups.
+template <class CFG, int PT, class EPI>
+__device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char* pin, const u32x4* __restrict__ w, const float* __restrict__ bias,
+                                         EPI&& epi) {
+  constexpr int C = CFG::C, NT = CFG::NTM, CB = CFG::CBM, LW = CFG::LW, PS = CFG::PS;
+  constexpr int SPT = C >= 32 ? C / 32 : 1;
+  constexpr int S = C >= 32 ? 9 * SPT : 5;
+  // c = 16: taps of step s for the lanes with (g & 1) == 0 / 1
+  constexpr int TA[5] = {0, 3, 6, 1, 4}, TB[5] = {2, 5, 8, 7, 4};
+  int soff[C >= 32 ? 1 : 5];
+  if constexpr (C < 32) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int ta = ((TA[s] / 3) * LW + TA[s] % 3) * PS, tb = ((TB[s] / 3) * LW + TB[s] % 3) * PS;
+      soff[s] = (cx.g & 1) ? tb : ta;
+    }
+  }
+  const int npt = (rg.R + 15) >> 4;
+  const int nblk = ((npt + PT - 1) / PT) * CB;
+  for (int blk = cx.wave; blk < nblk; blk += CFG::NW) {
+    const int cb = blk % CB, pbk = blk / CB;
+    int pb[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      int p = (pbk * PT + i) * 16 + cx.sig;
+      p = p < rg.R ? p : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      const int slot = (rg.fy0 + py) * LW + rg.fx0 + px;
+      pb[i] = (slot - LW - 1) * PS + (C >= 32 ? cx.gam * 16 : (cx.g >> 1) * 16);
+    }
+    floatx4 acc[NT][PT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // (laundered: the fragment addresses are loop-invariant when CB == 1, and LICM then hoists EVERY weight load of the
+    //  phase to the top of the kernel, where they are spilled one by one behind s_waitcnt vmcnt(0))
+    unsigned woff = (unsigned)(cb * S * NT * 64 + cx.lane) * 16u;
+    asm volatile("" : "+v"(woff));
+    const u32x4* wb = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w) + woff);
+    kloop<S, 4, 2, NT, PT>(
+        acc,
+        [&](int s, half8(&af)[NT]) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) af[t] = as_h8(wb[(s * NT + t) * 64]);
+        },
+        [&](int s, half8(&bf)[PT]) {
+          if constexpr (C >= 32) {
+            const int tap = s / SPT, cblk = s % SPT;
+            const int off = ((tap / 3) * LW + tap % 3) * PS + cblk * 64;
+#pragma unroll
+            for (int i = 0; i < PT; ++i) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pin + pb[i] + off));
+          } else {
+#pragma unroll
+            for (int i = 0; i < PT; ++i) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pin + pb[i] + soff[s]));
+          }
+        },
+        NoFix{});
+    floatx4 bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int p0 = (pbk * PT + i) * 16 + cx.sig;
+      const bool ok = p0 < rg.R;
+      const int p = ok ? p0 : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      floatx4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
+      epi(cb, ok, py, px, v);
+    }
+  }
+}
+
+// ---- 3x3 stride-2 pad-1 conv + SiLU, pixel operand gathered from global memory (whole-image configurations: the region is
+//      the image).  Taps above / left of the image read the centre tap's address instead and are zeroed before use.
+template <class CFG, int NT, int CB, int PT, class EPI>
+__device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const char* __restrict__ src, int pitch, const u32x4* __restrict__ w,
+                                           const float* __restrict__ bias, EPI&& epi) {
+  constexpr int SPT = CFG::KS2 / 32, S = 9 * SPT;
+  const int H2 = 2 * cx.H, W2 = 2 * cx.W;
+  const int pixb = pitch * 2, rowb = W2 * pixb;
+  const int npt = (rg.R + 15) >> 4;
+  const int nblk = ((npt + PT - 1) / PT) * CB;
+  for (int blk = cx.wave; blk < nblk; blk += CFG::NW) {
+    const int cb = blk % CB, pbk = blk / CB;
+    unsigned base[PT];
+    int fl[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      int p = (pbk * PT + i) * 16 + cx.sig;
+      p = p < rg.R ? p : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      const int gy = rg.gy0 + py, gx = rg.gx0 + px;
+      base[i] = (unsigned)(((cx.n * H2 + 2 * gy) * W2 + 2 * gx) * pitch) * 2u + (unsigned)cx.gam * 16u;
+      fl[i] = (gy == 0 ? 1 : 0) | (gx == 0 ? 2 : 0);
+    }
+    floatx4 acc[NT][PT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // (laundered: the fragment addresses are loop-invariant when CB == 1, and LICM then hoists EVERY weight load of the
+    //  phase to the top of the kernel, where they are spilled one by one behind s_waitcnt vmcnt(0))
+    unsigned woff = (unsigned)(cb * S * NT * 64 + cx.lane) * 16u;
+    asm volatile("" : "+v"(woff));
+    const u32x4* wb = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w) + woff);
+    constexpr int D = NT * PT <= 20 ? 3 : 2;
+    kloop<S, D, D, NT, PT>(
+        acc,
+        [&](int s, half8(&af)[NT]) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) af[t] = as_h8(wb[(s * NT + t) * 64]);
+        },
+        [&](int s, half8(&bf)[PT]) {
+          const int tap = s / SPT, cblk = s % SPT;
+          const int dy = tap / 3, dx = tap % 3;
+          const int toff = (dy - 1) * rowb + (dx - 1) * pixb;
+#pragma unroll
+          for (int i = 0; i < PT; ++i) {
+            const bool inv = (dy == 0 && (fl[i] & 1)) || (dx == 0 && (fl[i] & 2));
+            const unsigned o = base[i] + (unsigned)(inv ? 0 : toff);
+            bf[i] = as_h8(*reinterpret_cast<const u32x4*>(src + (size_t)o + cblk * 64));
+          }
+        },
+        [&](int s, half8(&bf)[PT]) {
+          const int tap = s / SPT;
+          const int dy = tap / 3, dx = tap % 3;
+          if (dy == 0 || dx == 0) {
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+              const bool inv = (dy == 0 && (fl[i] & 1)) || (dx == 0 && (fl[i] & 2));
+              const u32x4 m = __builtin_bit_cast(u32x4, bf[i]);
+              bf[i] = as_h8(inv ? u32x4{0u, 0u, 0u, 0u} : m);
+            }
+          }
+        });
+    floatx4 bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int p0 = (pbk * PT + i) * 16 + cx.sig;
+      const bool ok = p0 < rg.R;
+      const int p = ok ? p0 : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      floatx4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
+      epi(cb, ok, py, px, v);
+    }
+  }
+}
+
+// ---- 5x5 stride-1 pad-2 max pool of the whole image (SPPF, model.ncnn.param:79-83), separable: a horizontal 5-max from
+//      plane `pio` into plane `ptmp`, then a vertical 5-max back into `pio` (the pooled map replaces its input, which the
+//      caller has already stored) and to global memory.  Window positions outside the image are clamped onto the border
+//      pixel: it is inside the window anyway, so the maximum is the same and the loops are branch-free.
+template <class CFG>
+__device__ __forceinline__ void pool_phase(const Ctx& cx, char* pio, char* ptmp, char* gdst, int gpitch) {
+  constexpr int CG = CFG::C / 8, LW = CFG::LW, PS = CFG::PS, F = CFG::F, TH = CFG::TH, TW = CFG::TW;
+  for (int it = threadIdx.x; it < TH * TW * CG; it += CFG::NW * 64) {
+    const int pix = it / CG, cg = it - pix * CG;
+    const int y = pix / TW, x = pix - y * TW;
+    const char* row = pio + ((y + F) * LW + F) * PS + cg * 16;
+    half8 m = *reinterpret_cast<const half8*>(row + x * PS);
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      if (dx == 0) continue;
+      const int xx = min(max(x + dx, 0), TW - 1);
+      m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(row + xx * PS));
+    }
+    *reinterpret_cast<half8*>(ptmp + ((y + F) * LW + x + F) * PS + cg * 16) = m;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < TH * TW * CG; it += CFG::NW * 64) {
+    const int pix = it / CG, cg = it - pix * CG;
+    const int y = pix / TW, x = pix - y * TW;
+    const char* colp = ptmp + (F * LW + x + F) * PS + cg * 16;
+    half8 m = *reinterpret_cast<const half8*>(colp + y * LW * PS);
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy) {
+      if (dy == 0) continue;
+      const int yy = min(max(y + dy, 0), TH - 1);
+      m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(colp + yy * LW * PS));
+    }
+    *reinterpret_cast<half8*>(pio + ((y + F) * LW + x + F) * PS + cg * 16) = m;
+    *reinterpret_cast<half8*>(gdst + (size_t)(((cx.n * cx.H + y) * cx.W + x) * gpitch) * 2 + cg * 16) = m;
+  }
+}
+
+template <class CFG>
+__global__ __launch_bounds__(512, CFG::WPS) void c2f_kernel(const C2fArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int C = CFG::C, NB = CFG::NB, F = CFG::F, LW = CFG::LW, PS = CFG::PS, TH = CFG::TH, TW = CFG::TW;
+  char* P0 = smem;
+  char* P1 = smem + CFG::PLANE;
+  Ctx cx;
+  cx.lane = threadIdx.x & 63;
+  cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  cx.g = cx.lane >> 4;
+  {
+    const int col = cx.lane & 15;
+    cx.sig = col < 4 ? 2 * col : (col < 12 ? 2 * (col - 4) + 1 : 2 * (col - 8));
+    cx.gam = ((cx.g & 1) << 1) | (cx.g >> 1);
+  }
+  cx.n = blockIdx.x % a.N;   // image fastest: the tiles of an image (which share halo pixels) meet in one XCD's L2
+  const int tile = blockIdx.x / a.N;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  cx.oy0 = ty * TH; cx.ox0 = tx * TW;
+  cx.H = a.H; cx.W = a.W;
+  C2F_STAMP(0)
+  C2F_STAMP(1)
+
+  // pixels outside the image must read as zero (the convs' padding): they are never written, so clear the planes once.
+  // Interior tiles write every pixel a later phase reads.
+  {
+    const bool interior = !CFG::PERIMG && cx.oy0 >= F && cx.ox0 >= F && cx.oy0 + TH + F <= a.H && cx.ox0 + TW + F <= a.W;
+    if (!interior) {
+      for (int i = threadIdx.x; i < 2 * CFG::PLANE / 16; i += CFG::NW * 64) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  const char* src1 = reinterpret_cast<const char*>(a.src1);
+  char* cat = reinterpret_cast<char*>(a.cat);
+
+  // ---- [s2] entry conv -> x (global)
+  if constexpr (CFG::MODE >= 1) {
+    const Rg rg = make_region<CFG>(cx, 0);
+    char* xo = reinterpret_cast<char*>(a.x);
+    c3s2_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1>(cx, rg, reinterpret_cast<const char*>(a.s2_in), a.s2_pitch,
+                                                 reinterpret_cast<const u32x4*>(a.w[C2F_W_S2]), a.b[C2F_W_S2],
+                                                 [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT1]) {
+                                                   constexpr int NT = CFG::NT1;
+                                                   const int chb = cb * 16 * NT + 4 * NT * cx.g;
+                                                   half_t h[4 * NT];
+#pragma unroll
+                                                   for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                                     for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+                                                   const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+                                                   if (ok) store_h<NT>(xo + (size_t)((unsigned)gpix * (unsigned)a.x_pitch) * 2 + chb * 2, h);
+                                                 });
+  }
+  __syncthreads();
+  C2F_STAMP(2)
+
+  // ---- cv1 -> y0 | y1: both into the concat buffer (tile pixels only), y1 also into plane 0 (whole region)
+  {
+    const Rg rg = make_region<CFG>(cx, CFG::e_cv1);
+    pw_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1, CFG::KA, CFG::KB, CFG::UP>(
+        cx, rg, reinterpret_cast<const char*>(a.src0), a.pitch0, src1, a.pitch1, reinterpret_cast<const u32x4*>(a.w[C2F_W_CV1]), a.b[C2F_W_CV1],
+        [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT1]) {
+          constexpr int NT = CFG::NT1;
+          const int chb = cb * 16 * NT + 4 * NT * cx.g;
+          half_t h[4 * NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+          const int fy = rg.fy0 + py, fx = rg.fx0 + px;
+          if (ok) {
+            if (chb >= C) store_h<NT>(P0 + (fy * LW + fx) * PS + (chb - C) * 2, h);
+            if (fy >= F && fy < F + TH && fx >= F && fx < F + TW) {
+              const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+              store_h<NT>(cat + (size_t)((unsigned)gpix * (unsigned)a.cat_pitch) * 2 + chb * 2, h);
+            }
+          }
+        });
+  }
+  __syncthreads();
+  C2F_STAMP(3)
+
+  // ---- bottlenecks: a_k: plane 0 -> plane 1; b_k: plane 1 -> y_{k+2} = y_{k+1} + .. (in place in plane 0, and into the concat buffer)
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    {
+      const Rg rg = make_region<CFG>(cx, CFG::e_a(k));
+      auto epi_a = [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NTM]) {
+        constexpr int NT = CFG::NTM;
+        const int chb = cb * 16 * NT + 4 * NT * cx.g;
+        half_t h[4 * NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+        if (ok) store_h<NT>(P1 + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + chb * 2, h);
+      };
+      const u32x4* wa = reinterpret_cast<const u32x4*>(a.w[C2F_W_A0 + 2 * k]);
+      const float* ba = a.b[C2F_W_A0 + 2 * k];
+      if (k == 0) c3_phase<CFG, CFG::ptm(CFG::e_a(0))>(cx, rg, P0, wa, ba, epi_a);
+      else c3_phase<CFG, CFG::ptm(CFG::e_a(NB - 1))>(cx, rg, P0, wa, ba, epi_a);
+    }
+    __syncthreads();
+    {
+      const Rg rg = make_region<CFG>(cx, CFG::e_b(k));
+      const bool last = k == NB - 1;
+      auto epi_b = [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NTM]) {
+        constexpr int NT = CFG::NTM;
+        const int chb = cb * 16 * NT + 4 * NT * cx.g;
+        const int fy = rg.fy0 + py, fx = rg.fx0 + px;
+        char* yp = P0 + (fy * LW + fx) * PS + chb * 2;
+        half_t r[4 * NT], h[4 * NT];
+        load_h<NT>(yp, r);
+        // silu rounded to fp16, shortcut added in fp32, rounded again: what a stored conv output + an add kernel give
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) h[4 * t + q] = (half_t)((float)(half_t)v[t][q] + (float)r[4 * t + q]);
+        if (ok) {
+          if (!last) store_h<NT>(yp, h);
+          if (fy >= F && fy < F + TH && fx >= F && fx < F + TW) {
+            const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+            store_h<NT>(cat + (size_t)((unsigned)gpix * (unsigned)a.cat_pitch) * 2 + ((2 + k) * C + chb) * 2, h);
+          }
+        }
+      };
+      const u32x4* wbk = reinterpret_cast<const u32x4*>(a.w[C2F_W_B0 + 2 * k]);
+      const float* bbk = a.b[C2F_W_B0 + 2 * k];
+      if (k == 0) c3_phase<CFG, CFG::ptm(CFG::e_b(0))>(cx, rg, P1, wbk, bbk, epi_b);
+      else c3_phase<CFG, CFG::ptm(CFG::e_b(NB - 1))>(cx, rg, P1, wbk, bbk, epi_b);
+    }
+    __syncthreads();
+  }
+  C2F_STAMP(4)
+
+  // ---- cv2 over the concat buffer (this workgroup's own stores of the last phases, published by the barrier) -> out
+  {
+    const Rg rg = make_region<CFG>(cx, 0);
+    char* out = reinterpret_cast<char*>(a.out);
+    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, (2 + NB) * C, false>(
+        cx, rg, nullptr, 0, cat, a.cat_pitch, reinterpret_cast<const u32x4*>(a.w[C2F_W_CV2]), a.b[C2F_W_CV2],
+        [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT2]) {
+          constexpr int NT = CFG::NT2;
+          const int chb = cb * 16 * NT + 4 * NT * cx.g;
+          half_t h[4 * NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+          const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+          if (ok) store_h<NT>(out + (size_t)((unsigned)gpix * (unsigned)a.out_pitch) * 2 + chb * 2, h);
+        });
+  }
+  C2F_STAMP(5)
+
+  // ---- [sppf] cv1 (out -> s) -> pools -> cv2 over concat(s, p1, p2, p3)
+  if constexpr (CFG::MODE == 2) {
+    __syncthreads();
+    const Rg rg = make_region<CFG>(cx, 0);
+    char* cat2 = reinterpret_cast<char*>(a.cat2);
+    pw_phase<CFG, CFG::NTS, CFG::CBS, CFG::PTS, 0, CFG::COUT, false>(
+        cx, rg, nullptr, 0, reinterpret_cast<const char*>(a.out), a.out_pitch, reinterpret_cast<const u32x4*>(a.w[C2F_W_SP1]), a.b[C2F_W_SP1],
+        [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NTS]) {
+          constexpr int NT = CFG::NTS;
+          const int chb = cb * 16 * NT + 4 * NT * cx.g;
+          half_t h[4 * NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+          const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+          if (ok) {
+            store_h<NT>(P0 + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + chb * 2, h);
+            store_h<NT>(cat2 + (size_t)((unsigned)gpix * (unsigned)a.cat2_pitch) * 2 + chb * 2, h);
+          }
+        });
+    __syncthreads();
+    pool_phase<CFG>(cx, P0, P1, cat2 + C * 2, a.cat2_pitch);
+    __syncthreads();
+    pool_phase<CFG>(cx, P0, P1, cat2 + 2 * C * 2, a.cat2_pitch);
+    __syncthreads();
+    pool_phase<CFG>(cx, P0, P1, cat2 + 3 * C * 2, a.cat2_pitch);
+    __syncthreads();
+    C2F_STAMP(6)
+    char* out2 = reinterpret_cast<char*>(a.out2);
+    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, 4 * C, false>(
+        cx, rg, nullptr, 0, cat2, a.cat2_pitch, reinterpret_cast<const u32x4*>(a.w[C2F_W_SP2]), a.b[C2F_W_SP2],
+        [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT2]) {
+          constexpr int NT = CFG::NT2;
+          const int chb = cb * 16 * NT + 4 * NT * cx.g;
+          half_t h[4 * NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+          const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+          if (ok) store_h<NT>(out2 + (size_t)((unsigned)gpix * (unsigned)a.out2_pitch) * 2 + chb * 2, h);
+        });
+  }
+  C2F_STAMP(7)
+  C2F_STAMP(15)
+}
+
+// ---- instantiated configurations (YOLO-LitePi v1 widths; model.ncnn.param line of the module's cv1) ----------------------
+typedef C2fCfg<32, 1, 128, 64, true, 64, 0, 0> CfgNeck40;    // :90  up(P5) | P4 -> C2f(n=1) @40x40
+typedef C2fCfg<16, 1, 64, 32, true, 32, 0, 0> CfgNeck80;     // :105 up(F4) | P3 -> C2f(n=1) @80x80
+typedef C2fCfg<32, 1, 0, 128, false, 64, 0, 0> CfgPan40;     // :121 conv_37 | F4 -> C2f(n=1) @40x40
+typedef C2fCfg<64, 1, 0, 256, false, 128, 1, 64> CfgPan20;   // :134-147 conv_42 (s2) | P5 -> C2f(n=1) @20x20
+typedef C2fCfg<64, 1, 0, 128, false, 128, 2, 64> CfgBb20;    // :62-85 conv_22 (s2) -> C2f(n=1) -> SPPF @20x20
+typedef C2fCfg<16, 2, 0, 32, false, 32, 0, 0> CfgBb80;       // :22-38 C2f(n=2) @80x80
+typedef C2fCfg<32, 2, 0, 64, false, 64, 0, 0> CfgBb40;       // :43-59 C2f(n=2) @40x40
+
+template <class CFG> struct CfgName;
+#define C2F_NAME(T, s) \
+  template <> struct CfgName<T> { static const char* get() { return s; } };
+C2F_NAME(CfgNeck40, "c2f<32,1,up128+64>")
+C2F_NAME(CfgNeck80, "c2f<16,1,up64+32>")
+C2F_NAME(CfgPan40, "c2f<32,1,128>")
+C2F_NAME(CfgPan20, "c2f<64,1,s2+256>")
+C2F_NAME(CfgBb20, "c2f<64,1,s2+128,sppf>")
+C2F_NAME(CfgBb80, "c2f<16,2,32>")
+C2F_NAME(CfgBb40, "c2f<32,2,64>")
+
+template <class CFG> size_t cfg_lds() { return (size_t)2 * CFG::PLANE; }
+
+template <class CFG> bool try_launch(const C2fShape& s, const C2fArgs& a, hipStream_t st) {
+  if (!(s == CFG::shape())) return false;
+  const size_t lds = cfg_lds<CFG>();
+  set_max_dynamic_lds(reinterpret_cast<const void*>(&c2f_kernel<CFG>), (int)lds);
+  const int grid = a.N * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL(c2f_kernel<CFG>, dim3(grid), dim3(CFG::NW * 64), lds, st, a);
+  return true;
+}
+template <class CFG> bool try_info(const C2fShape& s, size_t& lds, const char*& name, bool& perimg) {
+  if (!(s == CFG::shape())) return false;
+  lds = cfg_lds<CFG>();
+  name = CfgName<CFG>::get();
+  perimg = CFG::PERIMG;
+  return true;
+}
+bool cfg_info(const C2fShape& s, size_t& lds, const char*& name, bool& perimg) {
+  return try_info<CfgNeck40>(s, lds, name, perimg) || try_info<CfgNeck80>(s, lds, name, perimg) || try_info<CfgPan40>(s, lds, name, perimg) ||
+         try_info<CfgPan20>(s, lds, name, perimg) || try_info<CfgBb20>(s, lds, name, perimg) || try_info<CfgBb80>(s, lds, name, perimg) ||
+         try_info<CfgBb40>(s, lds, name, perimg);
+}
+
+int gam_of(int g) { return ((g & 1) << 1) | (g >> 1); }
+
+// A fragments of one phase: [channel block][K step][tile][lane][8 halfs]; lane (g = lane >> 4, m = lane & 15) holds
+// A[row m][K group g].  Rows are permuted so that a lane's D rows 4g .. 4g+3 of tiles 0 .. NT-1 are 4*NT consecutive
+// channels (vector stores).  kidx(s, g, j) -> index into the K axis of Wm ([cout][ktot]) or -1 (zero).
+template <class KIDX>
+void pack_phase(DevBuf& dst, const std::vector<float>& Wm, int cout, int ktot, int NT, int S, KIDX&& kidx) {
+  LP_CHECK((int)Wm.size() == cout * ktot && cout % (16 * NT) == 0, LP_ERR_STATE, "c2f: weight matrix %zu != %d x %d", Wm.size(), cout, ktot);
+  const int CB = cout / (16 * NT);
+  std::vector<uint16_t> buf((size_t)CB * S * NT * 64 * 8, 0);
+  for (int cb = 0; cb < CB; ++cb)
+    for (int s = 0; s < S; ++s)
+      for (int t = 0; t < NT; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int g = lane >> 4, m = lane & 15, gm = m >> 2, r = m & 3;
+          const int oc = cb * 16 * NT + gm * 4 * NT + t * 4 + r;
+          const size_t f = ((((size_t)cb * S + s) * NT + t) * 64 + lane) * 8;
+          for (int j = 0; j < 8; ++j) {
+            const int k = kidx(s, g, j);
+            if (k >= 0) buf[f + j] = f32_to_f16(Wm[(size_t)oc * ktot + k]);
+          }
+        }
+  dst.alloc(buf.size() * 2, false);
+  LP_HIP(hipMemcpy(dst.p, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+}
+void put_bias(DevBuf& dst, const std::vector<float>* b, int cout) {
+  std::vector<float> v(cout + 64, 0.f);
+  if (b) {
+    LP_CHECK((int)b->size() >= cout, LP_ERR_STATE, "c2f: bias vector too short");
+    for (int c = 0; c < cout; ++c) v[c] = (*b)[c];
+  }
+  dst.alloc(v.size() * 4, false);
+  LP_HIP(hipMemcpy(dst.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+}
+
+}  // namespace
+
+bool C2fLayer::supported(const C2fShape& s, int h, int w) {
+  size_t lds;
+  const char* nm;
+  bool perimg;
+  if (!cfg_info(s, lds, nm, perimg)) return false;
+  if (h % 20 != 0 || w % 20 != 0) return false;
+  if (perimg && (h != 20 || w != 20)) return false;
+  if (s.UP && (h % 2 || w % 2)) return false;
+  return lds <= 160 * 1024;
+}
+
+void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
+  LP_CHECK(supported(s, h, w), LP_ERR_STATE, "c2f: unsupported shape");
+  sh = s; H = h; W = w;
+  const char* nm;
+  bool perimg;
+  cfg_info(s, lds_bytes, nm, perimg);
+  const int C = s.C;
+  auto nt_of = [](int ct, int cap) { return ct < cap ? ct : cap; };
+  auto pw_k = [](int ktot) {
+    return [ktot](int s_, int g, int j) {
+      const int k = 32 * s_ + 8 * gam_of(g) + j;
+      return k < ktot ? k : -1;
+    };
+  };
+  // 3x3: weights come as [cout][tap][cin]
+  auto c3_pack = [&](DevBuf& d, const std::vector<float>& wv, int cout, int cin, int NT) {
+    if (cin >= 32) {
+      const int spt = cin / 32;
+      pack_phase(d, wv, cout, 9 * cin, NT, 9 * spt, [&](int s_, int g, int j) { return (s_ / spt) * cin + 32 * (s_ % spt) + 8 * gam_of(g) + j; });
+    } else {
+      static const int TA[5] = {0, 3, 6, 1, 4}, TB[5] = {2, 5, 8, 7, -1};
+      pack_phase(d, wv, cout, 9 * cin, NT, 5, [&](int s_, int g, int j) {
+        const int tap = (g & 1) ? TB[s_] : TA[s_];
+        return tap < 0 ? -1 : tap * cin + 8 * (g >> 1) + j;
+      });
+    }
+  };
+  const int K1 = s.KA + s.KB;
+  pack_phase(d_w[C2F_W_CV1], *src.cv1, 2 * C, K1, nt_of(2 * C / 16, 4), (K1 + 31) / 32, pw_k(K1));
+  put_bias(d_b[C2F_W_CV1], src.cv1_b, 2 * C);
+  const int ntm = nt_of(C / 16, 2);
+  for (int k = 0; k < s.NB; ++k) {
+    c3_pack(d_w[C2F_W_A0 + 2 * k], *src.a[k], C, C, ntm);
+    put_bias(d_b[C2F_W_A0 + 2 * k], src.a_b[k], C);
+    c3_pack(d_w[C2F_W_B0 + 2 * k], *src.bb[k], C, C, ntm);
+    put_bias(d_b[C2F_W_B0 + 2 * k], src.bb_b[k], C);
+  }
+  const int ct2 = s.COUT / 16, nt2 = ct2 >= 2 ? ct2 / 2 : 1;
+  const int K2 = (2 + s.NB) * C;
+  pack_phase(d_w[C2F_W_CV2], *src.cv2, s.COUT, K2, nt2, (K2 + 31) / 32, pw_k(K2));
+  put_bias(d_b[C2F_W_CV2], src.cv2_b, s.COUT);
+  macs_per_image = ((double)2 * C * K1 + (double)s.NB * 2 * 9 * C * C + (double)s.COUT * K2) * h * w;
+  if (s.MODE >= 1) {
+    c3_pack(d_w[C2F_W_S2], *src.s2, 2 * C, s.KS2, nt_of(2 * C / 16, 4));
+    put_bias(d_b[C2F_W_S2], src.s2_b, 2 * C);
+    macs_per_image += 9.0 * s.KS2 * 2 * C * h * w;
+  }
+  if (s.MODE == 2) {
+    pack_phase(d_w[C2F_W_SP1], *src.sp1, C, s.COUT, ntm, (s.COUT + 31) / 32, pw_k(s.COUT));
+    put_bias(d_b[C2F_W_SP1], src.sp1_b, C);
+    pack_phase(d_w[C2F_W_SP2], *src.sp2, s.COUT, 4 * C, nt2, (4 * C + 31) / 32, pw_k(4 * C));
+    put_bias(d_b[C2F_W_SP2], src.sp2_b, s.COUT);
+    macs_per_image += ((double)C * s.COUT + (double)s.COUT * 4 * C) * h * w;
+  }
+}
+
+std::string C2fLayer::kernel_name() const {
+  size_t lds;
+  const char* nm = "c2f";
+  bool perimg;
+  cfg_info(sh, lds, nm, perimg);
+  return nm;
+}
+
+void C2fLayer::launch(const IO& io, int N, hipStream_t st) const {
+  C2fArgs a;
+  memset(&a, 0, sizeof(a));
+  auto span_ok = [&](const View& v, int mult) { return !v.base || (double)N * v.H * v.W * v.pitch * 2.0 * mult < 4294967296.0; };
+  LP_CHECK(span_ok(io.src0, 1) && span_ok(io.src1, 1) && span_ok(io.cat, 1) && span_ok(io.out, 1) && span_ok(io.s2_in, 1) && span_ok(io.x, 1) &&
+               span_ok(io.cat2, 1) && span_ok(io.out2, 1), LP_ERR_ARG, "c2f: tensor too large for 32-bit byte offsets");
+  LP_CHECK(io.src1.base && io.cat.base && io.out.base && io.src1.H == H && io.src1.W == W && io.cat.H == H && io.out.H == H, LP_ERR_STATE,
+           "c2f %s: bad views", name.c_str());
+  LP_CHECK((sh.KA > 0) == (io.src0.base != nullptr), LP_ERR_STATE, "c2f %s: src0 mismatch", name.c_str());
+  if (sh.KA > 0) LP_CHECK(io.src0.H == (sh.UP ? H / 2 : H) && io.src0.W == (sh.UP ? W / 2 : W) && io.src0.C >= sh.KA, LP_ERR_STATE, "c2f %s: src0 shape", name.c_str());
+  LP_CHECK(io.src1.C >= sh.KB && io.cat.C >= (2 + sh.NB) * sh.C && io.out.C >= sh.COUT, LP_ERR_STATE, "c2f %s: view channels", name.c_str());
+  a.src0 = io.src0.base; a.pitch0 = io.src0.pitch;
+  a.src1 = io.src1.base; a.pitch1 = io.src1.pitch;
+  a.cat = io.cat.base; a.cat_pitch = io.cat.pitch;
+  a.out = io.out.base; a.out_pitch = io.out.pitch;
+  for (int i = 0; i < C2F_NW; ++i) { a.w[i] = d_w[i].p; a.b[i] = d_b[i].as<float>(); }
+  if (sh.MODE >= 1) {
+    LP_CHECK(io.s2_in.base && io.x.base && io.s2_in.H == 2 * H && io.s2_in.W == 2 * W && io.s2_in.C >= sh.KS2 && io.x.C >= 2 * sh.C, LP_ERR_STATE,
+             "c2f %s: entry conv views", name.c_str());
+    a.s2_in = io.s2_in.base; a.s2_pitch = io.s2_in.pitch;
+    a.x = io.x.base; a.x_pitch = io.x.pitch;
+  }
+  if (sh.MODE == 2) {
+    LP_CHECK(io.cat2.base && io.out2.base && io.cat2.C >= 4 * sh.C && io.out2.C >= sh.COUT, LP_ERR_STATE, "c2f %s: SPPF views", name.c_str());
+    a.cat2 = io.cat2.base; a.cat2_pitch = io.cat2.pitch;
+    a.out2 = io.out2.base; a.out2_pitch = io.out2.pitch;
+  }
+  a.N = N; a.H = H; a.W = W;
+  a.tiles_x = W / 20; a.tiles_y = H / 20;
+  static DevBuf stamp_buf;
+  static const char* stamp_file = getenv("LITEPI_C2F_STAMPS");
+  if (stamp_file) {
+    const size_t need = (size_t)N * a.tiles_x * a.tiles_y * 16 * 8;
+    if (stamp_buf.bytes < need) stamp_buf.alloc(need);
+    a.stamps = stamp_buf.as<unsigned long long>();
+  }
+  const bool ok = try_launch<CfgNeck40>(sh, a, st) || try_launch<CfgNeck80>(sh, a, st) || try_launch<CfgPan40>(sh, a, st) ||
+                  try_launch<CfgPan20>(sh, a, st) || try_launch<CfgBb20>(sh, a, st) || try_launch<CfgBb80>(sh, a, st) || try_launch<CfgBb40>(sh, a, st);
+  LP_CHECK(ok, LP_ERR_STATE, "c2f %s: no kernel for this shape", name.c_str());
+  LP_HIP(hipGetLastError());
+  if (stamp_file && getenv("LITEPI_C2F_TWICE")) {   // diagnostic: the stamps of an immediate second launch (warm instruction cache)
+    try_launch<CfgNeck40>(sh, a, st) || try_launch<CfgNeck80>(sh, a, st) || try_launch<CfgPan40>(sh, a, st) || try_launch<CfgPan20>(sh, a, st) ||
+        try_launch<CfgBb20>(sh, a, st) || try_launch<CfgBb80>(sh, a, st) || try_launch<CfgBb40>(sh, a, st);
+  }
+  if (stamp_file) {
+    LP_HIP(hipStreamSynchronize(st));
+    const size_t nwg = (size_t)N * a.tiles_x * a.tiles_y;
+    std::vector<unsigned long long> hst(nwg * 16);
+    LP_HIP(hipMemcpy(hst.data(), stamp_buf.p, nwg * 16 * 8, hipMemcpyDeviceToHost));
+    FILE* f = fopen(stamp_file, "a");
+    if (f) {
+      fprintf(f, "# %s %zu\n", name.c_str(), nwg);
+      for (size_t i = 0; i < nwg; ++i) {
+        for (int k = 0; k < 16; ++k) fprintf(f, "%llu%c", hst[i * 16 + k], k == 15 ? '\n' : ' ');
+      }
+      fclose(f);
+    }
+  }
+}
+
+}  // namespace lp

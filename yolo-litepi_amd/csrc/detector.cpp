@@ -97,7 +97,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   const size_t es = prec_ == LP_FP16 ? 2 : 4;
 
   tensors_.clear(); blob2tensor_.clear(); buffers_.clear(); convs_.clear(); ops_.clear(); levels_.clear();
-  bnecks_.clear(); dws_.clear(); attns_.clear(); heads_.clear();
+  bnecks_.clear(); dws_.clear(); attns_.clear(); heads_.clear(); c2fs_.clear(); c2f_io_.clear();
   fused_head_ = false;
   loaded_ = false;
 
@@ -386,6 +386,244 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   std::map<int, int> fuse_up;  // 1x1 conv layer -> half-resolution tensor it upsamples on the fly
   macs_ = 0;
   const double esd = (double)es;
+
+  // ---- whole-C2f launches (c2f_kernels.hip; fp16 MFMA plan, LITEPI_NO_C2F=1: off).  match_c2f recognises, from its cv1, a
+  //      complete C2f module: Convolution 1x1 + Swish -> Slice (c | c) -> n x [3x3 + Swish -> 3x3 + Swish -> BinaryOp add] ->
+  //      Concat(y0 .. y_{n+1}) (zero-copy, pass B) -> Convolution 1x1 + Swish.  try_c2f also folds in the stride-2 3x3 conv
+  //      in front of the module and the SPPF behind it when a whole-image configuration exists for the level.
+  struct C2fMatch {
+    int cv1 = -1, slice = -1, a[2] = {-1, -1}, b[2] = {-1, -1}, add[2] = {-1, -1}, cat = -1, cv2 = -1, nb = 0, c = 0;
+    int t_cat = -1;
+    std::vector<int> ys;
+  };
+  const bool c2f_on = !getenv("LITEPI_NO_C2F") && prec_ == LP_FP16 && impl_ == IMPL_MFMA;
+  auto is_silu_conv = [&](int j, int k, int s) {
+    return j >= 0 && L[j].type == "Convolution" && !is_tail(j) && !done[j] && L[j].ipar(1, 1) == k && L[j].ipar(3, 1) == s &&
+           fused_act[j] == ACT_SILU && !L[j].bias.empty() && cinfo[j].tin >= 0 && cinfo[j].tin != input_tensor;
+  };
+  auto sole_consumer = [&](int t) {
+    auto& cs = canon_consumers[tensors_[t].name];
+    return cs.size() == 1 ? cs[0] : -1;
+  };
+  auto zero_copy_concat = [&](int cc) {
+    for (auto& cj : copies)
+      if (cj.layer == cc) return false;
+    return true;
+  };
+  auto match_c2f = [&](int i1, C2fMatch& m) -> bool {
+    if (!is_silu_conv(i1, 1, 1)) return false;
+    const int t1 = cinfo[i1].tout;
+    const Tensor& T1 = tensors_[t1];
+    if (T1.segs.size() != 2 || T1.segs[0] != T1.segs[1] || T1.parent >= 0) return false;
+    const int c = T1.segs[0];
+    if (c % 16 != 0 || tensors_[cinfo[i1].tin].Cp != L[i1].in_ch) return false;
+    const int sl = sole_consumer(t1);
+    if (sl < 0 || L[sl].type != "Slice" || L[sl].outputs.size() != 2) return false;
+    const int ty0 = get(L[sl].outputs[0]), ty1 = get(L[sl].outputs[1]);
+    const int cc = sole_consumer(ty0);
+    if (cc < 0 || L[cc].type != "Concat" || is_tail(cc) || !zero_copy_concat(cc)) return false;
+    m = C2fMatch();
+    m.cv1 = i1; m.slice = sl; m.cat = cc; m.c = c;
+    m.ys = {ty0, ty1};
+    int cur = ty1;
+    for (;;) {
+      int ja = -1, jadd = -1;
+      bool has_cat = false;
+      for (int q : canon_consumers[tensors_[cur].name]) {
+        if (q == cc) has_cat = true;
+        else if (L[q].type == "Convolution" && ja == -1) ja = q;
+        else if (L[q].type == "BinaryOp" && jadd == -1) jadd = q;
+        else return false;
+      }
+      if (!has_cat) return false;
+      if (ja == -1 && jadd == -1) break;
+      if (ja < 0 || jadd < 0 || m.nb >= 2) return false;
+      if (!is_silu_conv(ja, 3, 1) || L[ja].ipar(0) != c || L[ja].in_ch != c) return false;
+      const int jb = sole_consumer(cinfo[ja].tout);
+      if (!is_silu_conv(jb, 3, 1) || L[jb].ipar(0) != c || L[jb].in_ch != c) return false;
+      if (sole_consumer(cinfo[jb].tout) != jadd || is_tail(jadd) || done[jadd]) return false;
+      const NcnnLayer& add = L[jadd];
+      if (add.ipar(0, 0) != 0 || add.inputs.size() != 2 || add.ipar(1, 0) != 0) return false;
+      const int ta = get(add.inputs[0]), tb = get(add.inputs[1]);
+      if (!((ta == cinfo[jb].tout && tb == cur) || (tb == cinfo[jb].tout && ta == cur))) return false;
+      m.a[m.nb] = ja; m.b[m.nb] = jb; m.add[m.nb] = jadd;
+      ++m.nb;
+      cur = get(add.outputs[0]);
+      m.ys.push_back(cur);
+    }
+    if (m.nb < 1 || L[cc].inputs.size() != m.ys.size()) return false;
+    for (size_t q = 0; q < m.ys.size(); ++q)
+      if (get(L[cc].inputs[q]) != m.ys[q]) return false;
+    m.t_cat = get(L[cc].outputs[0]);
+    const Tensor& TC = tensors_[m.t_cat];
+    if (TC.parent >= 0 || TC.buf < 0 || TC.Cp != (2 + m.nb) * c || T1.buf != TC.buf || T1.off != TC.off) return false;
+    for (size_t q = 2; q < m.ys.size(); ++q) {
+      const Tensor& Y = tensors_[m.ys[q]];
+      if (Y.buf != TC.buf || Y.off != TC.off + (int)q * c || Y.Cp != c) return false;
+    }
+    m.cv2 = sole_consumer(m.t_cat);
+    if (!is_silu_conv(m.cv2, 1, 1)) return false;
+    const Tensor& TO = tensors_[cinfo[m.cv2].tout];
+    if (TO.Cp != L[m.cv2].ipar(0) || TO.parent >= 0) return false;
+    for (int q : canon_consumers[TO.name])
+      if (L[q].type == "BinaryOp") return false;
+    return true;
+  };
+  auto c2f_shape = [&](const C2fMatch& m, int mode, int ks2) {
+    C2fShape s;
+    s.C = m.c; s.NB = m.nb; s.COUT = L[m.cv2].ipar(0); s.MODE = mode; s.KS2 = ks2;
+    const int tin = cinfo[m.cv1].tin;
+    if (fuse_up.count(m.cv1)) {
+      s.UP = 1;
+      s.KA = tensors_[fuse_up[m.cv1]].Cp;
+      s.KB = tensors_[tin].Cp - s.KA;
+    } else {
+      s.KB = tensors_[tin].Cp;
+    }
+    return s;
+  };
+  auto c2f_plain_ok = [&](int i1) {   // a stand-alone C2f launch exists for the module whose cv1 is layer i1
+    C2fMatch m;
+    if (!c2f_on || !match_c2f(i1, m)) return false;
+    const Tensor& T = tensors_[cinfo[i1].tout];
+    return C2fLayer::supported(c2f_shape(m, 0, 0), T.H, T.W);
+  };
+  // NCNN [out][in][kh][kw] -> [out][tap][in] (3x3) / [out][in] (1x1); these modules have no padded channel segments
+  auto conv_w = [&](int j) {
+    const NcnnLayer& lc = L[j];
+    const int k = lc.ipar(1, 1), co = lc.ipar(0), ci = lc.in_ch, taps = k * k;
+    std::vector<float> w((size_t)co * taps * ci);
+    for (int o = 0; o < co; ++o)
+      for (int c = 0; c < ci; ++c)
+        for (int t = 0; t < taps; ++t) w[((size_t)o * taps + t) * ci + c] = lc.weight[((size_t)o * ci + c) * taps + t];
+    return w;
+  };
+  auto try_c2f = [&](int i) -> bool {
+    if (!c2f_on) return false;
+    C2fMatch m;
+    int i0 = -1, xcat = -1, mode = 0;
+    if (is_silu_conv(i, 3, 2)) {
+      // stride-2 conv -> [Concat(x, other) ->] cv1: whole-image configurations only
+      const int tx = cinfo[i].tout;
+      if (tensors_[tx].segs.size() != 1 || tensors_[tx].Cp != L[i].ipar(0) || tensors_[cinfo[i].tin].Cp != L[i].in_ch) return false;
+      int jn = sole_consumer(tx);
+      if (jn >= 0 && L[jn].type == "Concat" && !is_tail(jn)) {
+        const int tcat_in = get(L[jn].outputs[0]);
+        if (L[jn].inputs.size() != 2 || get(L[jn].inputs[0]) != tx || !zero_copy_concat(jn) || tensors_[tx].buf != tensors_[tcat_in].buf ||
+            tensors_[tx].off != tensors_[tcat_in].off || tensors_[tcat_in].parent >= 0)
+          return false;
+        xcat = jn;
+        jn = sole_consumer(tcat_in);
+      }
+      if (jn < 0 || !match_c2f(jn, m) || fuse_up.count(jn) || L[i].ipar(0) != 2 * m.c) return false;
+      i0 = i;
+      mode = 1;
+    } else if (!match_c2f(i, m)) {
+      return false;
+    }
+    const int tout = cinfo[m.cv2].tout;
+    const int Hh = tensors_[tout].H, Ww = tensors_[tout].W;
+    // SPPF behind the module: cv1 (1x1) -> three chained 5x5 pools -> zero-copy Concat(s, p1, p2, p3) -> cv2 (1x1)
+    int js1 = -1, js2 = -1, spcat = -1, pools[3] = {-1, -1, -1};
+    if (mode == 1) {
+      const int j = sole_consumer(tout);
+      if (is_silu_conv(j, 1, 1) && L[j].ipar(0) == m.c && tensors_[cinfo[j].tout].segs.size() == 1) {
+        const int ts = cinfo[j].tout;
+        int cur = ts, cc = -1;
+        bool ok = true;
+        std::vector<int> chain = {ts};
+        for (int q = 0; q < 3 && ok; ++q) {
+          int jp = -1;
+          for (int cq : canon_consumers[tensors_[cur].name]) {
+            if (L[cq].type == "Pooling" && jp < 0) jp = cq;
+            else if (L[cq].type == "Concat" && (cc < 0 || cc == cq)) cc = cq;
+            else ok = false;
+          }
+          ok = ok && jp >= 0 && !done[jp];
+          if (ok) { pools[q] = jp; cur = get(L[jp].outputs[0]); chain.push_back(cur); }
+        }
+        if (ok) {
+          for (int cq : canon_consumers[tensors_[cur].name]) ok = ok && cq == cc;
+          ok = ok && cc >= 0 && !is_tail(cc) && zero_copy_concat(cc) && L[cc].inputs.size() == 4;
+          for (int q = 0; q < 4 && ok; ++q) ok = get(L[cc].inputs[q]) == chain[q];
+        }
+        if (ok) {
+          const int tc2 = get(L[cc].outputs[0]);
+          const Tensor& TC2 = tensors_[tc2];
+          ok = TC2.parent < 0 && TC2.buf >= 0 && TC2.Cp == 4 * m.c;
+          for (int q = 0; q < 4 && ok; ++q) ok = tensors_[chain[q]].buf == TC2.buf && tensors_[chain[q]].off == TC2.off + q * m.c && tensors_[chain[q]].Cp == m.c;
+          const int j2 = ok ? sole_consumer(tc2) : -1;
+          ok = ok && is_silu_conv(j2, 1, 1) && L[j2].ipar(0) == L[m.cv2].ipar(0) && tensors_[cinfo[j2].tout].Cp == L[j2].ipar(0) &&
+               tensors_[cinfo[j2].tout].parent < 0;
+          if (ok) { js1 = j; js2 = j2; spcat = cc; }
+        }
+      }
+      if (js1 >= 0) mode = 2;
+    }
+    C2fShape sh = c2f_shape(m, mode, i0 >= 0 ? L[i0].in_ch : 0);
+    if (!C2fLayer::supported(sh, Hh, Ww)) {
+      if (mode == 2) { mode = 1; sh = c2f_shape(m, 1, L[i0].in_ch); js1 = js2 = -1; }
+      if (!C2fLayer::supported(sh, Hh, Ww)) return false;   // (a stride-2 conv falls through to its own kernel; the module is tried again at its cv1)
+    }
+    // ---- build
+    std::vector<float> w_cv1 = conv_w(m.cv1), w_cv2 = conv_w(m.cv2), w_a[2], w_b[2], w_s2, w_sp1, w_sp2;
+    C2fLayer::Src src;
+    src.cv1 = &w_cv1; src.cv1_b = &L[m.cv1].bias;
+    src.cv2 = &w_cv2; src.cv2_b = &L[m.cv2].bias;
+    for (int k = 0; k < m.nb; ++k) {
+      w_a[k] = conv_w(m.a[k]); w_b[k] = conv_w(m.b[k]);
+      src.a[k] = &w_a[k]; src.a_b[k] = &L[m.a[k]].bias;
+      src.bb[k] = &w_b[k]; src.bb_b[k] = &L[m.b[k]].bias;
+    }
+    if (mode >= 1) { w_s2 = conv_w(i0); src.s2 = &w_s2; src.s2_b = &L[i0].bias; }
+    if (mode == 2) {
+      w_sp1 = conv_w(js1); w_sp2 = conv_w(js2);
+      src.sp1 = &w_sp1; src.sp1_b = &L[js1].bias;
+      src.sp2 = &w_sp2; src.sp2_b = &L[js2].bias;
+    }
+    c2fs_.emplace_back(new C2fLayer());
+    C2fLayer& cl = *c2fs_.back();
+    cl.name = (i0 >= 0 ? L[i0].name + "+" : std::string()) + L[m.cv1].name + ".." + L[m.cv2].name + (mode == 2 ? "+sppf" : "");
+    cl.build(sh, Hh, Ww, src);
+    C2fIO io;
+    io.src1 = cinfo[m.cv1].tin;
+    if (sh.UP) { io.src0 = fuse_up[m.cv1]; io.up_c = sh.KA; }
+    io.cat = m.t_cat;
+    io.out = tout;
+    ensure_buffer(tout);
+    for (size_t q = 2; q < m.ys.size(); ++q) tensors_[m.ys[q]].materialised = true;
+    if (mode >= 1) {
+      io.s2_in = cinfo[i0].tin;
+      io.x = cinfo[i0].tout;
+      if (xcat < 0) ensure_buffer(io.x);
+      else tensors_[io.x].materialised = true;
+    }
+    double bytes = ((double)tensors_[io.src1].C * Hh * Ww + (double)tensors_[tout].C * Hh * Ww) * esd;
+    if (sh.UP) bytes -= 0.75 * sh.KA * Hh * Ww * esd;   // the upsampled segment is read at half resolution
+    if (mode >= 1) bytes += ((double)sh.KS2 * 4 - (xcat < 0 ? (double)tensors_[io.src1].C : (double)tensors_[io.x].C)) * Hh * Ww * esd;
+    if (mode == 2) {
+      io.cat2 = get(L[spcat].outputs[0]);
+      io.out2 = cinfo[js2].tout;
+      ensure_buffer(io.out2);
+      for (int q = 0; q < 3; ++q) tensors_[get(L[pools[q]].outputs[0])].materialised = true;
+      tensors_[cinfo[js1].tout].materialised = true;
+      bytes += ((double)tensors_[io.out2].C - (double)tensors_[tout].C) * Hh * Ww * esd;
+    }
+    c2f_io_.push_back(io);
+    macs_ += cl.macs_per_image;
+    DetOp op;
+    op.kind = DetOp::C2F; op.conv = (int)c2fs_.size() - 1; op.layer = cl.name;
+    op.in = io.src1; op.out = mode == 2 ? io.out2 : tout;
+    op.flops = 2.0 * cl.macs_per_image;
+    op.bytes = bytes;
+    ops_.push_back(op);
+    done[m.cv1] = done[m.cv2] = 1;
+    for (int k = 0; k < m.nb; ++k) done[m.a[k]] = done[m.b[k]] = done[m.add[k]] = 1;
+    if (i0 >= 0) done[i0] = 1;
+    if (mode == 2) { done[js1] = done[js2] = 1; done[pools[0]] = done[pools[1]] = done[pools[2]] = 1; }
+    return true;
+  };
+
   for (int i = 0; i < first_tail; ++i) {
     if ((is_tail(i) && L[i].type != "Convolution") || skip[i] || done[i]) continue;
     const NcnnLayer& l = L[i];
@@ -442,6 +680,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
       continue;
     }
     if (l.type == "Convolution") {
+      if (try_c2f(i)) continue;
       const int tin = cinfo[i].tin;
       int tout = cinfo[i].tout, res = -1;
       const int k = l.ipar(1, 1), s = l.ipar(3, 1);
@@ -635,7 +874,8 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
           // B must not itself be the producer of a fused residual add
           bool b_feeds_add = false;
           for (int c : canon_consumers[tensors_[tb].name]) b_feeds_add = b_feeds_add || L[c].type == "BinaryOp";
-          if (plain1x1 && !b_feeds_add && ConvLayer::tail_supported(k, s, tensors_[tout].Cp, tensors_[tb].Cp)) {
+          // (a C2f.cv1 that the whole-C2f launch computes itself is not folded into this conv)
+          if (plain1x1 && !b_feeds_add && !c2f_plain_ok(cs2[0]) && ConvLayer::tail_supported(k, s, tensors_[tout].Cp, tensors_[tb].Cp)) {
             tail = cs2[0];
             tmid = tout;
             tout = tb;
@@ -1006,6 +1246,24 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         launch_copy(prec_, view(op.in), view(op.out), B, st);
         kname = std::string("copy") + sfx;
         break;
+      case DetOp::C2F: {
+        const C2fLayer& cl = *c2fs_[op.conv];
+        const C2fIO& ci = c2f_io_[op.conv];
+        C2fLayer::IO io;
+        io.src1 = view(ci.src1);
+        if (ci.src0 >= 0) {  // fused upsample: leading channels from the half-resolution tensor, the rest from the concat buffer
+          io.src0 = view(ci.src0);
+          io.src1.base = static_cast<char*>(io.src1.base) + (size_t)ci.up_c * 2;
+          io.src1.C -= ci.up_c;
+        }
+        io.cat = view(ci.cat);
+        io.out = view(ci.out);
+        if (ci.s2_in >= 0) { io.s2_in = view(ci.s2_in); io.x = view(ci.x); }
+        if (ci.cat2 >= 0) { io.cat2 = view(ci.cat2); io.out2 = view(ci.out2); }
+        cl.launch(io, B, st);
+        kname = cl.kernel_name() + sfx;
+        break;
+      }
       case DetOp::HEAD:
         heads_[op.conv]->launch(view(op.in), B, levels_[op.in2].off, A_, d_anchors_.as<float>(), d_strides_.as<float>(), d_dfl_.as<float>(), out0,
                                 geom, cand, cand_count, conf, st);
