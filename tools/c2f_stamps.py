@@ -24,5 +24,10 @@ for k, runs in out.items():
     order = np.argsort(a[:, 0])
     dur = (a[:, 15] - a[:, 0]) / 100.0
     first, rest = dur[order[:256]], dur[order[256:]]
+    a2 = a[a[:, 8] > 0]
+    if len(a2):
+        inner = [np.median(a2[:, 8] - a2[:, 2]), np.median(a2[:, 9] - a2[:, 8]), np.median(a2[:, 10] - a2[:, 9]), np.median(a2[:, 3] - a2[:, 10]),
+                 np.median(a2[:, 11] - a2[:, 4]), np.median(a2[:, 12] - a2[:, 11]), np.median(a2[:, 13] - a2[:, 12]), np.median(a2[:, 5] - a2[:, 13])]
+        print("      cv1: setup %d kloop %d epi %d drain+barrier %d | cv2: setup %d kloop %d epi %d end %d" % tuple(inner))
     extra = f"  first-256 wall {np.median(first):6.1f}" + (f" later {np.median(rest):6.1f}" if len(rest) else "")
     print(f"{k:<44} wgs {len(a):5d}  " + "  ".join(f"{l} {v:8.0f}" for l, v in zip(labels, d)) + f"   wg wall {wall:6.1f} us, launch span {span:6.1f} us" + extra)

@@ -33,6 +33,7 @@ struct C2fArgs {
   void* out2;
   int out2_pitch;
   int N, H, W, tiles_x, tiles_y;
+  int debug_store;    // 1: store every y segment to the concat buffer (tools/c2f_check.py), also those cv2 reads from LDS
   unsigned long long* stamps;  // diagnostic only (LITEPI_C2F_STAMPS=<file>): 16 clock stamps per workgroup
 };
 

@@ -39,14 +39,18 @@ namespace {
 
 constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 constexpr int min_c(int a, int b) { return a < b ? a : b; }
+constexpr int max_c(int a, int b) { return a > b ? a : b; }
 
-template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_>
+template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_, int TH_ = 20>
 struct C2fCfg {
   static constexpr int C = C_, NB = NB_, KA = KA_, KB = KB_, COUT = COUT_, MODE = MODE_, KS2 = KS2_;
   static constexpr bool UP = UP_;
   static constexpr bool PERIMG = MODE_ >= 1;   // the tile is the whole image: no halo recompute, a 1-pixel zero ring
-  static constexpr int NW = 8;                 // waves per workgroup
-  static constexpr int TH = 20, TW = 20;
+  // waves per workgroup.  c = 16: four, so that two workgroups (LDS allows it) share a CU at one wave each per SIMD with
+  // the whole register file -- two independent workgroups drift out of phase and cover each other's epilogues and waits;
+  // eight waves under a 128-register cap spilled in every epilogue
+  static constexpr int NW = C_ >= 32 ? 8 : 4;
+  static constexpr int TH = TH_, TW = 20;
   static constexpr int F = PERIMG ? 1 : 2 * NB;  // frame margin around the tile
   static constexpr int LW = TW + 2 * F, LH = TH + 2 * F;
   static constexpr int PS = 2 * C + 16;          // bytes per LDS pixel
@@ -57,14 +61,24 @@ struct C2fCfg {
   static constexpr int e_a(int k) { return PERIMG ? 0 : 2 * (NB - k) - 1; }
   static constexpr int e_b(int k) { return PERIMG ? 0 : 2 * (NB - k) - 2; }
   static constexpr int npt(int e) { return cdiv_c((TH + 2 * e) * (TW + 2 * e), 16); }
-  // block shapes (NT channel tiles x PT pixel tiles per wave, CB channel blocks): one round of blocks per phase
-  static constexpr int cap_pt(int nt, int pt) { return nt * pt > 20 ? cdiv_c(pt, 2) : pt; }   // two rounds of blocks rather than spills
+  // block shapes (NT channel tiles x PT pixel tiles per wave, CB channel blocks): one round of blocks per phase, two
+  // where one would not fit the register file (cap_pt)
+  static constexpr int cap_pt(int nt, int pt) { return nt * pt > 20 ? cdiv_c(pt, 2) : pt; }
   static constexpr int CT1 = 2 * C / 16, NT1 = min_c(CT1, 4), CB1 = CT1 / NT1, PT1 = cap_pt(NT1, cdiv_c(npt(e_cv1), NW / CB1));
   static constexpr int CTM = C / 16, NTM = min_c(CTM, 2), CBM = CTM / NTM;
   static constexpr int ptm(int e) { return cdiv_c(npt(e), NW / CBM); }
   static constexpr int CT2 = COUT / 16, NT2 = CT2 >= 2 ? CT2 / 2 : 1, CB2 = CT2 / NT2, PT2 = cap_pt(NT2, cdiv_c(npt(0), NW / CB2));
-  static constexpr int WPS = C >= 32 ? 2 : 4;   // waves per SIMD the register allocation must allow (c = 16: two workgroups per CU)
   static constexpr int NTS = min_c(C / 16, 2), CBS = (C / 16) / NTS, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
+  static constexpr int WPS = 2;   // waves per SIMD the register allocation must allow
+  // cv2 reads y_NB and y_{NB+1} from the LDS planes (whole K steps need c >= 32); the earlier segments from the concat buffer
+  static constexpr bool CV2_LDS = C >= 32;
+  static constexpr int K2G = CV2_LDS ? NB * C : (2 + NB) * C;
+  // weights staged in LDS (tile configurations): fragment bytes of every phase, in execution order
+  static constexpr bool AW = !PERIMG;
+  static constexpr int c3_steps = C >= 32 ? 9 * (C / 32) : 5;
+  static constexpr int WB_CV1 = CT1 * ((KA + KB) / 32) * 1024, WB_M = CTM * c3_steps * 1024, WB_CV2 = CT2 * cdiv_c((2 + NB) * C, 32) * 1024;
+  static constexpr int WSLOT = AW ? max_c(WB_CV1, max_c(WB_M, WB_CV2)) : 0;
+  static constexpr int LDS_BYTES = 2 * PLANE + 2 * WSLOT;
   static C2fShape shape() {
     C2fShape s;
     s.C = C; s.NB = NB; s.KA = KA; s.KB = KB; s.UP = UP ? 1 : 0; s.COUT = COUT; s.MODE = MODE; s.KS2 = KS2;
@@ -75,7 +89,15 @@ struct C2fCfg {
 struct Ctx {
   int n, oy0, ox0, H, W;
   int lane, wave, g, sig, gam;
+  unsigned long long* st;   // diagnostic stamps of this workgroup (null on the product path)
 };
+// in-phase stamp (wave 0's first lane), pinned between the surrounding instructions
+#define C2F_ISTAMP(k)                                          \
+  if (cx.st && threadIdx.x == 0) {                             \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    cx.st[(k)] = clock64();                                    \
+    __builtin_amdgcn_sched_barrier(0);                         \
+  }
 struct Rg {
   int gy0, gx0, fy0, fx0, rh, rw, R;
   unsigned magic;
@@ -83,6 +105,20 @@ struct Rg {
 
 #define C2F_STAMP(k) \
   if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = ((k) == 0 || (k) == 15) ? wall_clock64() : clock64();
+
+// 16-byte LDS-DMA: lane l's 16 bytes land at lds + 16*l (wave-uniform lds), no VGPR in between
+#define C2F_GLDS16(gptr, lptr)                                                                        \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gptr),          \
+                                   (void __attribute__((address_space(3)))*)(lptr), 16, 0, 0)
+
+// Phase boundary: every wave's global stores, LDS-DMA requests and LDS traffic are done, then the workgroup barrier.
+// (NOT __syncthreads(): its workgroup-scope fence does not wait for vmcnt on this target, so staged weights could still
+// be in flight when another wave reads the slot.)
+__device__ __forceinline__ void wg_sync() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 
 __device__ __forceinline__ floatx4 mma16(half8 a, half8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ half8 as_h8(u32x4 v) { return __builtin_bit_cast(half8, v); }
@@ -149,14 +185,19 @@ template <int NT> __device__ __forceinline__ void load_h(const char* src, half_t
     }
   }
 }
+template <int NT> __device__ __forceinline__ void to_half(const floatx4 (&v)[NT], half_t (&h)[4 * NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+}
 
-// K loop of one block: acc[t][i] += A(step s, tile t) . B(step s, pixel tile i).  The operand fragments of step s+1 are
-// requested before the MFMAs of step s (two register sets, static indices after unrolling); fix() runs on a step's B
-// fragments right before they are consumed (border masks of the stride-2 gather: applied at the load they would make the
-// wave wait for it at once).
+// K loop of one block: acc[t][i] += A(step s, tile t) . B(step s, pixel tile i).  DA / DB register sets for the A / B
+// fragments: step s + D - 1 is requested before the MFMAs of step s (static indices after unrolling); fix() runs on a
+// step's B fragments right before they are consumed (border masks of the stride-2 gather: applied at the load they would
+// make the wave wait for it at once).
 template <int S, int DA, int DB, int NT, int PT, class LA, class LB, class FX>
 __device__ __forceinline__ void kloop(floatx4 (&acc)[NT][PT], LA&& la, LB&& lb, FX&& fix) {
-  // DA / DB register sets for the A / B fragments: step s + D - 1 is requested before the MFMAs of step s
   half8 af[DA][NT], bf[DB][PT];
 #pragma unroll
   for (int s = 0; s < DA - 1; ++s)
@@ -180,14 +221,33 @@ struct NoFix {
   template <int PT> __device__ __forceinline__ void operator()(int, half8 (&)[PT]) const {}
 };
 
-// ---- 1x1 conv + SiLU, pixel operand from global memory: K = SA steps of 32 channels from srcA, then SB steps from srcB.
-//      UP: srcA is a half-resolution tensor read at (y/2, x/2) (Interp nearest x2 fused, as conv1x1_mfma_kernel's UPS).
+// Where a phase's A fragments ([channel block][K step][tile][lane][16 B]) come from: an LDS slot filled by stage_weights
+// (tile configurations: every wave of the workgroup needs the same fragments, so they cross the CU's L1 once instead of
+// eight times) or global memory / L2 (whole-image configurations, whose weights do not fit next to the planes).
+template <bool LDSW> struct ASrc {
+  const char* base;   // LDSW: LDS address of the slot; else the phase's fragments in global memory
+  template <int NT> __device__ __forceinline__ void load(int off_bytes, int s, half8 (&af)[NT]) const {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) af[t] = as_h8(*reinterpret_cast<const u32x4*>(base + off_bytes + (s * NT + t) * 1024));
+  }
+};
+// request the `bytes` (a multiple of 1 KiB) of a phase's fragments into an LDS slot; the pieces are dealt to the waves
+__device__ __forceinline__ void stage_weights(const Ctx& cx, const void* src, char* slot, int bytes, int nw) {
+  const char* s = reinterpret_cast<const char*>(src) + cx.lane * 16;
+  for (int p = cx.wave; p < (bytes >> 10); p += nw) C2F_GLDS16(s + p * 1024, slot + p * 1024);
+}
+
+// ---- 1x1 conv + SiLU.  K = KA channels from global srcA, then KB from global srcB, then KL0 from LDS plane 0 and KL1
+//      from LDS plane 1 (tile pixels: cv2 over concat(y0 .., y_NB, y_{NB+1})).  UP: srcA is a half-resolution tensor read
+//      at (y/2, x/2) (Interp nearest x2 fused, as conv1x1_mfma_kernel's UPS).
 //      epi(cb, ok, py, px, v): this lane's 4*NT activated channels (block cb) of region pixel (py, px); ok = a real pixel.
-template <class CFG, int NT, int CB, int PT, int KA, int KB, bool UP, class EPI>
+template <class CFG, int NT, int CB, int PT, int KA, int KB, int KL0, int KL1, bool UP, bool LDSW, class EPI>
 __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char* __restrict__ srcA, int pitchA, const char* __restrict__ srcB,
-                                         int pitchB, const u32x4* __restrict__ w, const float* __restrict__ bias, EPI&& epi) {
-  static_assert(KA % 32 == 0 && KB % 8 == 0, "K segments: whole steps from srcA, whole 8-channel groups from srcB");
-  constexpr int SA = KA / 32, SB = cdiv_c(KB, 32), S = SA + SB;
+                                         int pitchB, const char* pl0, const char* pl1, const ASrc<LDSW>& wsrc, const float* __restrict__ bias,
+                                         EPI&& epi, int stamp0 = -1) {
+  static_assert(KA % 32 == 0 && KB % 8 == 0 && KL0 % 32 == 0 && KL1 % 32 == 0 && (KB % 32 == 0 || KL0 + KL1 == 0),
+                "K segments: whole steps, except a global srcB tail of whole 8-channel groups at the very end");
+  constexpr int SA = KA / 32, SB = cdiv_c(KB, 32), SL0 = KL0 / 32, SL1 = KL1 / 32, SG = SA + SB, S = SG + SL0 + SL1;
   // a last K step that is not full (KB % 32 != 0): lanes whose channel group lies past the pixel's channels re-read group 0
   // of the same pixel (their weights are zero) -- the address stays inside the pixel
   const int tail_off = (4 * (SB - 1) + cx.gam < KB / 8) ? (SB - 1) * 64 : -cx.gam * 16;
@@ -195,7 +255,8 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
   const int nblk = ((npt + PT - 1) / PT) * CB;
   for (int blk = cx.wave; blk < nblk; blk += CFG::NW) {
     const int cb = blk % CB, pbk = blk / CB;
-    unsigned offA[SA > 0 ? PT : 1], offB[PT];
+    unsigned offA[SA > 0 ? PT : 1], offB[SB > 0 ? PT : 1];
+    int pb[SL0 + SL1 > 0 ? PT : 1];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       int p = (pbk * PT + i) * 16 + cx.sig;
@@ -208,7 +269,8 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
         const int HA = UP ? (cx.H >> 1) : cx.H, WA = UP ? (cx.W >> 1) : cx.W;
         offA[i] = (unsigned)(((cx.n * HA + ya) * WA + xa) * pitchA) * 2u + (unsigned)cx.gam * 16u;
       }
-      offB[i] = (unsigned)(((cx.n * cx.H + gy) * cx.W + gx) * pitchB) * 2u + (unsigned)cx.gam * 16u;
+      if constexpr (SB > 0) offB[i] = (unsigned)(((cx.n * cx.H + gy) * cx.W + gx) * pitchB) * 2u + (unsigned)cx.gam * 16u;
+      if constexpr (SL0 + SL1 > 0) pb[i] = ((rg.fy0 + py) * CFG::LW + rg.fx0 + px) * CFG::PS + cx.gam * 16;
     }
     floatx4 acc[NT][PT];
 #pragma unroll
@@ -217,28 +279,28 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
       for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
     // (laundered: the fragment addresses are loop-invariant when CB == 1, and LICM then hoists EVERY weight load of the
     //  phase to the top of the kernel, where they are spilled one by one behind s_waitcnt vmcnt(0))
-    unsigned woff = (unsigned)(cb * S * NT * 64 + cx.lane) * 16u;
+    int woff = (cb * S * NT * 64 + cx.lane) * 16;
     asm volatile("" : "+v"(woff));
-    const u32x4* wb = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w) + woff);
-    constexpr int D = (NT * PT <= 20 && CFG::C >= 32) ? 3 : 2;
-    kloop<S, D, D, NT, PT>(
-        acc,
-        [&](int s, half8(&af)[NT]) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) af[t] = as_h8(wb[(s * NT + t) * 64]);
-        },
-        [&](int s, half8(&bf)[PT]) {
-#pragma unroll
-          for (int i = 0; i < PT; ++i) {
-            if (SA > 0 && s < SA) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcA + (size_t)offA[SA > 0 ? i : 0] + s * 64));
-            else if (KB % 32 != 0 && s == S - 1) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcB + (size_t)(offB[i] + (unsigned)tail_off)));
-            else bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcB + (size_t)offB[i] + (s - SA) * 64));
-          }
-        },
-        NoFix{});
     floatx4 bv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+    constexpr int DB = (NT * PT <= 20 && CFG::C >= 32) ? 3 : 2;
+    constexpr int DA = LDSW ? 2 : DB;
+    if (stamp0 >= 0) { C2F_ISTAMP(stamp0) }
+    kloop<S, DA, DB, NT, PT>(
+        acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
+        [&](int s, half8(&bf)[PT]) {
+#pragma unroll
+          for (int i = 0; i < PT; ++i) {
+            if (s < SA) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcA + (size_t)offA[SA > 0 ? i : 0] + s * 64));
+            else if (s < SG && KB % 32 != 0 && s == SG - 1) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcB + (size_t)(offB[SB > 0 ? i : 0] + (unsigned)tail_off)));
+            else if (s < SG) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcB + (size_t)offB[SB > 0 ? i : 0] + (s - SA) * 64));
+            else if (s < SG + SL0) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl0 + pb[SL0 + SL1 > 0 ? i : 0] + (s - SG) * 64));
+            else bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl1 + pb[SL0 + SL1 > 0 ? i : 0] + (s - SG - SL0) * 64));
+          }
+        },
+        NoFix{});
+    if (stamp0 >= 0) { C2F_ISTAMP(stamp0 + 1) }
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int p0 = (pbk * PT + i) * 16 + cx.sig;
@@ -251,17 +313,20 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
       for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
       epi(cb, ok, py, px, v);
     }
+    if (stamp0 >= 0) { C2F_ISTAMP(stamp0 + 2) }
   }
 }
 
 // ---- 3x3 stride-1 conv + SiLU, LDS plane -> epilogue.  K walks (tap, 32-channel block); c = 16: a K step covers two taps
 //      (an even number of pixels apart: the conflict-free pairing of the header) x two channel groups.
-template <class CFG, int PT, class EPI>
-__device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char* pin, const u32x4* __restrict__ w, const float* __restrict__ bias,
+//      One block per wave (the block shapes guarantee it).  SYNC: a workgroup barrier between the K loop and the epilogue
+//      (the epilogue overwrites the plane the K loop reads).
+template <class CFG, int PT, bool SYNC, bool LDSW, class EPI>
+__device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char* pin, const ASrc<LDSW>& wsrc, const float* __restrict__ bias,
                                          EPI&& epi) {
   constexpr int C = CFG::C, NT = CFG::NTM, CB = CFG::CBM, LW = CFG::LW, PS = CFG::PS;
   constexpr int SPT = C >= 32 ? C / 32 : 1;
-  constexpr int S = C >= 32 ? 9 * SPT : 5;
+  constexpr int S = CFG::c3_steps;
   // c = 16: taps of step s for the lanes with (g & 1) == 0 / 1
   constexpr int TA[5] = {0, 3, 6, 1, 4}, TB[5] = {2, 5, 8, 7, 4};
   int soff[C >= 32 ? 1 : 5];
@@ -274,8 +339,12 @@ __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char
   }
   const int npt = (rg.R + 15) >> 4;
   const int nblk = ((npt + PT - 1) / PT) * CB;
-  for (int blk = cx.wave; blk < nblk; blk += CFG::NW) {
-    const int cb = blk % CB, pbk = blk / CB;
+  const bool has = cx.wave < nblk;   // wave-uniform
+  const int blk = has ? cx.wave : 0;
+  const int cb = blk % CB, pbk = blk / CB;
+  floatx4 acc[NT][PT];
+  floatx4 bv[NT];
+  if (has) {
     int pb[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
@@ -286,22 +355,16 @@ __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char
       const int slot = (rg.fy0 + py) * LW + rg.fx0 + px;
       pb[i] = (slot - LW - 1) * PS + (C >= 32 ? cx.gam * 16 : (cx.g >> 1) * 16);
     }
-    floatx4 acc[NT][PT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    // (laundered: the fragment addresses are loop-invariant when CB == 1, and LICM then hoists EVERY weight load of the
-    //  phase to the top of the kernel, where they are spilled one by one behind s_waitcnt vmcnt(0))
-    unsigned woff = (unsigned)(cb * S * NT * 64 + cx.lane) * 16u;
+    int woff = (cb * S * NT * 64 + cx.lane) * 16;
     asm volatile("" : "+v"(woff));
-    const u32x4* wb = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w) + woff);
-    kloop<S, 4, 2, NT, PT>(
-        acc,
-        [&](int s, half8(&af)[NT]) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) af[t] = as_h8(wb[(s * NT + t) * 64]);
-        },
+    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+    kloop<S, (LDSW ? 2 : 4), 2, NT, PT>(
+        acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
         [&](int s, half8(&bf)[PT]) {
           if constexpr (C >= 32) {
             const int tap = s / SPT, cblk = s % SPT;
@@ -314,9 +377,13 @@ __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char
           }
         },
         NoFix{});
-    floatx4 bv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+  }
+  if constexpr (SYNC) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (has) {
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int p0 = (pbk * PT + i) * 16 + cx.sig;
@@ -342,6 +409,7 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
   const int pixb = pitch * 2, rowb = W2 * pixb;
   const int npt = (rg.R + 15) >> 4;
   const int nblk = ((npt + PT - 1) / PT) * CB;
+  const ASrc<false> wsrc{reinterpret_cast<const char*>(w)};
   for (int blk = cx.wave; blk < nblk; blk += CFG::NW) {
     const int cb = blk % CB, pbk = blk / CB;
     unsigned base[PT];
@@ -361,18 +429,14 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    // (laundered: the fragment addresses are loop-invariant when CB == 1, and LICM then hoists EVERY weight load of the
-    //  phase to the top of the kernel, where they are spilled one by one behind s_waitcnt vmcnt(0))
-    unsigned woff = (unsigned)(cb * S * NT * 64 + cx.lane) * 16u;
+    int woff = (cb * S * NT * 64 + cx.lane) * 16;
     asm volatile("" : "+v"(woff));
-    const u32x4* wb = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w) + woff);
+    floatx4 bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
     constexpr int D = NT * PT <= 20 ? 3 : 2;
     kloop<S, D, D, NT, PT>(
-        acc,
-        [&](int s, half8(&af)[NT]) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) af[t] = as_h8(wb[(s * NT + t) * 64]);
-        },
+        acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
         [&](int s, half8(&bf)[PT]) {
           const int tap = s / SPT, cblk = s % SPT;
           const int dy = tap / 3, dx = tap % 3;
@@ -396,9 +460,6 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
             }
           }
         });
-    floatx4 bv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int p0 = (pbk * PT + i) * 16 + cx.sig;
@@ -434,7 +495,7 @@ __device__ __forceinline__ void pool_phase(const Ctx& cx, char* pio, char* ptmp,
     }
     *reinterpret_cast<half8*>(ptmp + ((y + F) * LW + x + F) * PS + cg * 16) = m;
   }
-  __syncthreads();
+  wg_sync();
   for (int it = threadIdx.x; it < TH * TW * CG; it += CFG::NW * 64) {
     const int pix = it / CG, cg = it - pix * CG;
     const int y = pix / TW, x = pix - y * TW;
@@ -452,11 +513,13 @@ __device__ __forceinline__ void pool_phase(const Ctx& cx, char* pio, char* ptmp,
 }
 
 template <class CFG>
-__global__ __launch_bounds__(512, CFG::WPS) void c2f_kernel(const C2fArgs a) {
+__global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int C = CFG::C, NB = CFG::NB, F = CFG::F, LW = CFG::LW, PS = CFG::PS, TH = CFG::TH, TW = CFG::TW;
+  constexpr bool AW = CFG::AW;
   char* P0 = smem;
   char* P1 = smem + CFG::PLANE;
+  char* WS = smem + 2 * CFG::PLANE;   // two weight slots (AW)
   Ctx cx;
   cx.lane = threadIdx.x & 63;
   cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -471,8 +534,26 @@ __global__ __launch_bounds__(512, CFG::WPS) void c2f_kernel(const C2fArgs a) {
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   cx.oy0 = ty * TH; cx.ox0 = tx * TW;
   cx.H = a.H; cx.W = a.W;
+  cx.st = a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr;
   C2F_STAMP(0)
   C2F_STAMP(1)
+
+  // weight slots: phase q (0 = cv1, 1 = a_0, 2 = b_0, .., 2 NB + 1 = cv2) uses slot q & 1; its fragments are requested at
+  // the start of phase q - 1, right behind the barrier that retired the slot's previous user, and have landed by the next
+  // barrier (__syncthreads waits for the issuing wave's vmcnt)
+  auto wslot = [&](int q) { return WS + (q & 1) * CFG::WSLOT; };
+  auto stage = [&](int q) {
+    if constexpr (AW) {
+      if (q == 0) stage_weights(cx, a.w[C2F_W_CV1], wslot(0), CFG::WB_CV1, CFG::NW);
+      else if (q == 2 * NB + 1) stage_weights(cx, a.w[C2F_W_CV2], wslot(q), CFG::WB_CV2, CFG::NW);
+      else if (q <= 2 * NB) stage_weights(cx, a.w[C2F_W_A0 + q - 1], wslot(q), CFG::WB_M, CFG::NW);
+    }
+  };
+  auto wsrc = [&](int q, int widx) {
+    return ASrc<AW>{AW ? wslot(q) : reinterpret_cast<const char*>(a.w[widx])};
+  };
+  stage(0);
+  stage(1);
 
   // pixels outside the image must read as zero (the convs' padding): they are never written, so clear the planes once.
   // Interior tiles write every pixel a later phase reads.
@@ -484,6 +565,7 @@ __global__ __launch_bounds__(512, CFG::WPS) void c2f_kernel(const C2fArgs a) {
   }
   const char* src1 = reinterpret_cast<const char*>(a.src1);
   char* cat = reinterpret_cast<char*>(a.cat);
+  const bool dbg = a.debug_store != 0;
 
   // ---- [s2] entry conv -> x (global)
   if constexpr (CFG::MODE >= 1) {
@@ -495,64 +577,58 @@ __global__ __launch_bounds__(512, CFG::WPS) void c2f_kernel(const C2fArgs a) {
                                                    constexpr int NT = CFG::NT1;
                                                    const int chb = cb * 16 * NT + 4 * NT * cx.g;
                                                    half_t h[4 * NT];
-#pragma unroll
-                                                   for (int t = 0; t < NT; ++t)
-#pragma unroll
-                                                     for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+                                                   to_half<NT>(v, h);
                                                    const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
                                                    if (ok) store_h<NT>(xo + (size_t)((unsigned)gpix * (unsigned)a.x_pitch) * 2 + chb * 2, h);
                                                  });
   }
-  __syncthreads();
+  wg_sync();
   C2F_STAMP(2)
 
-  // ---- cv1 -> y0 | y1: both into the concat buffer (tile pixels only), y1 also into plane 0 (whole region)
+  // ---- cv1 -> y0 | y1: y1 into plane 0 (whole region); into the concat buffer (tile pixels) whatever cv2 reads from there
   {
     const Rg rg = make_region<CFG>(cx, CFG::e_cv1);
-    pw_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1, CFG::KA, CFG::KB, CFG::UP>(
-        cx, rg, reinterpret_cast<const char*>(a.src0), a.pitch0, src1, a.pitch1, reinterpret_cast<const u32x4*>(a.w[C2F_W_CV1]), a.b[C2F_W_CV1],
+    pw_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1, CFG::KA, CFG::KB, 0, 0, CFG::UP, AW>(
+        cx, rg, reinterpret_cast<const char*>(a.src0), a.pitch0, src1, a.pitch1, nullptr, nullptr, wsrc(0, C2F_W_CV1), a.b[C2F_W_CV1],
         [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT1]) {
           constexpr int NT = CFG::NT1;
           const int chb = cb * 16 * NT + 4 * NT * cx.g;
           half_t h[4 * NT];
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+          to_half<NT>(v, h);
           const int fy = rg.fy0 + py, fx = rg.fx0 + px;
           if (ok) {
             if (chb >= C) store_h<NT>(P0 + (fy * LW + fx) * PS + (chb - C) * 2, h);
-            if (fy >= F && fy < F + TH && fx >= F && fx < F + TW) {
+            if ((chb < CFG::K2G || dbg) && fy >= F && fy < F + TH && fx >= F && fx < F + TW) {
               const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
               store_h<NT>(cat + (size_t)((unsigned)gpix * (unsigned)a.cat_pitch) * 2 + chb * 2, h);
             }
           }
-        });
+        }, 8);
   }
-  __syncthreads();
+  wg_sync();
   C2F_STAMP(3)
 
-  // ---- bottlenecks: a_k: plane 0 -> plane 1; b_k: plane 1 -> y_{k+2} = y_{k+1} + .. (in place in plane 0, and into the concat buffer)
+  // ---- bottlenecks: a_k: plane 0 -> plane 1; b_k: plane 1 -> y_{k+2} = y_{k+1} + ..
+  //      (not the last: in place in plane 0; the last: into plane 1 behind a barrier when cv2 reads the planes)
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
+    stage(2 * k + 2);
     {
       const Rg rg = make_region<CFG>(cx, CFG::e_a(k));
       auto epi_a = [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NTM]) {
         constexpr int NT = CFG::NTM;
         const int chb = cb * 16 * NT + 4 * NT * cx.g;
         half_t h[4 * NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+        to_half<NT>(v, h);
         if (ok) store_h<NT>(P1 + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + chb * 2, h);
       };
-      const u32x4* wa = reinterpret_cast<const u32x4*>(a.w[C2F_W_A0 + 2 * k]);
+      const ASrc<AW> wa = wsrc(2 * k + 1, C2F_W_A0 + 2 * k);
       const float* ba = a.b[C2F_W_A0 + 2 * k];
-      if (k == 0) c3_phase<CFG, CFG::ptm(CFG::e_a(0))>(cx, rg, P0, wa, ba, epi_a);
-      else c3_phase<CFG, CFG::ptm(CFG::e_a(NB - 1))>(cx, rg, P0, wa, ba, epi_a);
+      if (k == 0) c3_phase<CFG, CFG::ptm(CFG::e_a(0)), false, AW>(cx, rg, P0, wa, ba, epi_a);
+      else c3_phase<CFG, CFG::ptm(CFG::e_a(NB - 1)), false, AW>(cx, rg, P0, wa, ba, epi_a);
     }
-    __syncthreads();
+    wg_sync();
+    stage(2 * k + 3);
     {
       const Rg rg = make_region<CFG>(cx, CFG::e_b(k));
       const bool last = k == NB - 1;
@@ -570,81 +646,74 @@ __global__ __launch_bounds__(512, CFG::WPS) void c2f_kernel(const C2fArgs a) {
           for (int q = 0; q < 4; ++q) h[4 * t + q] = (half_t)((float)(half_t)v[t][q] + (float)r[4 * t + q]);
         if (ok) {
           if (!last) store_h<NT>(yp, h);
-          if (fy >= F && fy < F + TH && fx >= F && fx < F + TW) {
+          else if (CFG::CV2_LDS) store_h<NT>(P1 + (fy * LW + fx) * PS + chb * 2, h);
+          if (((2 + k) * C < CFG::K2G || dbg) && fy >= F && fy < F + TH && fx >= F && fx < F + TW) {
             const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
             store_h<NT>(cat + (size_t)((unsigned)gpix * (unsigned)a.cat_pitch) * 2 + ((2 + k) * C + chb) * 2, h);
           }
         }
       };
-      const u32x4* wbk = reinterpret_cast<const u32x4*>(a.w[C2F_W_B0 + 2 * k]);
+      const ASrc<AW> wbk = wsrc(2 * k + 2, C2F_W_B0 + 2 * k);
       const float* bbk = a.b[C2F_W_B0 + 2 * k];
-      if (k == 0) c3_phase<CFG, CFG::ptm(CFG::e_b(0))>(cx, rg, P1, wbk, bbk, epi_b);
-      else c3_phase<CFG, CFG::ptm(CFG::e_b(NB - 1))>(cx, rg, P1, wbk, bbk, epi_b);
+      if (k == 0 && NB > 1) c3_phase<CFG, CFG::ptm(CFG::e_b(0)), false, AW>(cx, rg, P1, wbk, bbk, epi_b);
+      else c3_phase<CFG, CFG::ptm(CFG::e_b(NB - 1)), CFG::CV2_LDS, AW>(cx, rg, P1, wbk, bbk, epi_b);
     }
-    __syncthreads();
+    wg_sync();
   }
   C2F_STAMP(4)
 
-  // ---- cv2 over the concat buffer (this workgroup's own stores of the last phases, published by the barrier) -> out
+  // ---- cv2 over concat(y0 .. y_{NB+1}): the leading segments from the concat buffer (this workgroup's own stores,
+  //      published by the barriers), y_NB and y_{NB+1} from the planes (c >= 32) -> out
   {
     const Rg rg = make_region<CFG>(cx, 0);
     char* out = reinterpret_cast<char*>(a.out);
-    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, (2 + NB) * C, false>(
-        cx, rg, nullptr, 0, cat, a.cat_pitch, reinterpret_cast<const u32x4*>(a.w[C2F_W_CV2]), a.b[C2F_W_CV2],
+    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, CFG::K2G, (CFG::CV2_LDS ? C : 0), (CFG::CV2_LDS ? C : 0), false, AW>(
+        cx, rg, nullptr, 0, cat, a.cat_pitch, P0, P1, wsrc(2 * NB + 1, C2F_W_CV2), a.b[C2F_W_CV2],
         [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT2]) {
           constexpr int NT = CFG::NT2;
           const int chb = cb * 16 * NT + 4 * NT * cx.g;
           half_t h[4 * NT];
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+          to_half<NT>(v, h);
           const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
           if (ok) store_h<NT>(out + (size_t)((unsigned)gpix * (unsigned)a.out_pitch) * 2 + chb * 2, h);
-        });
+        }, 11);
   }
   C2F_STAMP(5)
 
   // ---- [sppf] cv1 (out -> s) -> pools -> cv2 over concat(s, p1, p2, p3)
   if constexpr (CFG::MODE == 2) {
-    __syncthreads();
+    wg_sync();
     const Rg rg = make_region<CFG>(cx, 0);
     char* cat2 = reinterpret_cast<char*>(a.cat2);
-    pw_phase<CFG, CFG::NTS, CFG::CBS, CFG::PTS, 0, CFG::COUT, false>(
-        cx, rg, nullptr, 0, reinterpret_cast<const char*>(a.out), a.out_pitch, reinterpret_cast<const u32x4*>(a.w[C2F_W_SP1]), a.b[C2F_W_SP1],
-        [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NTS]) {
+    pw_phase<CFG, CFG::NTS, CFG::CBS, CFG::PTS, 0, CFG::COUT, 0, 0, false, false>(
+        cx, rg, nullptr, 0, reinterpret_cast<const char*>(a.out), a.out_pitch, nullptr, nullptr, ASrc<false>{reinterpret_cast<const char*>(a.w[C2F_W_SP1])},
+        a.b[C2F_W_SP1], [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NTS]) {
           constexpr int NT = CFG::NTS;
           const int chb = cb * 16 * NT + 4 * NT * cx.g;
           half_t h[4 * NT];
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+          to_half<NT>(v, h);
           const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
           if (ok) {
             store_h<NT>(P0 + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + chb * 2, h);
             store_h<NT>(cat2 + (size_t)((unsigned)gpix * (unsigned)a.cat2_pitch) * 2 + chb * 2, h);
           }
         });
-    __syncthreads();
+    wg_sync();
     pool_phase<CFG>(cx, P0, P1, cat2 + C * 2, a.cat2_pitch);
-    __syncthreads();
+    wg_sync();
     pool_phase<CFG>(cx, P0, P1, cat2 + 2 * C * 2, a.cat2_pitch);
-    __syncthreads();
+    wg_sync();
     pool_phase<CFG>(cx, P0, P1, cat2 + 3 * C * 2, a.cat2_pitch);
-    __syncthreads();
+    wg_sync();
     C2F_STAMP(6)
     char* out2 = reinterpret_cast<char*>(a.out2);
-    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, 4 * C, false>(
-        cx, rg, nullptr, 0, cat2, a.cat2_pitch, reinterpret_cast<const u32x4*>(a.w[C2F_W_SP2]), a.b[C2F_W_SP2],
+    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, 4 * C, 0, 0, false, false>(
+        cx, rg, nullptr, 0, cat2, a.cat2_pitch, nullptr, nullptr, ASrc<false>{reinterpret_cast<const char*>(a.w[C2F_W_SP2])}, a.b[C2F_W_SP2],
         [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT2]) {
           constexpr int NT = CFG::NT2;
           const int chb = cb * 16 * NT + 4 * NT * cx.g;
           half_t h[4 * NT];
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[4 * t + r] = (half_t)v[t][r];
+          to_half<NT>(v, h);
           const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
           if (ok) store_h<NT>(out2 + (size_t)((unsigned)gpix * (unsigned)a.out2_pitch) * 2 + chb * 2, h);
         });
@@ -659,7 +728,7 @@ typedef C2fCfg<16, 1, 64, 32, true, 32, 0, 0> CfgNeck80;     // :105 up(F4) | P3
 typedef C2fCfg<32, 1, 0, 128, false, 64, 0, 0> CfgPan40;     // :121 conv_37 | F4 -> C2f(n=1) @40x40
 typedef C2fCfg<64, 1, 0, 256, false, 128, 1, 64> CfgPan20;   // :134-147 conv_42 (s2) | P5 -> C2f(n=1) @20x20
 typedef C2fCfg<64, 1, 0, 128, false, 128, 2, 64> CfgBb20;    // :62-85 conv_22 (s2) -> C2f(n=1) -> SPPF @20x20
-typedef C2fCfg<16, 2, 0, 32, false, 32, 0, 0> CfgBb80;       // :22-38 C2f(n=2) @80x80
+typedef C2fCfg<16, 2, 0, 32, false, 32, 0, 0, 16> CfgBb80;       // :22-38 C2f(n=2) @80x80
 typedef C2fCfg<32, 2, 0, 64, false, 64, 0, 0> CfgBb40;       // :43-59 C2f(n=2) @40x40
 
 template <class CFG> struct CfgName;
@@ -673,7 +742,7 @@ C2F_NAME(CfgBb20, "c2f<64,1,s2+128,sppf>")
 C2F_NAME(CfgBb80, "c2f<16,2,32>")
 C2F_NAME(CfgBb40, "c2f<32,2,64>")
 
-template <class CFG> size_t cfg_lds() { return (size_t)2 * CFG::PLANE; }
+template <class CFG> size_t cfg_lds() { return (size_t)CFG::LDS_BYTES; }
 
 template <class CFG> bool try_launch(const C2fShape& s, const C2fArgs& a, hipStream_t st) {
   if (!(s == CFG::shape())) return false;
@@ -683,17 +752,21 @@ template <class CFG> bool try_launch(const C2fShape& s, const C2fArgs& a, hipStr
   hipLaunchKernelGGL(c2f_kernel<CFG>, dim3(grid), dim3(CFG::NW * 64), lds, st, a);
   return true;
 }
-template <class CFG> bool try_info(const C2fShape& s, size_t& lds, const char*& name, bool& perimg) {
+struct CfgInfo { size_t lds; const char* name; bool perimg; int th, tw; };
+template <class CFG> bool try_info(const C2fShape& s, CfgInfo& ci) {
   if (!(s == CFG::shape())) return false;
-  lds = cfg_lds<CFG>();
-  name = CfgName<CFG>::get();
-  perimg = CFG::PERIMG;
+  ci.lds = cfg_lds<CFG>();
+  ci.name = CfgName<CFG>::get();
+  ci.perimg = CFG::PERIMG;
+  ci.th = CFG::TH; ci.tw = CFG::TW;
   return true;
 }
-bool cfg_info(const C2fShape& s, size_t& lds, const char*& name, bool& perimg) {
-  return try_info<CfgNeck40>(s, lds, name, perimg) || try_info<CfgNeck80>(s, lds, name, perimg) || try_info<CfgPan40>(s, lds, name, perimg) ||
-         try_info<CfgPan20>(s, lds, name, perimg) || try_info<CfgBb20>(s, lds, name, perimg) || try_info<CfgBb80>(s, lds, name, perimg) ||
-         try_info<CfgBb40>(s, lds, name, perimg);
+bool cfg_info(const C2fShape& s, CfgInfo& ci) {
+  // (CfgBb80, the n = 2 module on the 80x80 map, is opt-in: its halo-4 recompute of 16-channel layers is VALU work the
+  //  two-launch bottleneck plan does not have -- 65-75 us against 59; LITEPI_C2F_BB80=1 enables it for A/B runs)
+  static const bool bb80 = getenv("LITEPI_C2F_BB80") != nullptr;
+  return try_info<CfgNeck40>(s, ci) || try_info<CfgNeck80>(s, ci) || try_info<CfgPan40>(s, ci) || try_info<CfgPan20>(s, ci) ||
+         try_info<CfgBb20>(s, ci) || (bb80 && try_info<CfgBb80>(s, ci)) || try_info<CfgBb40>(s, ci);
 }
 
 int gam_of(int g) { return ((g & 1) << 1) | (g >> 1); }
@@ -734,22 +807,20 @@ void put_bias(DevBuf& dst, const std::vector<float>* b, int cout) {
 }  // namespace
 
 bool C2fLayer::supported(const C2fShape& s, int h, int w) {
-  size_t lds;
-  const char* nm;
-  bool perimg;
-  if (!cfg_info(s, lds, nm, perimg)) return false;
-  if (h % 20 != 0 || w % 20 != 0) return false;
-  if (perimg && (h != 20 || w != 20)) return false;
+  CfgInfo ci;
+  if (!cfg_info(s, ci)) return false;
+  if (h % ci.th != 0 || w % ci.tw != 0) return false;
+  if (ci.perimg && (h != ci.th || w != ci.tw)) return false;
   if (s.UP && (h % 2 || w % 2)) return false;
-  return lds <= 160 * 1024;
+  return ci.lds <= 160 * 1024;
 }
 
 void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
   LP_CHECK(supported(s, h, w), LP_ERR_STATE, "c2f: unsupported shape");
   sh = s; H = h; W = w;
-  const char* nm;
-  bool perimg;
-  cfg_info(s, lds_bytes, nm, perimg);
+  CfgInfo ci;
+  cfg_info(s, ci);
+  lds_bytes = ci.lds;
   const int C = s.C;
   auto nt_of = [](int ct, int cap) { return ct < cap ? ct : cap; };
   auto pw_k = [](int ktot) {
@@ -801,11 +872,8 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
 }
 
 std::string C2fLayer::kernel_name() const {
-  size_t lds;
-  const char* nm = "c2f";
-  bool perimg;
-  cfg_info(sh, lds, nm, perimg);
-  return nm;
+  CfgInfo ci;
+  return cfg_info(sh, ci) ? ci.name : "c2f";
 }
 
 void C2fLayer::launch(const IO& io, int N, hipStream_t st) const {
@@ -836,7 +904,11 @@ void C2fLayer::launch(const IO& io, int N, hipStream_t st) const {
     a.out2 = io.out2.base; a.out2_pitch = io.out2.pitch;
   }
   a.N = N; a.H = H; a.W = W;
-  a.tiles_x = W / 20; a.tiles_y = H / 20;
+  CfgInfo ci;
+  cfg_info(sh, ci);
+  a.tiles_x = W / ci.tw; a.tiles_y = H / ci.th;
+  static const bool store_all = getenv("LITEPI_C2F_STORE_ALL") != nullptr;   // bisect aid: every y segment goes to the concat buffer
+  a.debug_store = store_all ? 1 : 0;
   static DevBuf stamp_buf;
   static const char* stamp_file = getenv("LITEPI_C2F_STAMPS");
   if (stamp_file) {
