@@ -53,7 +53,7 @@ PEAK_HBM_GBS = 8000.0
 CONF, IOU, MIN_AREA = 0.25, 0.45, 50
 NUM_CLASSES = 91            # TT100K classifier head
 TARGET_CANDIDATES = 8       # anchors per image above conf after calibration
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def parse_args():
@@ -74,8 +74,13 @@ def parse_args():
     ap.add_argument("--nbatches", type=int, default=4, help="distinct input batches the steps rotate over")
     ap.add_argument("--windows", type=int, default=9, help="extra timed windows of --steps steps (median / p95)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-resident (PCIe-inclusive) measurement")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the HybridPipeline.run_batch (host images -> dicts) measurement")
     ap.add_argument("--conf", type=float, default=None, help="experiment: detector confidence threshold (default 0.25, BASELINE configs[2])")
     ap.add_argument("--dump-profile", default="", help="write the per-launch profile of the roofline pass to this JSON file")
+    ap.add_argument("--rccl-self", action="store_true",
+                    help="N=1 only: initialise the nccl (RCCL) process group at world size 1 and push every step's payload through "
+                         "the gather (a self-gather), so that the multi-GPU step -- RCCL init, stream ordering against the handle's "
+                         "stream, the receive-slot views -- executes on a single-GPU box")
     return ap.parse_args()
 
 
@@ -147,9 +152,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.rccl_self:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    use_gather = world > 1 or args.rccl_self
 
     from litepi import Engine
     from litepi.distributed import Gatherer, alloc_result_buffers
@@ -181,7 +188,7 @@ def main():
         engs.append(e); streams.append(st); outs.append(alloc_result_buffers(B, args.max_det, dev))
     NH = len(engs)
     eng, (dets, counts) = engs[0], outs[0]
-    gatherers = [Gatherer(o, dst=0) for o in outs]   # receive slots allocated once (rank 0), nothing per step
+    gatherers = [Gatherer(o, dst=0, force=args.rccl_self) for o in outs]   # receive slots allocated once (rank 0), nothing per step
     torch.cuda.synchronize()
     step_no = [0]
 
@@ -192,7 +199,7 @@ def main():
         d, c = outs[i]
         with torch.cuda.stream(streams[i]):
             engs[i].run_batch_device(imgs[j].data_ptr(), B, 640, 640, run_conf, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
-            if world > 1:
+            if use_gather:
                 return gatherers[i].gather(outs[i])
         return d, c.view(1, -1)
 
@@ -234,30 +241,79 @@ def main():
     kept = counts[:B].sum().item()
     prefilter = counts[B:2 * B].sum().item()
 
-    # ---- the same loop from pinned host memory (PCIe-inclusive) -------------------------------------
+    # ---- host-to-host (PCIe-inclusive): the batch starts in PINNED HOST memory and the records end there ------------
+    # The reference's t_total runs from a host image to host results (e2e.py:446-506).  Uploads ride a dedicated copy
+    # stream into 2 staging buffers per handle (the copy of step k+NH overlaps the kernels of steps k..k+NH-1); the
+    # payload (records + counts, 0.61 MB) leaves through an async D2H into pinned memory on the handle's stream.
     h2d = None
     if not args.no_h2d:
         host = [torch.from_numpy(imgs_np[j]).pin_memory() for j in range(NB)]
-        stage = [torch.empty((B, 640, 640, 3), dtype=torch.uint8, device=dev) for _ in range(NH)]
+        NS = 2 * NH
+        stage = [torch.empty((B, 640, 640, 3), dtype=torch.uint8, device=dev) for _ in range(NS)]
+        host_out = [torch.empty_like(outs[i].payload, device="cpu").pin_memory() for i in range(NH)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        copied = [torch.cuda.Event() for _ in range(NS)]
+        freed = [torch.cuda.Event() for _ in range(NS)]
         hstep_no = [0]
 
         def hstep():
             k = hstep_no[0]
             hstep_no[0] += 1
-            i, j = k % NH, k % NB
+            i, j, sidx = k % NH, k % NB, k % NS
             d, c = outs[i]
+            with torch.cuda.stream(copy_stream):
+                if k >= NS:
+                    copy_stream.wait_event(freed[sidx])      # the step that last read this staging buffer is done
+                stage[sidx].copy_(host[j], non_blocking=True)
+                copied[sidx].record(copy_stream)
             with torch.cuda.stream(streams[i]):
-                stage[i].copy_(host[j], non_blocking=True)
-                engs[i].run_batch_device(stage[i].data_ptr(), B, 640, 640, run_conf, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
-                if world > 1:
-                    return gatherers[i].gather(outs[i])
+                streams[i].wait_event(copied[sidx])
+                engs[i].run_batch_device(stage[sidx].data_ptr(), B, 640, 640, run_conf, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
+                freed[sidx].record(streams[i])
+                if use_gather:
+                    r = gatherers[i].gather(outs[i])
+                host_out[i].copy_(outs[i].payload, non_blocking=True)   # records + counts back to the host
 
-        for _ in range(2 * lcm + args.warmup):
+        lcm_h = NS * NB // int(np.gcd(NS, NB))
+        for _ in range(2 * lcm_h + args.warmup):
             hstep()
         hel, _ = timed(hstep, K)
+        nbytes = B * 640 * 640 * 3
         h2d = {"value": world * B * K / hel, "unit": "images/sec", "ms_per_step": hel / K * 1e3,
-               "note": "batch starts in pinned host memory: hipMemcpyAsync of 78.6 MB per step on the handle's stream, then the "
-                       "same pipeline; copies of one handle overlap the kernels of the others"}
+               "upload_gbs": nbytes * K / hel / 1e9,
+               "note": "host to host: the batch starts in pinned host memory (hipMemcpyAsync of 78.6 MB per step on a dedicated "
+                       "copy stream into double-buffered staging, overlapping the kernels of the steps in flight), the same "
+                       "pipeline, then the records + counts (0.61 MB) back into pinned host memory by an async D2H"}
+
+    # ---- the drop-in call itself: HybridPipeline.run_batch on B host NumPy images -> per-image result dicts ----------
+    dropin = None
+    if rank == 0 and not args.no_dropin:
+        from litepi import HybridPipeline
+        cls_path = os.path.join(workdir, "cls.pth")
+        torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in cls_state.items()}, cls_path)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):   # the constructor prints the reference's banner
+            pipe = HybridPipeline(param, binf, cls_path, "shufflenetv2", num_classes=NUM_CLASSES, precision=args.precision,
+                                  max_batch=B, max_det=args.max_det, device=local_rank)
+        try:
+            batches = [[imgs_np[j][i] for i in range(B)] for j in range(NB)]
+            for j in range(3):
+                pipe.run_batch(batches[j % NB], run_conf, IOU, MIN_AREA)
+            n_calls = max(4, min(K, 16))
+            t0 = time.perf_counter()
+            n_res = 0
+            for j in range(n_calls):
+                res = pipe.run_batch(batches[j % NB], run_conf, IOU, MIN_AREA)
+                n_res += sum(len(r[0]) for r in res)
+            dt = time.perf_counter() - t0
+            dropin = {"value": B * n_calls / dt, "unit": "images/sec", "ms_per_call": dt / n_calls * 1e3, "calls": n_calls,
+                      "results_per_call": n_res / n_calls,
+                      "note": "HybridPipeline.run_batch(list of 64 host uint8 images) -> per-image result dicts, synchronous, one "
+                              "handle: pageable-host upload of 78.6 MB, the pipeline, D2H of the records, Python dict building "
+                              "(the reference's t_total span, e2e.py:446-506, for a batch)"}
+        finally:
+            pipe.engine.close()
 
     # ---- roofline of the dominant conv kernel (one template instantiation): profiled passes of the same step ----
     roofline, families = None, {}
@@ -317,6 +373,18 @@ def main():
             base = k.split("<")[0] + (k[k.rindex("_f"):] if "<" in k and "_f" in k else "")
             fam_ms[base] = fam_ms.get(base, 0.0) + v["ms"]
         roofline["families_ms"] = {k: round(v, 4) for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])}
+        # the dominant FAMILY (all instantiations of one kernel template) next to the dominant instantiation above, so that
+        # rounds stay comparable whichever way "dominant" is read
+        fam_fl, fam_by = {}, {}
+        for k, v in det_fams.items():
+            base = k.split("<")[0] + (k[k.rindex("_f"):] if "<" in k and "_f" in k else "")
+            fam_fl[base] = fam_fl.get(base, 0.0) + v["flops"]
+            fam_by[base] = fam_by.get(base, 0.0) + v["bytes"]
+        domf = max(fam_fl, key=lambda k: fam_ms[k])
+        roofline["dominant_family"] = {
+            "family": domf, "ms": fam_ms[domf], "achieved": fam_fl[domf] / (fam_ms[domf] * 1e-3) / 1e12, "unit": "TFLOP/s",
+            "frac": fam_fl[domf] / (fam_ms[domf] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS,
+            "hbm_view_gbs": fam_by[domf] / (fam_ms[domf] * 1e-3) / 1e9}
         if args.dump_profile:
             with open(args.dump_profile, "w") as fh:
                 json.dump({"families": families, "launches": launches[-1]}, fh, indent=1)
@@ -364,6 +432,7 @@ def main():
                         "ms_per_step_p95": float(np.percentile(wm, 95)), "ms_per_step_min": float(wm.min()),
                         "images_per_sec_median": world * B / (float(np.median(wm)) * 1e-3)},
             "h2d_inclusive": h2d,
+            "dropin": dropin,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

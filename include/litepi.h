@@ -81,6 +81,12 @@ typedef struct lp_timing {
   float t_detection, t_roi_extract, t_classification, t_total;
 } lp_timing;
 
+/* ABI version of this header: bumped on every incompatible change of a signature, of lp_config's meaning or of a buffer
+ * contract.  300 (round 3) vs 100: lp_run_batch takes det_conf_avg, lp_test_postprocess changed, lp_config::numerics /
+ * cls_arch took two reserved words, and lp_run_batch_device's dev_counts holds 3*B int32 (was 2*B: a caller that still
+ * allocates 2*B is overrun).  litepi/_ffi.py refuses a library whose lp_version() differs. */
+#define LP_ABI_VERSION 300
+
 const char* lp_last_error(void);
 int lp_version(void);
 
@@ -132,6 +138,11 @@ int lp_run_batch(lp_handle* h, const uint8_t* const* imgs, const int* heights, c
  * bench.py times and what the multi-GPU gather consumes. */
 int lp_run_batch_device(lp_handle* h, const void* dev_imgs, int B, int H, int W,
                         float conf, float iou, int min_area, void* dev_dets, void* dev_counts);
+/* After lp_run_batch_device (synchronises the handle's stream): *kept = ROIs that survived the area filter in the last call,
+ * *classified = min(kept, max_rois).  kept > classified means a user-set lp_config::max_rois was too small and
+ * kept - classified detections still carry cls_class = -1 (lp_run_batch turns the same condition into LP_ERR_STATE;
+ * the asynchronous device path cannot).  With max_rois = 0 (default: max_batch * max_det) it cannot happen. */
+int lp_roi_overflow(lp_handle* h, int* classified, int* kept);
 
 /* ---- classifier alone ------------------------------------------------------------ */
 /* replaces PyTorchClassifier.predict_batch (e2e.py:378-396) for R host BGR crops of

@@ -1025,8 +1025,10 @@ def test_optimize_numerics_pipeline(tmp_path):
 # ResNet18 classifier (--clf_arch resnet18, e2e.py:320-323).  PARITY UNPINNED by the reference (no weights or outputs for it;
 # torchvision absent): the checker is oracle/resnet_ref.py on seeded synthetic weights.
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("conv_impl", [0, 1], ids=["mfma", "naive"])
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])
-def test_resnet18_classifier_matches_oracle(tmp_path, precision):
+def test_resnet18_classifier_matches_oracle(tmp_path, precision, conv_impl):
+    """conv_impl = 1: the naive debug kernels must honour the BasicBlock's add-before-ReLU too (ConvArgs::res_first)."""
     from litepi import PyTorchClassifier
     from oracle import resnet_ref as R
     ncls = 58
@@ -1037,7 +1039,7 @@ def test_resnet18_classifier_matches_oracle(tmp_path, precision):
     rng = np.random.default_rng(8)
     rois = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in
             ((64, 64), (31, 47), (12, 9), (90, 120), (200, 150), (64, 33), (17, 17), (75, 64), (40, 40), (128, 96), (55, 21))]
-    clf = PyTorchClassifier(path, "resnet18", ncls, precision=precision, max_rois=64)
+    clf = PyTorchClassifier(path, "resnet18", ncls, precision=precision, max_rois=64, conv_impl=conv_impl)
     try:
         ids, probs = clf.predict_batch(rois)
         assert clf.weights_loaded

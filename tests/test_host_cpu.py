@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in litepi.h but not exported"
     assert sorted(_ffi.SYMBOLS) == declared
-    assert lib.lp_version() >= 100
+    assert lib.lp_version() == _ffi.ABI_VERSION
 
 
 def test_struct_layouts_match_header():

@@ -189,7 +189,7 @@ struct lp_handle {
 extern "C" {
 
 const char* lp_last_error(void) { return lp::g_last_error.c_str(); }
-int lp_version(void) { return 100; }
+int lp_version(void) { return LP_ABI_VERSION; }
 
 void lp_default_config(lp_config* c) {
   memset(c, 0, sizeof(*c));
@@ -216,6 +216,14 @@ int lp_create(const lp_config* cfg, lp_handle** out) {
   h->cfg = *cfg;
   // every kept box is a ROI (the reference classifies all of them, e2e.py:493-497): the default capacity can not overflow
   h->max_rois = cfg->max_rois > 0 ? cfg->max_rois : cfg->max_batch * cfg->max_det;
+  // the classifier's widest per-ROI tensor must stay below 2^31 elements (32-bit element offsets in the conv kernels): say so
+  // here, not at the first launch.  ShuffleNetV2 / ResNet18 at cls_input S: conv1 output 24 (64) channels at (S/2)^2.
+  {
+    const double per_roi = (double)(cfg->cls_arch == LP_CLS_RESNET18 ? 64 : 24) * (cfg->cls_input / 2.0) * (cfg->cls_input / 2.0);
+    LP_CHECK(per_roi * h->max_rois < 2147483648.0, LP_ERR_ARG,
+             "max_rois = %d (max_batch %d x max_det %d when left 0) makes the classifier's activations exceed 2^31 elements; lower "
+             "max_det or set max_rois (at most %d for this classifier)", h->max_rois, cfg->max_batch, cfg->max_det, (int)(2147483647.0 / per_roi));
+  }
   LP_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   for (auto& e : h->ev) LP_HIP(hipEventCreate(&e));
@@ -584,6 +592,18 @@ int lp_run_batch_device(lp_handle* h, const void* dev_imgs, int B, int H, int W,
     if (classify) enqueue_classify(h, src, B, static_cast<lp_det*>(dev_dets), nullptr, nullptr, nullptr, prof);
   });
   if (prof) prof->enabled = false;  // records are collected by lp_profile_read after the caller synchronises
+  LP_API_END
+}
+
+int lp_roi_overflow(lp_handle* h, int* classified, int* kept) {
+  LP_API_BEGIN
+  LP_CHECK(h && classified && kept, LP_ERR_ARG, "null argument");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  LP_HIP(hipStreamSynchronize(h->stream));
+  int R[2] = {0, 0};
+  LP_HIP(hipMemcpy(R, h->d_roi_total.p, sizeof(R), hipMemcpyDeviceToHost));
+  *classified = R[0];
+  *kept = R[1];
   LP_API_END
 }
 

@@ -475,10 +475,17 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
   }
 }
 
+// LDS-only phase boundary (no global traffic of this wave has to be complete)
+__device__ __forceinline__ void lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ---- 5x5 stride-1 pad-2 max pool of the whole image (SPPF, model.ncnn.param:79-83), separable: a horizontal 5-max from
-//      plane `pio` into plane `ptmp`, then a vertical 5-max back into `pio` (the pooled map replaces its input, which the
-//      caller has already stored) and to global memory.  Window positions outside the image are clamped onto the border
-//      pixel: it is inside the window anyway, so the maximum is the same and the loops are branch-free.
+//      plane `pio` into plane `ptmp`, then a vertical 5-max back into `pio` (the pooled map replaces its input).  Window
+//      positions outside the image are clamped onto the border pixel: it is inside the window anyway, so the maximum is the
+//      same and the loops are branch-free.  gdst != null (bisect aid): the pooled map also goes to global memory.
 template <class CFG>
 __device__ __forceinline__ void pool_phase(const Ctx& cx, char* pio, char* ptmp, char* gdst, int gpitch) {
   constexpr int CG = CFG::C / 8, LW = CFG::LW, PS = CFG::PS, F = CFG::F, TH = CFG::TH, TW = CFG::TW;
@@ -495,7 +502,7 @@ __device__ __forceinline__ void pool_phase(const Ctx& cx, char* pio, char* ptmp,
     }
     *reinterpret_cast<half8*>(ptmp + ((y + F) * LW + x + F) * PS + cg * 16) = m;
   }
-  wg_sync();
+  lds_sync();
   for (int it = threadIdx.x; it < TH * TW * CG; it += CFG::NW * 64) {
     const int pix = it / CG, cg = it - pix * CG;
     const int y = pix / TW, x = pix - y * TW;
@@ -508,7 +515,87 @@ __device__ __forceinline__ void pool_phase(const Ctx& cx, char* pio, char* ptmp,
       m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(colp + yy * LW * PS));
     }
     *reinterpret_cast<half8*>(pio + ((y + F) * LW + x + F) * PS + cg * 16) = m;
-    *reinterpret_cast<half8*>(gdst + (size_t)(((cx.n * cx.H + y) * cx.W + x) * gpitch) * 2 + cg * 16) = m;
+    if (gdst) *reinterpret_cast<half8*>(gdst + (size_t)(((cx.n * cx.H + y) * cx.W + x) * gpitch) * 2 + cg * 16) = m;
+  }
+  lds_sync();
+}
+
+// ---- SPPF.cv2 over concat(s, p1, p2, p3) without the concat: out = silu(W0 s + W1 p1 + W2 p2 + W3 p3 + b), the four
+//      K segments accumulated as the pooled maps appear in plane 0 (each pool replaces its input there), so p1 .. p3 never
+//      leave the CU and the conv's pixel operand comes from LDS.  One block per wave, accumulators live across the pools;
+//      the next segment's weight fragments are requested before the pool that precedes it.
+template <class CFG, class EPI>
+__device__ __forceinline__ void sppf_tail(const Ctx& cx, const Rg& rg, char* P0, char* P1, const char* __restrict__ w, const float* __restrict__ bias,
+                                          char* gcat2, int gpitch, EPI&& epi) {
+  constexpr int C = CFG::C, NT = CFG::NT2, CB = CFG::CB2, PT = cdiv_c(CFG::npt(0), CFG::NW / CB), SPT = C / 32, S = 4 * SPT;
+  static_assert(NT * PT <= 28 && SPT == 2, "SPPF tail: block shape");
+  const int npt = (rg.R + 15) >> 4;
+  const int nblk = ((npt + PT - 1) / PT) * CB;
+  const bool has = cx.wave < nblk;
+  const int blk = has ? cx.wave : 0;
+  const int cb = blk % CB, pbk = blk / CB;
+  int pb[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    int p = (pbk * PT + i) * 16 + cx.sig;
+    p = p < rg.R ? p : rg.R - 1;
+    int py, px;
+    pix_of(rg, p, py, px);
+    pb[i] = ((rg.fy0 + py) * CFG::LW + rg.fx0 + px) * CFG::PS + cx.gam * 16;
+  }
+  floatx4 acc[NT][PT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  int woff = (cb * S * NT * 64 + cx.lane) * 16;
+  asm volatile("" : "+v"(woff));
+  floatx4 bv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+  half8 af[SPT][NT];
+  auto load_a = [&](int seg) {
+#pragma unroll
+    for (int s = 0; s < SPT; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) af[s][t] = as_h8(*reinterpret_cast<const u32x4*>(w + woff + ((seg * SPT + s) * NT + t) * 1024));
+  };
+  load_a(0);
+#pragma unroll
+  for (int seg = 0; seg < 4; ++seg) {
+    if (seg > 0) pool_phase<CFG>(cx, P0, P1, gcat2 ? gcat2 + seg * C * 2 : nullptr, gpitch);
+    if (has) {
+#pragma unroll
+      for (int s = 0; s < SPT; ++s) {
+        half8 bf[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(P0 + pb[i] + s * 64));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < PT; ++i) acc[t][i] = mma16(af[s][t], bf[i], acc[t][i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (seg < 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(seg + 1);   // flies during the pool
+      }
+    }
+    if (seg < 3) lds_sync();   // every wave has read plane 0 before the pool overwrites it
+  }
+  if (has) {
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int p0 = (pbk * PT + i) * 16 + cx.sig;
+      const bool ok = p0 < rg.R;
+      const int p = ok ? p0 : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      floatx4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
+      epi(cb, ok, py, px, v);
+    }
   }
 }
 
@@ -680,7 +767,7 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   }
   C2F_STAMP(5)
 
-  // ---- [sppf] cv1 (out -> s) -> pools -> cv2 over concat(s, p1, p2, p3)
+  // ---- [sppf] cv1 (out -> s, plane 0) -> cv2 accumulated over s and the three cascaded pools (sppf_tail)
   if constexpr (CFG::MODE == 2) {
     wg_sync();
     const Rg rg = make_region<CFG>(cx, 0);
@@ -692,31 +779,26 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
           const int chb = cb * 16 * NT + 4 * NT * cx.g;
           half_t h[4 * NT];
           to_half<NT>(v, h);
-          const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
           if (ok) {
             store_h<NT>(P0 + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + chb * 2, h);
-            store_h<NT>(cat2 + (size_t)((unsigned)gpix * (unsigned)a.cat2_pitch) * 2 + chb * 2, h);
+            if (dbg) {
+              const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+              store_h<NT>(cat2 + (size_t)((unsigned)gpix * (unsigned)a.cat2_pitch) * 2 + chb * 2, h);
+            }
           }
         });
-    wg_sync();
-    pool_phase<CFG>(cx, P0, P1, cat2 + C * 2, a.cat2_pitch);
-    wg_sync();
-    pool_phase<CFG>(cx, P0, P1, cat2 + 2 * C * 2, a.cat2_pitch);
-    wg_sync();
-    pool_phase<CFG>(cx, P0, P1, cat2 + 3 * C * 2, a.cat2_pitch);
-    wg_sync();
+    lds_sync();
     C2F_STAMP(6)
     char* out2 = reinterpret_cast<char*>(a.out2);
-    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, 4 * C, 0, 0, false, false>(
-        cx, rg, nullptr, 0, cat2, a.cat2_pitch, nullptr, nullptr, ASrc<false>{reinterpret_cast<const char*>(a.w[C2F_W_SP2])}, a.b[C2F_W_SP2],
-        [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT2]) {
-          constexpr int NT = CFG::NT2;
-          const int chb = cb * 16 * NT + 4 * NT * cx.g;
-          half_t h[4 * NT];
-          to_half<NT>(v, h);
-          const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
-          if (ok) store_h<NT>(out2 + (size_t)((unsigned)gpix * (unsigned)a.out2_pitch) * 2 + chb * 2, h);
-        });
+    sppf_tail<CFG>(cx, rg, P0, P1, reinterpret_cast<const char*>(a.w[C2F_W_SP2]), a.b[C2F_W_SP2], dbg ? cat2 : nullptr, a.cat2_pitch,
+                   [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT2]) {
+                     constexpr int NT = CFG::NT2;
+                     const int chb = cb * 16 * NT + 4 * NT * cx.g;
+                     half_t h[4 * NT];
+                     to_half<NT>(v, h);
+                     const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+                     if (ok) store_h<NT>(out2 + (size_t)((unsigned)gpix * (unsigned)a.out2_pitch) * 2 + chb * 2, h);
+                   });
   }
   C2F_STAMP(7)
   C2F_STAMP(15)

@@ -1169,7 +1169,11 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const ConvArgs a, int k
       for (int ci = 0; ci < a.Cin; ++ci) acc = fmaf((float)px[ci], (float)wt[ci], acc);
     }
   }
-  float v = activate<T>(acc + a.bias[co], a.act);
+  float v;
+  if (a.res && a.res_first)  // ResNet BasicBlock: act(conv + bias + identity), as store_lane_at
+    v = activate<T>(acc + (float)reinterpret_cast<const T*>(a.res)[pix * a.res_pitch + co] + a.bias[co], a.act);
+  else
+    v = activate<T>(acc + a.bias[co], a.act);
   if (a.x1) {  // shuffle epilogue (see store_quad)
     if (co < a.half_c) {
       const int l = 2 * co;
@@ -1180,7 +1184,7 @@ __global__ __launch_bounds__(256) void conv_naive_kernel(const ConvArgs a, int k
     }
     return;
   }
-  if (a.res) v += (float)reinterpret_cast<const T*>(a.res)[pix * a.res_pitch + co];
+  if (a.res && !a.res_first) v += (float)reinterpret_cast<const T*>(a.res)[pix * a.res_pitch + co];
   if (a.out_f32)
     reinterpret_cast<float*>(a.out)[pix * a.out_pitch + co] = v;
   else

@@ -591,7 +591,8 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     io.cat = m.t_cat;
     io.out = tout;
     ensure_buffer(tout);
-    for (size_t q = 2; q < m.ys.size(); ++q) tensors_[m.ys[q]].materialised = true;
+    // (the y segments cv2 takes from LDS are only stored in the bisect mode, LITEPI_C2F_STORE_ALL=1)
+    for (size_t q = 2; q < m.ys.size(); ++q) tensors_[m.ys[q]].materialised = getenv("LITEPI_C2F_STORE_ALL") != nullptr || sh.C < 32;
     if (mode >= 1) {
       io.s2_in = cinfo[i0].tin;
       io.x = cinfo[i0].tout;
@@ -605,8 +606,10 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
       io.cat2 = get(L[spcat].outputs[0]);
       io.out2 = cinfo[js2].tout;
       ensure_buffer(io.out2);
-      for (int q = 0; q < 3; ++q) tensors_[get(L[pools[q]].outputs[0])].materialised = true;
-      tensors_[cinfo[js1].tout].materialised = true;
+      if (getenv("LITEPI_C2F_STORE_ALL")) {   // (s and the pooled maps stay in LDS otherwise: sppf_tail)
+        for (int q = 0; q < 3; ++q) tensors_[get(L[pools[q]].outputs[0])].materialised = true;
+        tensors_[cinfo[js1].tout].materialised = true;
+      }
       bytes += ((double)tensors_[io.out2].C - (double)tensors_[tout].C) * Hh * Ww * esd;
     }
     c2f_io_.push_back(io);

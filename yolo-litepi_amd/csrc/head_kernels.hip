@@ -426,8 +426,35 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
 #pragma unroll
   for (int p = 0; p < PB; ++p) {
     // B operands: element j of K step (mt, s) of this lane = channel 32*mt + 16*h + 8*s + j = accumulator register 8*s + j
-    floatx16 ob[2], oc;
-    ob[0] = bC0; ob[1] = bC1; oc = bCc;
+    // ---- class projection first: its best score decides whether the anchor can become a candidate at all
+    floatx16 oc = bCc;
+#pragma unroll
+    for (int mt = 0; mt < C3T; ++mt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) oc = mfma32(wcc[mt * 2 + s], silu_h8(accC[mt][p], 8 * s), oc);
+    // class scores: this lane holds the logits of classes 16*h .. 16*h + 15.  The sigmoid is monotonic: the best class is the
+    // arg-max of the LOGITS (selects, no branches, no transcendentals), and one sigmoid gives its score.
+    float bl = -INFINITY;
+    int best_c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float v = (16 * h + i < a.nc) ? oc[i] : -INFINITY;
+      const bool up = v > bl;   // strict: the first maximum in class order stays
+      bl = up ? v : bl;
+      best_c = up ? 16 * h + i : best_c;
+    }
+    const float obl = __shfl_xor(bl, 32);
+    const int oc_ = __shfl_xor(best_c, 32);
+    if (h == 0 && obl > bl) { bl = obl; best_c = oc_; }   // the upper half wins only if larger
+    const float best = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(bl * -1.4426950408889634f));
+    // ---- box projection + DFL decode only where it can matter: emit_candidate keeps an anchor iff best > conf (the same
+    //      expression, so the kept set is identical), and a typical image has a handful of such anchors among 8400 -- the box
+    //      tower's projection (8 of this loop's 10 MFMAs), its 32 SiLUs and the two 16-bin softmaxes per lane are most of
+    //      stage C's cycles.  Wave-uniform branch; the parity hook (out0) needs every anchor and takes it always.
+    const bool pass = pvalid[p] && h == 0 && best > a.conf;
+    if (a.out0 == nullptr && !__any(pass)) continue;
+    floatx16 ob[2];
+    ob[0] = bC0; ob[1] = bC1;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -436,10 +463,6 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
         ob[0] = mfma32(wcb[0][mt * 2 + s], bq, ob[0]);
         ob[1] = mfma32(wcb[1][mt * 2 + s], bq, ob[1]);
       }
-#pragma unroll
-    for (int mt = 0; mt < C3T; ++mt)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) oc = mfma32(wcc[mt * 2 + s], silu_h8(accC[mt][p], 8 * s), oc);
     // ---- decode (model.ncnn.param:184-208).  The projection rows are permuted so that this lane holds, for row tile rt,
     //      the 16 bins of box side 2*rt + h.
     float dist[2];
@@ -461,21 +484,6 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
     }
     const float x0 = __shfl_xor(dist[0], 32), x1 = __shfl_xor(dist[1], 32);
     const float d0 = h ? x0 : dist[0], d1 = h ? dist[0] : x0, d2 = h ? x1 : dist[1], d3 = h ? dist[1] : x1;
-    // class scores: this lane holds the logits of classes 16*h .. 16*h + 15.  The sigmoid is monotonic: the best class is the
-    // arg-max of the LOGITS (selects, no branches, no transcendentals), and one sigmoid gives its score.
-    float bl = -INFINITY;
-    int best_c = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float v = (16 * h + i < a.nc) ? oc[i] : -INFINITY;
-      const bool up = v > bl;   // strict: the first maximum in class order stays
-      bl = up ? v : bl;
-      best_c = up ? 16 * h + i : best_c;
-    }
-    const float obl = __shfl_xor(bl, 32);
-    const int oc_ = __shfl_xor(best_c, 32);
-    if (h == 0 && obl > bl) { bl = obl; best_c = oc_; }   // the upper half wins only if larger
-    const float best = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(bl * -1.4426950408889634f));
     if (pvalid[p]) {
       const int anchor = anchor_i[p];
       float* o = a.out0 ? a.out0 + (long)n * (4 + a.nc) * a.A + anchor : nullptr;

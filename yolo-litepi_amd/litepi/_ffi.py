@@ -45,8 +45,9 @@ SYMBOLS = [
     "lp_last_error", "lp_version", "lp_default_config", "lp_create", "lp_destroy", "lp_load_detector_ncnn",
     "lp_load_classifier_tensors", "lp_detect_raw", "lp_detect", "lp_run_batch", "lp_run_batch_device", "lp_classify",
     "lp_set_stream", "lp_synchronize", "lp_profile_next", "lp_profile_read", "lp_detector_info", "lp_debug_blob",
-    "lp_test_conv", "lp_test_postprocess", "lp_test_nms_boxes", "lp_test_roi_resize", "lp_test_letterbox",
+    "lp_test_conv", "lp_test_postprocess", "lp_test_nms_boxes", "lp_test_roi_resize", "lp_test_letterbox", "lp_roi_overflow",
 ]
+ABI_VERSION = 300   # include/litepi.h LP_ABI_VERSION: a library built from another header is refused (load_library)
 
 _lib: Optional[C.CDLL] = None
 
@@ -90,9 +91,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.lp_test_nms_boxes.argtypes = [vp, fp, fp, ip, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, vp, ip, ip, ip]
     lib.lp_test_roi_resize.argtypes = [vp, u8pp, ip, ip, C.c_int, vp]
     lib.lp_test_letterbox.argtypes = [vp, vp, C.c_int, C.c_int, vp, fp, fp, fp]
+    lib.lp_roi_overflow.argtypes = [vp, ip, ip]
     for s in SYMBOLS:
         if s not in ("lp_last_error", "lp_default_config", "lp_destroy"):
             getattr(lib, s).restype = C.c_int
+    got = lib.lp_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{p} has ABI version {got}, these bindings need {ABI_VERSION}: rebuild with `python yolo-litepi_amd/build.py`")
     if path is None:
         _lib = lib
     return lib

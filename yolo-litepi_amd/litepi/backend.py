@@ -135,6 +135,12 @@ class Engine:
         check(self.lib, self.lib.lp_run_batch_device(self._h, C.c_void_p(dev_imgs), B, H, W, conf, iou, int(min_area),
                                                      C.c_void_p(dev_dets), C.c_void_p(dev_counts)))
 
+    def roi_overflow(self) -> Tuple[int, int]:
+        """(classified, kept) of the last run_batch_device call (synchronises): kept > classified means max_rois was too small."""
+        a, b = C.c_int(), C.c_int()
+        check(self.lib, self.lib.lp_roi_overflow(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def classify(self, rois: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
         imgs, ptrs, hs, ws = self._img_args(rois)
         R = len(imgs)
@@ -418,7 +424,7 @@ class PyTorchClassifier:
     """e2e.py:350-396 (name kept for drop-in use; the model runs in HIP, not torch)."""
 
     def __init__(self, model_path: str, arch: str, num_classes: int = 58, input_size: int = 64, device: str = "cpu", *,
-                 precision: str = "fp16", max_rois: int = 1024, _engine: Optional[Engine] = None):
+                 precision: str = "fp16", max_rois: int = 1024, conv_impl: int = 0, _engine: Optional[Engine] = None):
         if arch not in ("shufflenetv2", "resnet18"):
             raise ValueError(f"Unknown architecture for the HIP backend: {arch} (shufflenetv2 and resnet18 are accelerated; "
                              "efficientnet / mobilenetv2 of e2e.py:324-329 are not)")
@@ -428,7 +434,7 @@ class PyTorchClassifier:
         print(f"[HIP Classifier] Loading {arch} model...")
         print(f"  Model: {model_path}")
         self.engine = _engine or Engine(precision=precision, max_batch=1, max_det=max_rois, num_classes=num_classes,
-                                        cls_input=input_size, max_rois=max_rois, cls_arch=arch)
+                                        cls_input=input_size, max_rois=max_rois, cls_arch=arch, conv_impl=conv_impl)
         if self.engine.cls_arch != arch:
             raise ValueError(f"the engine was created for {self.engine.cls_arch}, not {arch}")
         sd, self.weights_loaded = load_classifier_state(model_path, num_classes, arch)
@@ -476,9 +482,9 @@ class HybridPipeline:
                 raise
             print(f"[HIP Pipeline] engine failure, returning no detections: {e}")
             return [([], PipelineMetrics()) for _ in images]
+        wall_ms = (time.perf_counter() - t0) * 1000.0   # t_total ends here; system metrics are sampled after it (e2e.py:505-516)
         conf_avg = self.engine.last_det_conf_avg
         sysm = _system_metrics()
-        wall_ms = (time.perf_counter() - t0) * 1000.0
         B = len(images)
         out = []
         for i in range(B):

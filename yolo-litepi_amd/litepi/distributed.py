@@ -63,9 +63,11 @@ class Gatherer:
     owns ``world`` receive slots of payload size; ``gather(buf)`` is one ``dist.gather`` (RCCL
     ``ncclGather``-style send/recv over xGMI on GPUs, gloo in the CPU tests) and returns views."""
 
-    def __init__(self, like: ResultBuffers, dst: int = 0, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, like: ResultBuffers, dst: int = 0, group: Optional[dist.ProcessGroup] = None, force: bool = False):
+        """force: run the collective even in a world of one (a self-gather: how the RCCL path is exercised on a
+        single-GPU box, ``bench.py --rccl-self`` and tests/test_gpu_device_path.py)."""
         self.dst, self.group = dst, group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.batch, self.max_det = like.batch, like.max_det
