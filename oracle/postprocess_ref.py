@@ -182,3 +182,31 @@ def roi_rects(boxes: np.ndarray, h: int, w: int, min_area: int = 100):
             rects.append((int(x1), int(y1), int(x2), int(y2)))
             valid.append(idx)
     return np.array(rects, np.int64).reshape(-1, 4), valid
+
+
+# ---- helpers of the fp16 comparisons (tests/, __graft_entry__.smoke) -------------------------------------------------
+def box_match(b, e, slack_px=4.0):
+    return np.abs(np.asarray(b, np.float64) - np.asarray(e, np.float64)).max() <= slack_px + 0.02 * np.abs(np.asarray(e, np.float64)).max()
+
+
+def stable_boxes(out0, hw, conf, iou, min_area, rng, trials=12, band=0.02):
+    """Oracle post-NMS boxes (score > conf + band, area filter passed) whose presence does not hinge on a near-tie: the
+    box must survive `trials` re-runs of the oracle's postprocess on out0 perturbed by the documented fp16 error scale
+    (scores +-0.015, box centres / sizes +-2 px).  What is left is what an fp16 detector has no excuse to miss; a box
+    that an NMS order swap or an IoU within a hair of the threshold can remove is excluded -- that, and the +-band around
+    the conf threshold, is the documented exclusion zone of the fp16 comparison."""
+    eb, es, _ = postprocess(out0, hw, 1.0, (0.0, 0.0), conf, iou)
+    if len(eb) == 0:
+        return []
+    _, valid = roi_rects(eb, hw[0], hw[1], min_area)
+    keep = [i for i in valid if es[i] > conf + band]
+    alive = {i: True for i in keep}
+    for _ in range(trials):
+        o = out0.copy()
+        o[4:] = np.clip(o[4:] + rng.uniform(-0.015, 0.015, o[4:].shape).astype(np.float32), 0, 1)
+        o[:4] += rng.uniform(-2.0, 2.0, o[:4].shape).astype(np.float32)
+        pb, _, _ = postprocess(o, hw, 1.0, (0.0, 0.0), conf, iou)
+        for i in keep:
+            if alive[i] and not any(box_match(q, eb[i], 6.0) for q in pb):
+                alive[i] = False
+    return [(eb[i], float(es[i])) for i in keep if alive[i]]

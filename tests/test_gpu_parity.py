@@ -139,6 +139,16 @@ def test_nms_reference_goldens(eng32, golden_dir):
         thr = float(g[key + "_thr"])
         eb, es, ec = P.postprocess(out0, (640, 640), 1.0, (0.0, 0.0), 0.0001, thr)
         _check_post(eng32, out0, (640, 640), 1.0, (0.0, 0.0), 0.0001, thr, eb, es, ec)
+        # ... and directly against the REFERENCE's kept indices: the device's kept boxes, in its order, are boxes[keep] in the
+        # reference's order (nms_numpy returns indices by descending score; one class here, so the orders coincide)
+        d = eng32.test_postprocess(out0, (640, 640), 1.0, (0.0, 0.0), 0.0001, thr)
+        gb, gs = np.stack([d["x1"], d["y1"], d["x2"], d["y2"]], 1), d["det_conf"]
+        keep = np.asarray(keep).astype(np.int64).ravel()
+        sel = keep[scores[keep] > 0.0001]
+        assert len(gb) == len(sel), f"{key}: device kept {len(gb)} boxes, the reference's nms_numpy kept {len(sel)}"
+        ref_sorted = sel[np.argsort(-scores[sel], kind="stable")]
+        assert np.array_equal(np.asarray(gs, np.float32), scores[ref_sorted].astype(np.float32)), f"{key}: kept scores differ from the reference's"
+        assert np.abs(np.asarray(gb, np.float32) - boxes[ref_sorted].astype(np.float32)).max() <= 1e-3, f"{key}: kept boxes differ from the reference's"
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
@@ -508,32 +518,7 @@ def _calibrate(param, binf, imgs, per_image):
     ncnn_export.shift_cls_bias(param, binf, float(np.log(0.25 / 0.75) - logit))
 
 
-def _box_match(b, e, slack_px=4.0):
-    return np.abs(np.asarray(b, np.float64) - np.asarray(e, np.float64)).max() <= slack_px + 0.02 * np.abs(np.asarray(e, np.float64)).max()
-
-
-def _stable_oracle_boxes(out0, hw, conf, iou, min_area, rng, trials=12, band=0.02):
-    """Oracle post-NMS boxes (score > conf + band, area filter passed) whose presence does not hinge on a near-tie: the
-    box must survive `trials` re-runs of the oracle's postprocess on out0 perturbed by the documented fp16 error scale
-    (scores +-0.015, box centres / sizes +-2 px).  What is left is what an fp16 detector has no excuse to miss; a box
-    that an NMS order swap or an IoU within a hair of the threshold can remove is excluded -- that, and the +-band around
-    the conf threshold, is the documented exclusion zone of the fp16 comparison."""
-    from oracle import postprocess_ref as P
-    eb, es, _ = P.postprocess(out0, hw, 1.0, (0.0, 0.0), conf, iou)
-    if len(eb) == 0:
-        return []
-    _, valid = P.roi_rects(eb, hw[0], hw[1], min_area)
-    keep = [i for i in valid if es[i] > conf + band]
-    alive = {i: True for i in keep}
-    for _ in range(trials):
-        o = out0.copy()
-        o[4:] = np.clip(o[4:] + rng.uniform(-0.015, 0.015, o[4:].shape).astype(np.float32), 0, 1)
-        o[:4] += rng.uniform(-2.0, 2.0, o[:4].shape).astype(np.float32)
-        pb, _, _ = P.postprocess(o, hw, 1.0, (0.0, 0.0), conf, iou)
-        for i in keep:
-            if alive[i] and not any(_box_match(q, eb[i], 6.0) for q in pb):
-                alive[i] = False
-    return [(eb[i], float(es[i])) for i in keep if alive[i]]
+from oracle.postprocess_ref import box_match as _box_match, stable_boxes as _stable_oracle_boxes  # noqa: E402
 
 
 def _check_fp16_against_oracle(pipe, layers, cls_model, imgs, conf=0.25, iou=0.45, min_area=50):
@@ -556,8 +541,8 @@ def _check_fp16_against_oracle(pipe, layers, cls_model, imgs, conf=0.25, iou=0.4
     assert err_b.mean() <= 0.5
     outs = pipe.run_batch(list(imgs), conf, iou, min_area)
     rng = np.random.default_rng(99)
-    stat = dict(score_err=float(err_s.max()), box_err=float(err_b.max()), box_err_mean=float(err_b.mean()), boxes=0, stable=0, missed=0,
-                cls_checked=0, cls_flips_in_margin=0, prob_err=0.0)
+    stat = dict(score_err=float(err_s.max()), box_err=float(err_b.max()), box_err_mean=float(err_b.mean()), boxes=0, stable=0, missed=0, unstable=0,
+                unstable_missed=0, cls_checked=0, cls_flips_in_margin=0, prob_err=0.0)
     for i in range(B):
         res, met = outs[i]
         hw = imgs[i].shape[:2]
@@ -591,12 +576,27 @@ def _check_fp16_against_oracle(pipe, layers, cls_model, imgs, conf=0.25, iou=0.4
         for box, sc in stable:
             hit = any(_box_match(fb, box.astype(int)) and abs(r["det_conf"] - sc) <= 0.02 for fb, r in zip(fboxes, res))
             stat["missed"] += 0 if hit else 1
+        # ... and the oracle boxes the stability filter set aside (score > conf + band, area filter passed, but a +-0.015 /
+        # +-2 px perturbation can remove them): counted and bounded too, so the exclusion zone is visible
+        eb0, es0, _ = P.postprocess(ref0[i], hw, 1.0, (0.0, 0.0), conf, iou)
+        if len(eb0):
+            _, valid0 = P.roi_rects(eb0, hw[0], hw[1], min_area)
+            for k in valid0:
+                if es0[k] <= conf + 0.02 or any(np.array_equal(eb0[k], sb) for sb, _ in stable):
+                    continue
+                stat["unstable"] += 1
+                hit = any(_box_match(fb, eb0[k].astype(int)) and abs(r["det_conf"] - float(es0[k])) <= 0.02 for fb, r in zip(fboxes, res))
+                stat["unstable_missed"] += 0 if hit else 1
         # nothing invented: a confident device box sits on an oracle candidate (pre-NMS, score > conf - band)
         cb, cs, _ = P.postprocess(ref0[i], hw, 1.0, (0.0, 0.0), conf - 0.02, 1.0)   # iou 1.0: every candidate survives
         for fb, r in zip(fboxes, res):
             if r["det_conf"] > conf + 0.02:
                 assert any(_box_match(fb, q.astype(int)) for q in cb), f"image {i}: device box {r['bbox']} has no oracle candidate"
     assert stat["missed"] == 0, f"{stat['missed']} of {stat['stable']} stable oracle boxes missed"
+    print(f"unstable oracle boxes (set aside by the perturbation filter): {stat['unstable']}, of which the fp16 path missed {stat['unstable_missed']}")
+    # boxes whose survival hinges on a near-tie may go either way, but only a small share of them does: at most 1 in 5
+    # (the filter's own perturbations, +-0.015 / +-2 px, are 2-5 x the measured fp16 error)
+    assert stat["unstable_missed"] <= max(2, stat["unstable"] // 5), f"{stat['unstable_missed']} of {stat['unstable']} unstable oracle boxes missed"
     return stat
 
 
@@ -1111,12 +1111,30 @@ def test_capacity_128_matches_capacity_64(tmp_path):
         try:
             out = pipe.run_batch(list(imgs[:cap]), 0.25, 0.45, 50)
             out = pipe.run_batch(list(imgs[:cap]), 0.25, 0.45, 50)   # second call: the captured graph
-            res[cap] = [[(r["bbox"], round(r["det_conf"], 3)) for r in rr] for rr, _ in out]
+            res[cap] = [[(r["bbox"], r["det_conf"]) for r in rr] for rr, _ in out]
         finally:
             pipe.engine.close()
     nbox = sum(len(x) for x in res[64])
     same = sum(1 for a, c in zip(res[64], res[128][:64]) if [q[0] for q in a] == [q[0] for q in c])
-    print(f"capacity 64 vs 128: {nbox} boxes in 64 images, {same}/64 images with identical box lists; "
+    # The two handles pick different tile shapes, so the same convolution sums its terms in another order and scores differ in
+    # the last fp16 bits (printed).  A box may therefore exist in one list only when its score is within BAND of the
+    # threshold (or, through NMS, when the box that suppresses it is); everything else must agree box for box.
+    BAND = 0.01
+    max_ds, flips = 0.0, 0
+    for i, (a, c) in enumerate(zip(res[64], res[128][:64])):
+        for (ba, sa) in a:
+            m = [sc for (bc, sc) in c if np.abs(np.array(ba) - np.array(bc)).max() <= 2]
+            if m:
+                max_ds = max(max_ds, min(abs(sa - x) for x in m))
+            else:
+                flips += 1
+                assert sa <= 0.25 + BAND or any(sx <= 0.25 + BAND for _, sx in a + c), f"image {i}: box {ba} ({sa:.4f}) only at capacity 64"
+        for (bc, sc) in c:
+            if not any(np.abs(np.array(bc) - np.array(ba)).max() <= 2 for (ba, _) in a):
+                flips += 1
+                assert sc <= 0.25 + BAND or any(sx <= 0.25 + BAND for _, sx in a + c), f"image {i}: box {bc} ({sc:.4f}) only at capacity 128"
+    print(f"capacity 64 vs 128: {nbox} boxes in 64 images, {same}/64 images with identical box lists, {flips} boxes in one list only "
+          f"(all within {BAND} of conf, directly or through NMS), max score difference of matched boxes {max_ds:.5f}; "
           f"{sum(len(x) for x in res[128])} boxes in 128 images")
-    assert nbox >= 64 and same >= 60   # different tile shapes sum in different orders: a box at the conf threshold may flip
+    assert nbox >= 64 and max_ds <= 5e-3
     assert sum(len(x) for x in res[128][64:]) >= 32
