@@ -38,7 +38,7 @@ enum lp_status {
 
 enum lp_precision { LP_FP32 = 0, LP_FP16 = 1 };
 enum lp_numerics { LP_NUMERICS_E2E = 0, LP_NUMERICS_E2E_OPTIMIZE = 1 };
-enum lp_cls_arch { LP_CLS_SHUFFLENETV2 = 0, LP_CLS_RESNET18 = 1 };
+enum lp_cls_arch { LP_CLS_SHUFFLENETV2 = 0, LP_CLS_RESNET18 = 1, LP_CLS_MOBILENETV2 = 2, LP_CLS_EFFICIENTNET_B0 = 3 };   /* e2e.py:320-333 */
 
 typedef struct lp_config {
   int device;        /* HIP device ordinal */

@@ -1138,3 +1138,70 @@ def test_capacity_128_matches_capacity_64(tmp_path):
           f"{sum(len(x) for x in res[128])} boxes in 128 images")
     assert nbox >= 64 and max_ds <= 5e-3
     assert sum(len(x) for x in res[128][64:]) >= 32
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MobileNetV2 / EfficientNet-B0 classifiers (--clf_arch mobilenetv2 | efficientnet, e2e.py:324-329).  PARITY UNPINNED by the
+# reference (no weights or outputs for them; torchvision absent): the checker is oracle/mbnet_ref.py on seeded synthetic
+# weights, whose parameter counts equal torchvision's published ones (tests/test_oracle_cpu.py).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arch", ["mobilenetv2", "efficientnet"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_mbnet_classifier_matches_oracle(tmp_path, precision, arch):
+    from litepi import PyTorchClassifier
+    from oracle import mbnet_ref as M
+    ncls = 58
+    sd = M.seeded_state_dict(arch, ncls)
+    path = str(tmp_path / f"{arch}.pth")
+    torch.save(sd, path)
+    model = M.build(arch, ncls, sd)
+    rng = np.random.default_rng(8)
+    rois = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in
+            ((64, 64), (31, 47), (12, 9), (90, 120), (200, 150), (64, 33), (17, 17), (75, 64), (40, 40), (128, 96), (55, 21))]
+    clf = PyTorchClassifier(path, arch, ncls, precision=precision, max_rois=64)
+    try:
+        ids, probs = clf.predict_batch(rois)
+        assert clf.weights_loaded
+    finally:
+        clf.engine.close()
+    eids, eprobs = M.predict_batch(model, rois)
+    err = float(np.abs(probs - eprobs).max())
+    print(f"{arch} {precision}: max prob err {err:.2e}")
+    tol = 2e-4 if precision == "fp32" else 4e-2
+    assert probs.shape == eprobs.shape and err <= tol
+    for i in range(len(rois)):
+        top2 = np.sort(eprobs[i])[-2:]
+        assert ids[i] == eids[i] or top2[1] - top2[0] < 2 * tol
+
+
+@pytest.mark.parametrize("arch", ["mobilenetv2", "efficientnet"])
+def test_mbnet_pipeline_end_to_end(tmp_path, arch):
+    """--clf_arch mobilenetv2 / efficientnet through HybridPipeline.run_batch: every kept box is classified by the chosen network."""
+    from litepi import HybridPipeline
+    from oracle import mbnet_ref as M
+    p, b, imgs = _calibrated_model(tmp_path)
+    ncls = 58
+    sd = M.seeded_state_dict(arch, ncls)
+    cls_path = str(tmp_path / "cls.pth")
+    torch.save(sd, cls_path)
+    model = M.build(arch, ncls, sd)
+    pipe = HybridPipeline(p, b, cls_path, arch, num_classes=ncls, precision="fp32", max_batch=2, max_det=300)
+    try:
+        outs = pipe.run_batch([imgs[0], imgs[1]], 0.25, 0.45, 50)
+    finally:
+        pipe.engine.close()
+    total = 0
+    for i in range(2):
+        res, _ = outs[i]
+        crops = [imgs[i][max(r["bbox"][1], 0):r["bbox"][3], max(r["bbox"][0], 0):r["bbox"][2]] for r in res]
+        crops = [c for c in crops if c.size]
+        if not crops:
+            continue
+        ids, probs = M.predict_batch(model, crops)
+        for r, cid, pr in zip(res, ids, probs):
+            assert r["cls_class"] >= 0
+            top2 = np.sort(pr)[-2:]
+            assert r["cls_class"] == int(cid) or top2[1] - top2[0] < 5e-3
+            assert abs(r["cls_conf"] - float(pr[r["cls_class"]])) <= 5e-3
+            total += 1
+    assert total >= 4

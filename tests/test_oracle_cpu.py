@@ -251,3 +251,25 @@ def test_resnet18_oracle_shapes_and_param_count():
     assert y.shape == (3, 58) and f.shape == (3, 512, 2, 2) and torch.isfinite(y).all()
     ids, probs = R.predict_batch(m, [np.random.default_rng(0).integers(0, 256, (40, 30, 3), dtype=np.uint8)])
     assert probs.shape == (1, 58) and abs(float(probs.sum()) - 1.0) < 1e-5
+
+
+def test_mbnet_oracles_have_torchvision_parameter_counts_and_keys():
+    """oracle/mbnet_ref.py restates torchvision's mobilenet_v2 / efficientnet_b0 (torchvision is absent here): the parameter
+    counts must equal the published ones (3,504,872 / 5,288,548 at 1000 classes) and the state_dict keys torchvision's layout,
+    and the backend's random-init fallback must produce exactly those keys and shapes."""
+    import torch
+    from litepi.backend import random_efficientnet_state, random_mobilenetv2_state
+    from oracle import mbnet_ref as M
+    for arch, published, rnd, first, last in (("mobilenetv2", 3504872, random_mobilenetv2_state, "features.1.conv.0.0.weight", "features.18.1.running_var"),
+                                              ("efficientnet", 5288548, random_efficientnet_state, "features.1.0.block.1.fc1.weight", "features.8.1.running_var")):
+        m = M.build(arch, 1000)
+        assert sum(p.numel() for p in m.parameters()) == published, arch
+        sd = m.state_dict()
+        assert first in sd and last in sd and "classifier.1.weight" in sd
+        keys = sorted(k for k in sd if not k.endswith("num_batches_tracked"))
+        r = rnd(1000)
+        assert sorted(r.keys()) == keys
+        assert all(tuple(sd[k].shape) == r[k].shape for k in keys)
+    x = torch.zeros(1, 3, 64, 64)
+    with torch.no_grad():
+        assert M.build("mobilenetv2", 58)(x).shape == (1, 58) and M.build("efficientnet", 58)(x).shape == (1, 58)

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "litepi", "liblitepi_hip.so")
-SOURCES = ["api.cpp", "ncnn_graph.cpp", "detector.cpp", "classifier.cpp", "resnet.cpp",
+SOURCES = ["api.cpp", "ncnn_graph.cpp", "detector.cpp", "classifier.cpp", "resnet.cpp", "mbnet.cpp",
            "conv_kernels.hip", "misc_kernels.hip", "post_kernels.hip", "cls_kernels.hip", "cls_fused.hip", "cls_net.hip", "head_kernels.hip", "c2f_kernels.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off", "-fgpu-flush-denormals-to-zero"]

@@ -8,6 +8,7 @@
 #include <set>
 
 #include "classifier.h"
+#include "mbnet.h"
 #include "resnet.h"
 #include "common.h"
 #include "detector.h"
@@ -202,7 +203,7 @@ int lp_create(const lp_config* cfg, lp_handle** out) {
   LP_CHECK(cfg && out, LP_ERR_ARG, "null argument");
   LP_CHECK(cfg->max_batch >= 1 && cfg->max_batch <= 1024 && cfg->max_det >= 1 && cfg->det_input % 32 == 0 && cfg->det_input >= 64,
            LP_ERR_ARG, "bad config (max_batch %d, max_det %d, det_input %d)", cfg->max_batch, cfg->max_det, cfg->det_input);
-  LP_CHECK((cfg->numerics == 0 || cfg->numerics == 1) && (cfg->cls_arch == 0 || cfg->cls_arch == 1), LP_ERR_ARG,
+  LP_CHECK((cfg->numerics == 0 || cfg->numerics == 1) && cfg->cls_arch >= 0 && cfg->cls_arch <= LP_CLS_EFFICIENTNET_B0, LP_ERR_ARG,
            "bad config (numerics %d, cls_arch %d)", cfg->numerics, cfg->cls_arch);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device)
@@ -219,7 +220,8 @@ int lp_create(const lp_config* cfg, lp_handle** out) {
   // the classifier's widest per-ROI tensor must stay below 2^31 elements (32-bit element offsets in the conv kernels): say so
   // here, not at the first launch.  ShuffleNetV2 / ResNet18 at cls_input S: conv1 output 24 (64) channels at (S/2)^2.
   {
-    const double per_roi = (double)(cfg->cls_arch == LP_CLS_RESNET18 ? 64 : 24) * (cfg->cls_input / 2.0) * (cfg->cls_input / 2.0);
+    const double per_roi = cfg->cls_arch >= LP_CLS_MOBILENETV2 ? MBNetClassifier::widest_per_roi(cfg->cls_input)
+                                                               : (double)(cfg->cls_arch == LP_CLS_RESNET18 ? 64 : 24) * (cfg->cls_input / 2.0) * (cfg->cls_input / 2.0);
     LP_CHECK(per_roi * h->max_rois < 2147483648.0, LP_ERR_ARG,
              "max_rois = %d (max_batch %d x max_det %d when left 0) makes the classifier's activations exceed 2^31 elements; lower "
              "max_det or set max_rois (at most %d for this classifier)", h->max_rois, cfg->max_batch, cfg->max_det, (int)(2147483647.0 / per_roi));
@@ -281,6 +283,9 @@ int lp_load_classifier_tensors(lp_handle* h, int n, const char* const* names, co
   }
   std::unique_ptr<ClassifierBase> c;
   if (h->cfg.cls_arch == LP_CLS_RESNET18) c.reset(new ResNet18Classifier(h->cfg.precision, h->cfg.conv_impl, h->max_rois, h->cfg.num_classes, h->cfg.cls_input));
+  else if (h->cfg.cls_arch == LP_CLS_MOBILENETV2 || h->cfg.cls_arch == LP_CLS_EFFICIENTNET_B0)
+    c.reset(new MBNetClassifier(h->cfg.cls_arch == LP_CLS_MOBILENETV2 ? MBNetClassifier::MOBILENET_V2 : MBNetClassifier::EFFICIENTNET_B0, h->cfg.precision,
+                                h->cfg.conv_impl, h->max_rois, h->cfg.num_classes, h->cfg.cls_input));
   else c.reset(new Classifier(h->cfg.precision, h->cfg.conv_impl, h->max_rois, h->cfg.num_classes, h->cfg.cls_input));
   c->load(sd);
   h->drop_graphs();

@@ -280,6 +280,155 @@ void launch_spatial_mean(int prec, const View& in, const View& out, const int* m
 }
 
 // ------------------------------------------------------------------------------------
+// MobileNetV2 / EfficientNet-B0 pieces (mbnet.cpp; build_classifier('mobilenetv2' | 'efficientnet'), e2e.py:324-329).
+// Activation codes as common.h Act, plus 3 = ReLU6 for the kernels of this section.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float mb_act(float v, int act) {
+  if (act == 1) return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));   // SiLU, as Tr<T>::silu
+  if (act == 2) return fmaxf(v, 0.f);
+  if (act == 3) return fminf(fmaxf(v, 0.f), 6.f);
+  return v;
+}
+
+// features[0]: 3x3 stride 2 pad 1, 3 -> CO (a multiple of 8), + folded BN + activation, on t = (x/255 - 0.18)/0.34.
+// One thread per (output pixel, 8-channel group); w fp32 [27][CO] in (ky, kx, rgb) order.
+template <typename T>
+__global__ __launch_bounds__(256) void cls_stem_act_kernel(const uint8_t* __restrict__ rgb, T* __restrict__ out, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int S, int CO, int act, int out_pitch,
+                                                           const int* __restrict__ m_dyn) {
+  const int So = S / 2, CG = CO / 8;
+  const long total = (long)(*m_dyn) * So * So * CG;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    const long pix = idx / CG;
+    const int ox = (int)(pix % So);
+    const int oy = (int)((pix / So) % So);
+    const long r = pix / ((long)So * So);
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= S) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= S) continue;
+        const uint8_t* px = rgb + ((r * S + iy) * S + ix) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float t = __fdiv_rn(__fsub_rn(__fdiv_rn((float)px[c], 255.f), 0.18f), 0.34f);
+          const float* wr = w + ((ky * 3 + kx) * 3 + c) * CO + cg * 8;
+#pragma unroll
+          for (int co = 0; co < 8; ++co) acc[co] = fmaf(t, wr[co], acc[co]);
+        }
+      }
+    }
+    T* o = out + pix * out_pitch + cg * 8;
+#pragma unroll
+    for (int co = 0; co < 8; ++co) o[co] = (T)mb_act(acc[co] + bias[cg * 8 + co], act);
+  }
+}
+
+void launch_cls_stem_act(int prec, const uint8_t* rgb, const float* w, const float* bias, int CO, int act, const View& out, int S,
+                         const int* m_dyn, int max_items, hipStream_t st) {
+  LP_CHECK(CO % 8 == 0, LP_ERR_STATE, "classifier stem: output channels must be a multiple of 8");
+  dim3 grid(grid_for((long)max_items * (S / 2) * (S / 2) * (CO / 8)));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(cls_stem_act_kernel<half_t>, grid, dim3(256), 0, st, rgb, (half_t*)out.base, w, bias, S, CO, act, out.pitch, m_dyn);
+  else
+    hipLaunchKernelGGL(cls_stem_act_kernel<float>, grid, dim3(256), 0, st, rgb, (float*)out.base, w, bias, S, CO, act, out.pitch, m_dyn);
+  LP_HIP(hipGetLastError());
+}
+
+// depthwise k x k (k = 3 | 5), pad k/2, stride 1|2, + bias (folded BN) + activation; w fp32 [k*k][C]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_act_kernel(const T* __restrict__ in, T* __restrict__ out, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int H, int W, int Ho, int Wo, int C, int k, int stride,
+                                                         int act, int in_pitch, int out_pitch, const int* __restrict__ m_dyn) {
+  typedef typename VecT<T>::type vec;
+  constexpr int G = VecT<T>::G;
+  const int CG = C / G, pad = k / 2;
+  const long total = (long)(*m_dyn) * Ho * Wo * CG;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    const long pix = idx / CG;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const long r = pix / ((long)Wo * Ho);
+    float acc[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) acc[i] = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * stride - pad + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * stride - pad + kx;
+        if (ix < 0 || ix >= W) continue;
+        const vec v = *reinterpret_cast<const vec*>(in + ((r * H + iy) * W + ix) * in_pitch + cg * G);
+        const float* wr = w + (ky * k + kx) * C + cg * G;
+#pragma unroll
+        for (int i = 0; i < G; ++i) acc[i] = fmaf((float)v[i], wr[i], acc[i]);
+      }
+    }
+    vec o;
+#pragma unroll
+    for (int i = 0; i < G; ++i) o[i] = (T)mb_act(acc[i] + bias[cg * G + i], act);
+    *reinterpret_cast<vec*>(out + pix * out_pitch + cg * G) = o;
+  }
+}
+
+void launch_dwconv_act(int prec, const View& in, const View& out, const float* w, const float* bias, int k, int stride, int act,
+                       const int* m_dyn, int max_items, hipStream_t st) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  dim3 grid(grid_for((long)max_items * out.H * out.W * (in.C / G)));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(dwconv_act_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, w, bias, in.H, in.W,
+                       out.H, out.W, in.C, k, stride, act, in.pitch, out.pitch, m_dyn);
+  else
+    hipLaunchKernelGGL(dwconv_act_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, w, bias, in.H, in.W, out.H,
+                       out.W, in.C, k, stride, act, in.pitch, out.pitch, m_dyn);
+  LP_HIP(hipGetLastError());
+}
+
+// in place: x = min(x, cap) (ReLU6 behind a conv whose epilogue already applied ReLU), or, with scale != null, the
+// squeeze-excitation gate x[r, p, c] *= sigmoid(scale[r, c]) (torchvision SqueezeExcitation.forward: scale * input)
+template <typename T>
+__global__ __launch_bounds__(256) void mb_eltwise_kernel(T* __restrict__ x, const T* __restrict__ scale, int HW, int C, int pitch, int spitch, float cap,
+                                                         const int* __restrict__ m_dyn) {
+  typedef typename VecT<T>::type vec;
+  constexpr int G = VecT<T>::G;
+  const int CG = C / G;
+  const long total = (long)(*m_dyn) * HW * CG;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    const long pix = idx / CG;
+    vec v = *reinterpret_cast<const vec*>(x + pix * pitch + cg * G);
+    if (scale) {
+      const long r = pix / HW;
+      const vec sv = *reinterpret_cast<const vec*>(scale + r * spitch + cg * G);
+#pragma unroll
+      for (int i = 0; i < G; ++i) v[i] = (T)((float)v[i] * __builtin_amdgcn_rcpf(1.f + __expf(-(float)sv[i])));
+    } else {
+#pragma unroll
+      for (int i = 0; i < G; ++i) v[i] = (T)fminf((float)v[i], cap);
+    }
+    *reinterpret_cast<vec*>(x + pix * pitch + cg * G) = v;
+  }
+}
+
+void launch_mb_eltwise(int prec, const View& x, const View* scale, float cap, const int* m_dyn, int max_items, hipStream_t st) {
+  const int G = prec == LP_FP16 ? 8 : 4;
+  dim3 grid(grid_for((long)max_items * x.H * x.W * (x.C / G)));
+  if (prec == LP_FP16)
+    hipLaunchKernelGGL(mb_eltwise_kernel<half_t>, grid, dim3(256), 0, st, (half_t*)x.base, scale ? (const half_t*)scale->base : nullptr, x.H * x.W,
+                       x.C, x.pitch, scale ? scale->pitch : 0, cap, m_dyn);
+  else
+    hipLaunchKernelGGL(mb_eltwise_kernel<float>, grid, dim3(256), 0, st, (float*)x.base, scale ? (const float*)scale->base : nullptr, x.H * x.W, x.C,
+                       x.pitch, scale ? scale->pitch : 0, cap, m_dyn);
+  LP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------
 // softmax(dim=1) + argmax (e2e.py:394-396), one wavefront per ROI (classes strided over lanes,
 // wave-level max / sum / arg-max reductions)
 // ------------------------------------------------------------------------------------

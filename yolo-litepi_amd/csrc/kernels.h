@@ -115,6 +115,15 @@ void launch_maxpool3x3s2(int prec, const View& in, const View& out, const int* m
 // depthwise 3x3 pad 1 stride 1|2 + folded BN (no activation); w fp32 [9][C], bias fp32 [C]
 void launch_dwconv3x3(int prec, const View& in, const View& out, const float* w, const float* bias, int stride,
                       const int* m_dyn, int max_items, hipStream_t st);
+// MobileNetV2 / EfficientNet-B0 (mbnet.cpp).  act: 0 none, 1 SiLU, 2 ReLU, 3 ReLU6.
+// features[0] 3x3/s2 (3 -> CO) + folded BN + activation on the normalised uint8 crops; w fp32 [27][CO] in (ky, kx, rgb) order
+void launch_cls_stem_act(int prec, const uint8_t* rgb, const float* w, const float* bias, int CO, int act, const View& out, int S,
+                         const int* m_dyn, int max_items, hipStream_t st);
+// depthwise k x k (3 | 5), pad k/2, stride 1|2, + folded BN + activation; w fp32 [k*k][C]
+void launch_dwconv_act(int prec, const View& in, const View& out, const float* w, const float* bias, int k, int stride, int act,
+                       const int* m_dyn, int max_items, hipStream_t st);
+// in place: scale == null: x = min(x, cap); else x[r, p, c] *= sigmoid(scale[r, c]) (squeeze-excitation gate)
+void launch_mb_eltwise(int prec, const View& x, const View* scale, float cap, const int* m_dyn, int max_items, hipStream_t st);
 // x.mean([2,3]) : [R,H,W,C] -> [R,1,1,C]
 void launch_spatial_mean(int prec, const View& in, const View& out, const int* m_dyn, int max_items, hipStream_t st);
 // softmax + argmax over fp32 logits [R,pitch]; writes probs [R,nc], ids [R], conf [R] and, when dets != null,

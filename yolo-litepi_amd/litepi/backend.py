@@ -29,6 +29,9 @@ def _as_bgr(img: np.ndarray) -> np.ndarray:
     return a
 
 
+CLS_ARCHS = ("resnet18", "efficientnet", "mobilenetv2", "shufflenetv2")   # the --clf_arch choices of e2e.py:1021
+
+
 class Engine:
     """One GPU pipeline handle (not thread-safe; one per GPU)."""
 
@@ -36,14 +39,15 @@ class Engine:
                  det_input: int = 640, cls_input: int = 64, device: int = 0, max_rois: int = 0, conv_impl: int = 0,
                  numerics: str = "e2e", cls_arch: str = "shufflenetv2"):
         """numerics: "e2e" = HybridPipeline of e2e.py (default), "e2e_optimize" = HybridPipelineOptimized of e2e_optimize.py
-        (other ROI clip rule, cv2-linear ROI resize).  cls_arch: "shufflenetv2" | "resnet18" (e2e.py:320-333)."""
+        (other ROI clip rule, cv2-linear ROI resize).  cls_arch: "shufflenetv2" | "resnet18" | "mobilenetv2" | "efficientnet"
+        (the four choices of build_classifier, e2e.py:320-333)."""
         self.lib = _ffi.load_library()
         cfg = LpConfig()
         self.lib.lp_default_config(C.byref(cfg))
         cfg.device, cfg.precision, cfg.max_batch, cfg.max_det = device, _PREC[precision], max_batch, max_det
         cfg.num_classes, cfg.det_input, cfg.cls_input, cfg.max_rois, cfg.conv_impl = num_classes, det_input, cls_input, max_rois, conv_impl
         cfg.numerics = {"e2e": 0, "e2e_optimize": 1}[numerics]
-        cfg.cls_arch = {"shufflenetv2": 0, "resnet18": 1}[cls_arch]
+        cfg.cls_arch = {"shufflenetv2": 0, "resnet18": 1, "mobilenetv2": 2, "efficientnet": 3}[cls_arch]
         self.numerics, self.cls_arch = numerics, cls_arch
         self.cfg = cfg
         self.precision = precision
@@ -348,7 +352,8 @@ def load_classifier_state(model_path: Optional[str], num_classes: int, arch: str
             print(f"WARNING: could not load classifier weights ({e}); the classifier stays RANDOM-INIT")
     else:
         print(f"WARNING: classifier weights {model_path!r} not found; the classifier stays RANDOM-INIT")
-    return (random_resnet18_state(num_classes) if arch == "resnet18" else random_shufflenet_state(num_classes)), False
+    return {"resnet18": random_resnet18_state, "mobilenetv2": random_mobilenetv2_state, "efficientnet": random_efficientnet_state,
+            "shufflenetv2": random_shufflenet_state}[arch](num_classes), False
 
 
 def random_shufflenet_state(num_classes: int, seed: int = 0) -> Dict[str, np.ndarray]:
@@ -389,6 +394,67 @@ def random_shufflenet_state(num_classes: int, seed: int = 0) -> Dict[str, np.nda
     return sd
 
 
+def _rand_helpers(rng, sd, gain):
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = (rng.standard_normal((co, ci, k, k)) * (gain / (ci * k * k)) ** 0.5).astype(np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = rng.uniform(0.75, 1.25, c).astype(np.float32)
+        sd[name + ".bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_mean"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_var"] = rng.uniform(0.75, 1.25, c).astype(np.float32)
+    return conv, bn
+
+
+def random_mobilenetv2_state(num_classes: int, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded random mobilenet_v2 state_dict with torchvision's key names and shapes (features.i.conv.*, classifier.1.*)."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    conv, bn = _rand_helpers(rng, sd, 2.0)
+    conv("features.0.0", 32, 3, 3); bn("features.0.1", 32)
+    inp, idx = 32, 1
+    for t, c, n, s in ([1, 16, 1, 1], [6, 24, 2, 2], [6, 32, 3, 2], [6, 64, 4, 2], [6, 96, 3, 1], [6, 160, 3, 2], [6, 320, 1, 1]):
+        for _ in range(n):
+            p, hid, li = f"features.{idx}.conv.", inp * t, 0
+            if t != 1:
+                conv(p + "0.0", hid, inp, 1); bn(p + "0.1", hid)
+                li = 1
+            conv(p + f"{li}.0", hid, 1, 3); bn(p + f"{li}.1", hid)
+            conv(p + f"{li + 1}", c, hid, 1); bn(p + f"{li + 2}", c)
+            inp = c
+            idx += 1
+    conv("features.18.0", 1280, inp, 1); bn("features.18.1", 1280)
+    sd["classifier.1.weight"] = (rng.standard_normal((num_classes, 1280)) * (1.0 / 1280) ** 0.5).astype(np.float32)
+    sd["classifier.1.bias"] = (rng.standard_normal(num_classes) * 0.1).astype(np.float32)
+    return sd
+
+
+def random_efficientnet_state(num_classes: int, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded random efficientnet_b0 state_dict with torchvision's key names and shapes (features.s.r.block.*, classifier.1.*)."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    conv, bn = _rand_helpers(rng, sd, 2.0)
+    conv("features.0.0", 32, 3, 3); bn("features.0.1", 32)
+    cfg = [(1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3), (6, 5, 1, 80, 112, 3),
+           (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1)]
+    for si, (e, k, s, i, o, n) in enumerate(cfg):
+        for r in range(n):
+            inp = i if r == 0 else o
+            p, exp, li = f"features.{si + 1}.{r}.block.", inp * e, 0
+            if e != 1:
+                conv(p + "0.0", exp, inp, 1); bn(p + "0.1", exp)
+                li = 1
+            conv(p + f"{li}.0", exp, 1, k); bn(p + f"{li}.1", exp)
+            sq = max(1, inp // 4)
+            conv(p + f"{li + 1}.fc1", sq, exp, 1); sd[p + f"{li + 1}.fc1.bias"] = (rng.standard_normal(sq) * 0.1).astype(np.float32)
+            conv(p + f"{li + 1}.fc2", exp, sq, 1); sd[p + f"{li + 1}.fc2.bias"] = (rng.standard_normal(exp) * 0.1).astype(np.float32)
+            conv(p + f"{li + 2}.0", o, exp, 1); bn(p + f"{li + 2}.1", o)
+    conv("features.8.0", 1280, 320, 1); bn("features.8.1", 1280)
+    sd["classifier.1.weight"] = (rng.standard_normal((num_classes, 1280)) * (1.0 / 1280) ** 0.5).astype(np.float32)
+    sd["classifier.1.bias"] = (rng.standard_normal(num_classes) * 0.1).astype(np.float32)
+    return sd
+
+
 def random_resnet18_state(num_classes: int, seed: int = 0) -> Dict[str, np.ndarray]:
     """Seeded random resnet18 state_dict with torchvision's key names and shapes."""
     rng = np.random.default_rng(seed)
@@ -425,9 +491,8 @@ class PyTorchClassifier:
 
     def __init__(self, model_path: str, arch: str, num_classes: int = 58, input_size: int = 64, device: str = "cpu", *,
                  precision: str = "fp16", max_rois: int = 1024, conv_impl: int = 0, _engine: Optional[Engine] = None):
-        if arch not in ("shufflenetv2", "resnet18"):
-            raise ValueError(f"Unknown architecture for the HIP backend: {arch} (shufflenetv2 and resnet18 are accelerated; "
-                             "efficientnet / mobilenetv2 of e2e.py:324-329 are not)")
+        if arch not in CLS_ARCHS:
+            raise ValueError(f"Unknown architecture: {arch}")   # as build_classifier, e2e.py:334
         self.input_size = input_size
         self.num_classes = num_classes
         self.arch = arch
@@ -463,7 +528,7 @@ class HybridPipeline:
         print("=" * 70)
         self.engine = Engine(precision=precision, max_batch=max_batch, max_det=max_det, num_classes=num_classes,
                              det_input=det_input_size, cls_input=cls_input_size, device=device, max_rois=max_rois,
-                             numerics=numerics, cls_arch=classifier_arch if classifier_arch in ("shufflenetv2", "resnet18") else "shufflenetv2")
+                             numerics=numerics, cls_arch=classifier_arch if classifier_arch in CLS_ARCHS else "shufflenetv2")
         self.detector = NCNNDetector(detector_param, detector_bin, det_input_size, use_gpu_detector, detector_threads,
                                      _engine=self.engine)
         self.classifier = PyTorchClassifier(classifier_path, classifier_arch, num_classes, cls_input_size, classifier_device,
