@@ -113,10 +113,26 @@ def test_harness_main_two_passes_csv_and_keep_all(tmp_path, monkeypatch, capsys)
     assert (out / "synthetic.ncnn+shufflenetv2").is_dir()
     # equal thresholds: ONE pass per chunk (e2e.py:983-984), and the row is appended
     calls.clear()
-    assert e2e.main(argv + ["--yolo_conf", "0.25", "--num_samples", "2"]) == 0
+    assert e2e.main(argv + ["--yolo_conf", "0.25", "--num_samples", "2", "--save_viz", "1"]) == 0
     assert [c[1] for c in calls] == [0.25]
     df = pd.read_csv(summary)
     assert len(df) == 2 and df.loc[1, "num_test_images"] == 2
+    # ---- --save_viz: one overlay per processed image (e2e.py:1003-1009), readable, the image's size, and drawn on
+    #      (predictions in green: the reference's (0, 255, 0) rectangles)
+    from PIL import Image
+    viz = sorted((out / "synthetic.ncnn+shufflenetv2" / "visualizations").glob("vis_*.png"))
+    assert len(viz) == 2
+    for vp in viz:
+        im = np.asarray(Image.open(vp).convert("RGB"))
+        src = next(f for f in img_dir.iterdir() if f.stem == vp.stem[4:])
+        assert im.shape[:2] == np.asarray(Image.open(src)).shape[:2]   # the overlay is the image itself, drawn on
+        assert (im[6:34, 6:min(399, im.shape[1] - 1)] == 0).mean() > 0.5   # the summary bar
+    count = lambda rgb: sum(int(((np.asarray(Image.open(vp).convert("RGB")) == rgb).all(-1)).sum()) for vp in viz)   # noqa: E731
+    assert count((0, 0, 255)) > 100                                      # ground truths in blue (the reference's BGR (255, 0, 0))
+    if sum(calls[0][4]) > 0:
+        assert count((0, 255, 0)) > 100                                  # predictions in green
+    # ---- t_roi_extract is measured (the ROI resize launch), not a constant 0 (e2e.py:475)
+    assert any(m.t_roi_extract > 0 for c in calls for m in c[5])
 
     # ---- nothing dropped: the evaluation pass returns exactly what the oracle's postprocess + ROI filter keep on the
     #      device's own out0 (640x640 images: identity letterbox)

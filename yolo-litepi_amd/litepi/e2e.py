@@ -8,7 +8,9 @@ Ultralytics-style metric (e2e.py:656-824) and the same appended ``comparison_sum
 
 Differences, on purpose: images are decoded with Pillow (cv2 is not a dependency);
 ``--detector_threads`` and ``--device`` are accepted and ignored (everything runs on the GPU);
-``--clf_arch`` shufflenetv2 and resnet18 are accelerated (efficientnet / mobilenetv2 raise); ``--save_viz`` is accepted and ignored.
+all four ``--clf_arch`` choices run on the GPU; ``--save_viz`` overlays (e2e.py:826-884, 1003-1009) are drawn with Pillow: same
+layout and colours as the reference's cv2 drawing (ground truth blue, predictions green, label boxes, summary bar), Pillow's
+default font instead of Hershey.
 """
 from __future__ import annotations
 
@@ -44,7 +46,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--batch_size", type=int, default=8, help="kept for compatibility: all ROIs of a call are classified together")
     p.add_argument("--device", type=str, choices=["cpu", "cuda", "hip"], default="hip", help="ignored: always the HIP device")
     p.add_argument("--output", type=str, default="output_eval")
-    p.add_argument("--save_viz", default=False, help="accepted and ignored")
+    p.add_argument("--save_viz", default=False, help="write visualizations/vis_<image>.png overlays like the reference (any non-empty value)")
     # new
     p.add_argument("--batch_images", type=int, default=1, help="images per GPU call")
     p.add_argument("--precision", type=str, choices=["fp16", "fp32"], default="fp16")
@@ -102,6 +104,41 @@ def sample_images(files: Sequence, num_samples: Optional[int], seed: int = 42):
         return list(files)
     random.seed(seed)
     return sorted(random.sample(list(files), num_samples))
+
+
+def visualize_prediction(img_bgr: np.ndarray, predictions: Sequence[Dict], ground_truths, class_names: Sequence[str], output_path) -> None:
+    """Ground truths (blue) and predictions (green) drawn on the image, like the reference's visualize_prediction
+    (e2e.py:826-884): 3-px rectangles, "GT: <name>" above each ground truth, "PRED: <name>" and "Cls:x Det:y" below each
+    prediction on filled label boxes, and the "GT: n | Predictions: m" bar in the top-left corner.  Drawn with Pillow (RGB)."""
+    from PIL import Image, ImageDraw, ImageFont
+    im = Image.fromarray(np.ascontiguousarray(img_bgr[:, :, ::-1]))
+    d = ImageDraw.Draw(im)
+    font = ImageFont.load_default()
+    h, w = img_bgr.shape[:2]
+    BLUE, GREEN, DGREEN, WHITE, BLACK = (0, 0, 255), (0, 255, 0), (0, 200, 0), (255, 255, 255), (0, 0, 0)
+
+    def name_of(i):
+        return class_names[i] if 0 <= int(i) < len(class_names) else str(i)
+
+    def label(x, y_base, text, fill):
+        l, t, r, b = d.textbbox((0, 0), text, font=font)
+        tw, th = r - l, b - t
+        d.rectangle([x, y_base - th - 4, x + tw + 2, y_base + 2], fill=fill)
+        d.text((x + 1, y_base - th - 2), text, fill=WHITE, font=font)
+        return th
+
+    for gt_cls, x1, y1, x2, y2 in ground_truths:
+        d.rectangle([x1, y1, x2, y2], outline=BLUE, width=3)
+        label(x1, max(y1 - 10, 15), f"GT: {name_of(gt_cls)}", BLUE)
+    for pred in predictions:
+        x1, y1, x2, y2 = [int(v) for v in pred["bbox"]]
+        d.rectangle([x1, y1, x2, y2], outline=GREEN, width=3)
+        ty = min(y2 + 25, h - 5)
+        th = label(x1, ty, f"PRED: {name_of(pred['cls_class'])}", GREEN)
+        label(x1, ty + th + 7, f"Cls:{pred['cls_conf']:.2f} Det:{pred['det_conf']:.2f}", DGREEN)
+    d.rectangle([5, 5, 400, 35], fill=BLACK)
+    d.text((10, 14), f"GT: {len(ground_truths)} | Predictions: {len(predictions)}", fill=WHITE, font=font)
+    im.save(str(output_path))
 
 
 def read_image_bgr(path) -> Optional[np.ndarray]:
@@ -262,6 +299,10 @@ def run_evaluation(args) -> Dict:
             for f, im, (res, _) in zip(chunk, imgs, ev):
                 lp = (label_dir / f"{f.stem}.txt") if label_dir else f.parent / "labels" / f"{f.stem}.txt"
                 all_gts.append(parse_yolo_label(lp, im.shape[1], im.shape[0]))
+                if args.save_viz:   # overlays of the evaluation pass, e2e.py:1003-1009
+                    viz_dir = out_dir / "visualizations"
+                    viz_dir.mkdir(parents=True, exist_ok=True)
+                    visualize_prediction(im, res, all_gts[-1], class_names, viz_dir / f"vis_{f.stem}.png")
                 all_preds.append([{"bbox": r["bbox"], "conf": r.get("det_conf", 0.0), "cls_class": r.get("cls_class", -1)} for r in res])
                 names.append(f.name)
     finally:
