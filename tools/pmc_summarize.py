@@ -17,6 +17,10 @@ import sys
 def short(name):
     m = re.search(r"lp::?(\w+)|_ZN2lp\d+(\w+?)I", name)
     base = name
+    if name.startswith("_ZN2lp12_GLOBAL__N_1"):   # kernels of an anonymous namespace (c2f_kernels.hip): name + integer template arguments
+        m = re.match(r"_ZN2lp12_GLOBAL__N_1\d+([a-z0-9_]+?)I", name)
+        args = re.findall(r"L[ib](\d+)E", name)
+        return (m.group(1) if m else name) + "<" + ",".join(args) + ">"
     if name.startswith("_ZN2lp"):
         m = re.match(r"_ZN2lp\d+([a-z0-9_]+?)(I.*)?E", name)
         base = m.group(1) if m else name
@@ -24,6 +28,9 @@ def short(name):
         if tm:
             args = re.findall(r"Li(\d+)E", tm.group(2))
             base += "<" + ("f16" if tm.group(1) == "DF16_" else "f32") + ("," + ",".join(args) if args else "") + ">"
+    elif "c2f_kernel<" in name:   # demangled, anonymous namespace: keep the configuration's template arguments
+        m = re.search(r"C2fCfg<([^>]*)>", name)
+        base = "c2f_kernel<" + (m.group(1).replace(" ", "") if m else "") + ">"
     else:
         base = re.sub(r"\(.*", "", name).replace("void ", "").replace("lp::", "")
     return base

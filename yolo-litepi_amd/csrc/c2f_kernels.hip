@@ -41,7 +41,7 @@ constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 constexpr int min_c(int a, int b) { return a < b ? a : b; }
 constexpr int max_c(int a, int b) { return a > b ? a : b; }
 
-template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_, int TH_ = 20>
+template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_, int TH_ = 20, int NW_PERIMG = 8>
 struct C2fCfg {
   static constexpr int C = C_, NB = NB_, KA = KA_, KB = KB_, COUT = COUT_, MODE = MODE_, KS2 = KS2_;
   static constexpr bool UP = UP_;
@@ -49,7 +49,10 @@ struct C2fCfg {
   // waves per workgroup.  c = 16: four, so that two workgroups (LDS allows it) share a CU at one wave each per SIMD with
   // the whole register file -- two independent workgroups drift out of phase and cover each other's epilogues and waits;
   // eight waves under a 128-register cap spilled in every epilogue
-  static constexpr int NW = C_ >= 32 ? 8 : 4;
+  // whole-image configurations: NW_PERIMG = 8.  (Four waves with the whole register file each -- every wave streams its
+  // channel block's weights from L2 itself, so halving the waves halves that traffic -- measured slower: 112 vs 100 us for
+  // the backbone kernel; one wave per SIMD exposes every LDS and L2 latency.)
+  static constexpr int NW = MODE_ >= 1 ? NW_PERIMG : (C_ >= 32 ? 8 : 4);
   static constexpr int TH = TH_, TW = 20;
   static constexpr int F = PERIMG ? 1 : 2 * NB;  // frame margin around the tile
   static constexpr int LW = TW + 2 * F, LH = TH + 2 * F;
@@ -63,13 +66,14 @@ struct C2fCfg {
   static constexpr int npt(int e) { return cdiv_c((TH + 2 * e) * (TW + 2 * e), 16); }
   // block shapes (NT channel tiles x PT pixel tiles per wave, CB channel blocks): one round of blocks per phase, two
   // where one would not fit the register file (cap_pt)
-  static constexpr int cap_pt(int nt, int pt) { return nt * pt > 20 ? cdiv_c(pt, 2) : pt; }
+  static constexpr int MAXT = (MODE_ >= 1 && NW_PERIMG == 4) ? 52 : 20;   // accumulator tiles a wave can hold
+  static constexpr int cap_pt(int nt, int pt) { return nt * pt > MAXT ? cdiv_c(pt, 2) : pt; }
   static constexpr int CT1 = 2 * C / 16, NT1 = min_c(CT1, 4), CB1 = CT1 / NT1, PT1 = cap_pt(NT1, cdiv_c(npt(e_cv1), NW / CB1));
   static constexpr int CTM = C / 16, NTM = min_c(CTM, 2), CBM = CTM / NTM;
   static constexpr int ptm(int e) { return cdiv_c(npt(e), NW / CBM); }
   static constexpr int CT2 = COUT / 16, NT2 = CT2 >= 2 ? CT2 / 2 : 1, CB2 = CT2 / NT2, PT2 = cap_pt(NT2, cdiv_c(npt(0), NW / CB2));
   static constexpr int NTS = min_c(C / 16, 2), CBS = (C / 16) / NTS, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
-  static constexpr int WPS = 2;   // waves per SIMD the register allocation must allow
+  static constexpr int WPS = NW == 4 && MODE_ >= 1 ? 1 : 2;   // waves per SIMD the register allocation must allow
   // cv2 reads y_NB and y_{NB+1} from the LDS planes (whole K steps need c >= 32); the earlier segments from the concat buffer
   static constexpr bool CV2_LDS = C >= 32;
   static constexpr int K2G = CV2_LDS ? NB * C : (2 + NB) * C;
@@ -284,7 +288,7 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
     floatx4 bv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
-    constexpr int DB = (NT * PT <= 20 && CFG::C >= 32) ? 3 : 2;
+    constexpr int DB = ((NT * PT <= 20 && CFG::C >= 32) || (CFG::WPS == 1 && NT * PT <= 28)) ? 3 : 2;
     constexpr int DA = LDSW ? 2 : DB;
     if (stamp0 >= 0) { C2F_ISTAMP(stamp0) }
     kloop<S, DA, DB, NT, PT>(
@@ -434,7 +438,7 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
     floatx4 bv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
-    constexpr int D = NT * PT <= 20 ? 3 : 2;
+    constexpr int D = (NT * PT <= 20 || (CFG::WPS == 1 && NT * PT <= 28)) ? 3 : 2;
     kloop<S, D, D, NT, PT>(
         acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
         [&](int s, half8(&bf)[PT]) {
@@ -528,7 +532,7 @@ template <class CFG, class EPI>
 __device__ __forceinline__ void sppf_tail(const Ctx& cx, const Rg& rg, char* P0, char* P1, const char* __restrict__ w, const float* __restrict__ bias,
                                           char* gcat2, int gpitch, EPI&& epi) {
   constexpr int C = CFG::C, NT = CFG::NT2, CB = CFG::CB2, PT = cdiv_c(CFG::npt(0), CFG::NW / CB), SPT = C / 32, S = 4 * SPT;
-  static_assert(NT * PT <= 28 && SPT == 2, "SPPF tail: block shape");
+  static_assert(NT * PT <= 52 && SPT == 2, "SPPF tail: block shape");
   const int npt = (rg.R + 15) >> 4;
   const int nblk = ((npt + PT - 1) / PT) * CB;
   const bool has = cx.wave < nblk;
