@@ -19,6 +19,19 @@ import sys
 def family(name):
     f16 = "_f16" if "DF16_" in name or "<f16" in name else "_f32"
     ints = [int(v) for v in re.findall(r"Li(\d+)E", name)]
+    if "c2f_kernel" in name:   # C2fCfg<C, NB, KA, KB, UP, COUT, MODE, KS2, TH, NW>: the profiler's name is CfgName of c2f_kernels.hip
+        m = re.search(r"C2fCfg<([^>]*)>", name)
+        if m:
+            t = [x.strip() for x in m.group(1).split(",")]
+            v = [int(x) if x.lstrip("-").isdigit() else (1 if x == "true" else 0) for x in t]
+        else:
+            v = [int(x) for x in re.findall(r"L[ib](\d+)E", name)]
+        C, NB, KA, KB, UP, COUT, MODE, KS2 = (v + [0] * 8)[:8]
+        if MODE >= 1:
+            src = "s2+%d" % KB + (",sppf" if MODE == 2 else "")
+        else:
+            src = ("up%d+%d" % (KA, KB)) if UP else str(KA + KB)
+        return "c2f<%d,%d,%s>_f16" % (C, NB, src)
     if "bottleneck_mfma_kernel" in name:   # <T, NT, P1, P2, SEP, T2, SG>: the profiler's name carries <NT,P1,P2,T2,SG>
         v = (ints + [0, 0, 0, 0, 0])[:5]
         return "bottleneck3x3x2<%d,%d,%d,%d,%d>" % tuple(v) + f16

@@ -56,8 +56,13 @@ struct C2fCfg {
   static constexpr int TH = TH_, TW = 20;
   static constexpr int F = PERIMG ? 1 : 2 * NB;  // frame margin around the tile
   static constexpr int LW = TW + 2 * F, LH = TH + 2 * F;
-  static constexpr int PS = 2 * C + 16;          // bytes per LDS pixel
-  static constexpr int PLANE = LW * LH * PS;
+  static constexpr int PS = 2 * C + 16;          // bytes per LDS pixel of a c-channel plane
+  // c = 16, one bottleneck: plane 0 holds cv1's whole output y0 | y1 (2c channels per pixel), so that cv2's first K step
+  // (32 channels) is one plane-0 read and the module's concat buffer is never touched: no global round trip of y0 .. y2
+  static constexpr bool Y01 = C == 16 && NB == 1 && MODE_ == 0;
+  static constexpr int PS0 = Y01 ? 4 * C + 16 : PS;   // plane 0 pixel pitch
+  static constexpr int Y1OFF = Y01 ? 2 * C : 0;       // byte offset of y1 inside a plane-0 pixel
+  static constexpr int PLANE0 = LW * LH * PS0, PLANE = LW * LH * PS;
   static constexpr int XC = 2 * C;               // output channels of the entry conv
   // how far each phase's region extends beyond the tile
   static constexpr int e_cv1 = PERIMG ? 0 : 2 * NB;
@@ -75,14 +80,14 @@ struct C2fCfg {
   static constexpr int NTS = min_c(C / 16, 2), CBS = (C / 16) / NTS, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
   static constexpr int WPS = NW == 4 && MODE_ >= 1 ? 1 : 2;   // waves per SIMD the register allocation must allow
   // cv2 reads y_NB and y_{NB+1} from the LDS planes (whole K steps need c >= 32); the earlier segments from the concat buffer
-  static constexpr bool CV2_LDS = C >= 32;
-  static constexpr int K2G = CV2_LDS ? NB * C : (2 + NB) * C;
+  static constexpr bool CV2_LDS = C >= 32 || Y01;
+  static constexpr int K2G = Y01 ? 0 : (CV2_LDS ? NB * C : (2 + NB) * C);
   // weights staged in LDS (tile configurations): fragment bytes of every phase, in execution order
   static constexpr bool AW = !PERIMG;
   static constexpr int c3_steps = C >= 32 ? 9 * (C / 32) : 5;
   static constexpr int WB_CV1 = CT1 * ((KA + KB) / 32) * 1024, WB_M = CTM * c3_steps * 1024, WB_CV2 = CT2 * cdiv_c((2 + NB) * C, 32) * 1024;
   static constexpr int WSLOT = AW ? max_c(WB_CV1, max_c(WB_M, WB_CV2)) : 0;
-  static constexpr int LDS_BYTES = 2 * PLANE + 2 * WSLOT;
+  static constexpr int LDS_BYTES = PLANE0 + PLANE + 2 * WSLOT;
   static C2fShape shape() {
     C2fShape s;
     s.C = C; s.NB = NB; s.KA = KA; s.KB = KB; s.UP = UP ? 1 : 0; s.COUT = COUT; s.MODE = MODE; s.KS2 = KS2;
@@ -245,13 +250,13 @@ __device__ __forceinline__ void stage_weights(const Ctx& cx, const void* src, ch
 //      from LDS plane 1 (tile pixels: cv2 over concat(y0 .., y_NB, y_{NB+1})).  UP: srcA is a half-resolution tensor read
 //      at (y/2, x/2) (Interp nearest x2 fused, as conv1x1_mfma_kernel's UPS).
 //      epi(cb, ok, py, px, v): this lane's 4*NT activated channels (block cb) of region pixel (py, px); ok = a real pixel.
-template <class CFG, int NT, int CB, int PT, int KA, int KB, int KL0, int KL1, bool UP, bool LDSW, class EPI>
+template <class CFG, int NT, int CB, int PT, int KA, int KB, int KL0, int KL1, bool UP, bool LDSW, class EPI, int PSL0 = CFG::PS, int PSL1 = CFG::PS>
 __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char* __restrict__ srcA, int pitchA, const char* __restrict__ srcB,
                                          int pitchB, const char* pl0, const char* pl1, const ASrc<LDSW>& wsrc, const float* __restrict__ bias,
                                          EPI&& epi, int stamp0 = -1) {
-  static_assert(KA % 32 == 0 && KB % 8 == 0 && KL0 % 32 == 0 && KL1 % 32 == 0 && (KB % 32 == 0 || KL0 + KL1 == 0),
-                "K segments: whole steps, except a global srcB tail of whole 8-channel groups at the very end");
-  constexpr int SA = KA / 32, SB = cdiv_c(KB, 32), SL0 = KL0 / 32, SL1 = KL1 / 32, SG = SA + SB, S = SG + SL0 + SL1;
+  static_assert(KA % 32 == 0 && KB % 8 == 0 && KL0 % 32 == 0 && KL1 % 16 == 0 && (KB % 32 == 0 || KL0 + KL1 == 0),
+                "K segments: whole steps, except a tail of whole 8-channel groups at the very end (global srcB, or 16 channels of plane 1)");
+  constexpr int SA = KA / 32, SB = cdiv_c(KB, 32), SL0 = KL0 / 32, SL1 = cdiv_c(KL1, 32), SG = SA + SB, S = SG + SL0 + SL1;
   // a last K step that is not full (KB % 32 != 0): lanes whose channel group lies past the pixel's channels re-read group 0
   // of the same pixel (their weights are zero) -- the address stays inside the pixel
   const int tail_off = (4 * (SB - 1) + cx.gam < KB / 8) ? (SB - 1) * 64 : -cx.gam * 16;
@@ -260,7 +265,7 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
   for (int blk = cx.wave; blk < nblk; blk += CFG::NW) {
     const int cb = blk % CB, pbk = blk / CB;
     unsigned offA[SA > 0 ? PT : 1], offB[SB > 0 ? PT : 1];
-    int pb[SL0 + SL1 > 0 ? PT : 1];
+    int pb[SL0 + SL1 > 0 ? PT : 1];   // pixel slot index (x 16-byte units are added per plane)
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       int p = (pbk * PT + i) * 16 + cx.sig;
@@ -274,7 +279,7 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
         offA[i] = (unsigned)(((cx.n * HA + ya) * WA + xa) * pitchA) * 2u + (unsigned)cx.gam * 16u;
       }
       if constexpr (SB > 0) offB[i] = (unsigned)(((cx.n * cx.H + gy) * cx.W + gx) * pitchB) * 2u + (unsigned)cx.gam * 16u;
-      if constexpr (SL0 + SL1 > 0) pb[i] = ((rg.fy0 + py) * CFG::LW + rg.fx0 + px) * CFG::PS + cx.gam * 16;
+      if constexpr (SL0 + SL1 > 0) pb[i] = (rg.fy0 + py) * CFG::LW + rg.fx0 + px;
     }
     floatx4 acc[NT][PT];
 #pragma unroll
@@ -299,8 +304,9 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
             if (s < SA) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcA + (size_t)offA[SA > 0 ? i : 0] + s * 64));
             else if (s < SG && KB % 32 != 0 && s == SG - 1) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcB + (size_t)(offB[SB > 0 ? i : 0] + (unsigned)tail_off)));
             else if (s < SG) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcB + (size_t)offB[SB > 0 ? i : 0] + (s - SA) * 64));
-            else if (s < SG + SL0) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl0 + pb[SL0 + SL1 > 0 ? i : 0] + (s - SG) * 64));
-            else bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl1 + pb[SL0 + SL1 > 0 ? i : 0] + (s - SG - SL0) * 64));
+            else if (s < SG + SL0) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl0 + pb[SL0 + SL1 > 0 ? i : 0] * PSL0 + cx.gam * 16 + (s - SG) * 64));
+            // (a 16-channel plane 1: the lanes of K groups 2, 3 re-read groups 0, 1 -- their weights are zero)
+            else bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl1 + pb[SL0 + SL1 > 0 ? i : 0] * PSL1 + (KL1 % 32 ? (cx.gam & 1) : cx.gam) * 16 + (s - SG - SL0) * 64));
           }
         },
         NoFix{});
@@ -325,10 +331,11 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
 //      (an even number of pixels apart: the conflict-free pairing of the header) x two channel groups.
 //      One block per wave (the block shapes guarantee it).  SYNC: a workgroup barrier between the K loop and the epilogue
 //      (the epilogue overwrites the plane the K loop reads).
-template <class CFG, int PT, bool SYNC, bool LDSW, class EPI>
+template <class CFG, int PT, bool SYNC, bool LDSW, int PS, int CHOFF, class EPI>
 __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char* pin, const ASrc<LDSW>& wsrc, const float* __restrict__ bias,
                                          EPI&& epi) {
-  constexpr int C = CFG::C, NT = CFG::NTM, CB = CFG::CBM, LW = CFG::LW, PS = CFG::PS;
+  // PS: pixel pitch of the input plane; CHOFF: byte offset of the conv's input channels inside a pixel
+  constexpr int C = CFG::C, NT = CFG::NTM, CB = CFG::CBM, LW = CFG::LW;
   constexpr int SPT = C >= 32 ? C / 32 : 1;
   constexpr int S = CFG::c3_steps;
   // c = 16: taps of step s for the lanes with (g & 1) == 0 / 1
@@ -357,7 +364,7 @@ __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char
       int py, px;
       pix_of(rg, p, py, px);
       const int slot = (rg.fy0 + py) * LW + rg.fx0 + px;
-      pb[i] = (slot - LW - 1) * PS + (C >= 32 ? cx.gam * 16 : (cx.g >> 1) * 16);
+      pb[i] = (slot - LW - 1) * PS + CHOFF + (C >= 32 ? cx.gam * 16 : (cx.g >> 1) * 16);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -608,9 +615,10 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int C = CFG::C, NB = CFG::NB, F = CFG::F, LW = CFG::LW, PS = CFG::PS, TH = CFG::TH, TW = CFG::TW;
   constexpr bool AW = CFG::AW;
+  constexpr int PS0 = CFG::PS0, Y1OFF = CFG::Y1OFF;
   char* P0 = smem;
-  char* P1 = smem + CFG::PLANE;
-  char* WS = smem + 2 * CFG::PLANE;   // two weight slots (AW)
+  char* P1 = smem + CFG::PLANE0;
+  char* WS = smem + CFG::PLANE0 + CFG::PLANE;   // two weight slots (AW)
   Ctx cx;
   cx.lane = threadIdx.x & 63;
   cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   {
     const bool interior = !CFG::PERIMG && cx.oy0 >= F && cx.ox0 >= F && cx.oy0 + TH + F <= a.H && cx.ox0 + TW + F <= a.W;
     if (!interior) {
-      for (int i = threadIdx.x; i < 2 * CFG::PLANE / 16; i += CFG::NW * 64) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+      for (int i = threadIdx.x; i < (CFG::PLANE0 + CFG::PLANE) / 16; i += CFG::NW * 64) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
     }
   }
   const char* src1 = reinterpret_cast<const char*>(a.src1);
@@ -688,7 +696,8 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
           to_half<NT>(v, h);
           const int fy = rg.fy0 + py, fx = rg.fx0 + px;
           if (ok) {
-            if (chb >= C) store_h<NT>(P0 + (fy * LW + fx) * PS + (chb - C) * 2, h);
+            if (CFG::Y01) store_h<NT>(P0 + (fy * LW + fx) * PS0 + chb * 2, h);   // y0 | y1 side by side
+            else if (chb >= C) store_h<NT>(P0 + (fy * LW + fx) * PS0 + (chb - C) * 2, h);
             if ((chb < CFG::K2G || dbg) && fy >= F && fy < F + TH && fx >= F && fx < F + TW) {
               const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
               store_h<NT>(cat + (size_t)((unsigned)gpix * (unsigned)a.cat_pitch) * 2 + chb * 2, h);
@@ -715,8 +724,8 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
       };
       const ASrc<AW> wa = wsrc(2 * k + 1, C2F_W_A0 + 2 * k);
       const float* ba = a.b[C2F_W_A0 + 2 * k];
-      if (k == 0) c3_phase<CFG, CFG::ptm(CFG::e_a(0)), false, AW>(cx, rg, P0, wa, ba, epi_a);
-      else c3_phase<CFG, CFG::ptm(CFG::e_a(NB - 1)), false, AW>(cx, rg, P0, wa, ba, epi_a);
+      if (k == 0) c3_phase<CFG, CFG::ptm(CFG::e_a(0)), false, AW, PS0, Y1OFF>(cx, rg, P0, wa, ba, epi_a);
+      else c3_phase<CFG, CFG::ptm(CFG::e_a(NB - 1)), false, AW, PS0, Y1OFF>(cx, rg, P0, wa, ba, epi_a);
     }
     wg_sync();
     stage(2 * k + 3);
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
         constexpr int NT = CFG::NTM;
         const int chb = cb * 16 * NT + 4 * NT * cx.g;
         const int fy = rg.fy0 + py, fx = rg.fx0 + px;
-        char* yp = P0 + (fy * LW + fx) * PS + chb * 2;
+        char* yp = P0 + (fy * LW + fx) * PS0 + Y1OFF + chb * 2;
         half_t r[4 * NT], h[4 * NT];
         load_h<NT>(yp, r);
         // silu rounded to fp16, shortcut added in fp32, rounded again: what a stored conv output + an add kernel give
@@ -746,8 +755,8 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
       };
       const ASrc<AW> wbk = wsrc(2 * k + 2, C2F_W_B0 + 2 * k);
       const float* bbk = a.b[C2F_W_B0 + 2 * k];
-      if (k == 0 && NB > 1) c3_phase<CFG, CFG::ptm(CFG::e_b(0)), false, AW>(cx, rg, P1, wbk, bbk, epi_b);
-      else c3_phase<CFG, CFG::ptm(CFG::e_b(NB - 1)), CFG::CV2_LDS, AW>(cx, rg, P1, wbk, bbk, epi_b);
+      if (k == 0 && NB > 1) c3_phase<CFG, CFG::ptm(CFG::e_b(0)), false, AW, PS, 0>(cx, rg, P1, wbk, bbk, epi_b);
+      else c3_phase<CFG, CFG::ptm(CFG::e_b(NB - 1)), CFG::CV2_LDS, AW, PS, 0>(cx, rg, P1, wbk, bbk, epi_b);
     }
     wg_sync();
   }
@@ -758,16 +767,17 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   {
     const Rg rg = make_region<CFG>(cx, 0);
     char* out = reinterpret_cast<char*>(a.out);
-    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, CFG::K2G, (CFG::CV2_LDS ? C : 0), (CFG::CV2_LDS ? C : 0), false, AW>(
-        cx, rg, nullptr, 0, cat, a.cat_pitch, P0, P1, wsrc(2 * NB + 1, C2F_W_CV2), a.b[C2F_W_CV2],
-        [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT2]) {
+    auto epi_cv2 = [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT2]) {
           constexpr int NT = CFG::NT2;
           const int chb = cb * 16 * NT + 4 * NT * cx.g;
           half_t h[4 * NT];
           to_half<NT>(v, h);
           const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
           if (ok) store_h<NT>(out + (size_t)((unsigned)gpix * (unsigned)a.out_pitch) * 2 + chb * 2, h);
-        }, 11);
+        };
+    // K segments: [concat buffer, K2G channels] [plane 0] [plane 1]; Y01: plane 0 = y0 | y1 (2c), plane 1 = y2 (c)
+    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, CFG::K2G, (CFG::CV2_LDS ? (CFG::Y01 ? 2 * C : C) : 0), (CFG::CV2_LDS ? C : 0), false, AW,
+             decltype(epi_cv2)&, PS0, PS>(cx, rg, nullptr, 0, cat, a.cat_pitch, P0, P1, wsrc(2 * NB + 1, C2F_W_CV2), a.b[C2F_W_CV2], epi_cv2, 11);
   }
   C2F_STAMP(5)
 
@@ -810,7 +820,7 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
 
 // ---- instantiated configurations (YOLO-LitePi v1 widths; model.ncnn.param line of the module's cv1) ----------------------
 typedef C2fCfg<32, 1, 128, 64, true, 64, 0, 0> CfgNeck40;    // :90  up(P5) | P4 -> C2f(n=1) @40x40
-typedef C2fCfg<16, 1, 64, 32, true, 32, 0, 0> CfgNeck80;     // :105 up(F4) | P3 -> C2f(n=1) @80x80
+typedef C2fCfg<16, 1, 64, 32, true, 32, 0, 0, 16> CfgNeck80;     // :105 up(F4) | P3 -> C2f(n=1) @80x80
 typedef C2fCfg<32, 1, 0, 128, false, 64, 0, 0> CfgPan40;     // :121 conv_37 | F4 -> C2f(n=1) @40x40
 typedef C2fCfg<64, 1, 0, 256, false, 128, 1, 64> CfgPan20;   // :134-147 conv_42 (s2) | P5 -> C2f(n=1) @20x20
 typedef C2fCfg<64, 1, 0, 128, false, 128, 2, 64> CfgBb20;    // :62-85 conv_22 (s2) -> C2f(n=1) -> SPPF @20x20

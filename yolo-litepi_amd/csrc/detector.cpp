@@ -592,7 +592,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     io.out = tout;
     ensure_buffer(tout);
     // (the y segments cv2 takes from LDS are only stored in the bisect mode, LITEPI_C2F_STORE_ALL=1)
-    for (size_t q = 2; q < m.ys.size(); ++q) tensors_[m.ys[q]].materialised = getenv("LITEPI_C2F_STORE_ALL") != nullptr || sh.C < 32;
+    for (size_t q = 2; q < m.ys.size(); ++q) tensors_[m.ys[q]].materialised = getenv("LITEPI_C2F_STORE_ALL") != nullptr || (sh.C < 32 && sh.NB > 1);
     if (mode >= 1) {
       io.s2_in = cinfo[i0].tin;
       io.x = cinfo[i0].tout;
