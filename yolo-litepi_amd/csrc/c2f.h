@@ -81,4 +81,14 @@ struct C2fLayer {
   std::string kernel_name() const;
 };
 
+// Stand-alone 3x3 stride-2 conv + SiLU on the c2f machinery (s2conv_kernel): weights [cout][tap][cin] over physical channels
+struct S2ConvLayer {
+  int Cin = 0, Cout = 0, H = 0, W = 0;   // H, W: OUTPUT map
+  std::string name;
+  DevBuf d_w, d_b;
+  static bool supported(int cin, int cout, int hout, int wout);
+  void build(int cin, int cout, int hout, int wout, const std::vector<float>& w_taps, const std::vector<float>& bias);
+  void launch(const View& in, const View& out, int N, hipStream_t st) const;
+};
+
 }  // namespace lp

@@ -412,15 +412,14 @@ __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char
 
 // ---- 3x3 stride-2 pad-1 conv + SiLU, pixel operand gathered from global memory (whole-image configurations: the region is
 //      the image).  Taps above / left of the image read the centre tap's address instead and are zeroed before use.
-template <class CFG, int NT, int CB, int PT, class EPI>
-__device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const char* __restrict__ src, int pitch, const u32x4* __restrict__ w,
+template <class CFG, int NT, int CB, int PT, bool LDSW, class EPI>
+__device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const char* __restrict__ src, int pitch, const ASrc<LDSW>& wsrc,
                                            const float* __restrict__ bias, EPI&& epi) {
   constexpr int SPT = CFG::KS2 / 32, S = 9 * SPT;
   const int H2 = 2 * cx.H, W2 = 2 * cx.W;
   const int pixb = pitch * 2, rowb = W2 * pixb;
   const int npt = (rg.R + 15) >> 4;
   const int nblk = ((npt + PT - 1) / PT) * CB;
-  const ASrc<false> wsrc{reinterpret_cast<const char*>(w)};
   for (int blk = cx.wave; blk < nblk; blk += CFG::NW) {
     const int cb = blk % CB, pbk = blk / CB;
     unsigned base[PT];
@@ -446,7 +445,7 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
 #pragma unroll
     for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
     constexpr int D = (NT * PT <= 20 || (CFG::WPS == 1 && NT * PT <= 28)) ? 3 : 2;
-    kloop<S, D, D, NT, PT>(
+    kloop<S, (LDSW ? 2 : D), D, NT, PT>(
         acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
         [&](int s, half8(&bf)[PT]) {
           const int tap = s / SPT, cblk = s % SPT;
@@ -670,8 +669,8 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   if constexpr (CFG::MODE >= 1) {
     const Rg rg = make_region<CFG>(cx, 0);
     char* xo = reinterpret_cast<char*>(a.x);
-    c3s2_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1>(cx, rg, reinterpret_cast<const char*>(a.s2_in), a.s2_pitch,
-                                                 reinterpret_cast<const u32x4*>(a.w[C2F_W_S2]), a.b[C2F_W_S2],
+    c3s2_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1, false>(cx, rg, reinterpret_cast<const char*>(a.s2_in), a.s2_pitch,
+                                                 ASrc<false>{reinterpret_cast<const char*>(a.w[C2F_W_S2])}, a.b[C2F_W_S2],
                                                  [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT1]) {
                                                    constexpr int NT = CFG::NT1;
                                                    const int chb = cb * 16 * NT + 4 * NT * cx.g;
@@ -817,6 +816,49 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   C2F_STAMP(7)
   C2F_STAMP(15)
 }
+
+// ---- stand-alone 3x3 stride-2 conv + SiLU (the downsampling convs between the modules, model.ncnn.param:41,118): one
+//      workgroup per 20 x 20 output tile, the weights staged once in LDS, the pixel operand gathered from global memory
+//      (every input pixel is touched by 2.25 taps on average; the tile's neighbours share them through L1 / L2).
+template <int CIN_, int COUT_>
+struct S2Cfg {
+  static constexpr int KS2 = CIN_, COUT = COUT_, NW = 8, TH = 20, TW = 20, F = 0, WPS = 2, C = 32;
+  static constexpr int CT = COUT / 16, NT = min_c(CT, 4), CB = CT / NT, PT = cdiv_c(cdiv_c(TH * TW, 16), NW / CB);
+  static constexpr int WBYTES = CT * 9 * (KS2 / 32) * 1024;
+};
+template <class CFG>
+__global__ __launch_bounds__(CFG::NW * 64, 2) void s2conv_kernel(const C2fArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Ctx cx;
+  cx.lane = threadIdx.x & 63;
+  cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  cx.g = cx.lane >> 4;
+  {
+    const int col = cx.lane & 15;
+    cx.sig = col < 4 ? 2 * col : (col < 12 ? 2 * (col - 4) + 1 : 2 * (col - 8));
+    cx.gam = ((cx.g & 1) << 1) | (cx.g >> 1);
+  }
+  cx.n = blockIdx.x % a.N;
+  const int tile = blockIdx.x / a.N;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  cx.oy0 = ty * CFG::TH; cx.ox0 = tx * CFG::TW;
+  cx.H = a.H; cx.W = a.W;
+  cx.st = nullptr;
+  stage_weights(cx, a.w[C2F_W_S2], smem, CFG::WBYTES, CFG::NW);
+  const Rg rg = make_region<CFG>(cx, 0);
+  wg_sync();
+  char* xo = reinterpret_cast<char*>(a.x);
+  c3s2_phase<CFG, CFG::NT, CFG::CB, CFG::PT, true>(cx, rg, reinterpret_cast<const char*>(a.s2_in), a.s2_pitch, ASrc<true>{smem}, a.b[C2F_W_S2],
+                                                  [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT]) {
+                                                    constexpr int NT = CFG::NT;
+                                                    const int chb = cb * 16 * NT + 4 * NT * cx.g;
+                                                    half_t h[4 * NT];
+                                                    to_half<NT>(v, h);
+                                                    const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+                                                    if (ok) store_h<NT>(xo + (size_t)((unsigned)gpix * (unsigned)a.x_pitch) * 2 + chb * 2, h);
+                                                  });
+}
+typedef S2Cfg<32, 64> S2Cfg32x64;   // model.ncnn.param:41 (conv_15: 32 -> 64 @40x40) and :118 (conv_37)
 
 // ---- instantiated configurations (YOLO-LitePi v1 widths; model.ncnn.param line of the module's cv1) ----------------------
 typedef C2fCfg<32, 1, 128, 64, true, 64, 0, 0> CfgNeck40;    // :90  up(P5) | P4 -> C2f(n=1) @40x40
@@ -965,6 +1007,34 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
     put_bias(d_b[C2F_W_SP2], src.sp2_b, s.COUT);
     macs_per_image += ((double)C * s.COUT + (double)s.COUT * 4 * C) * h * w;
   }
+}
+
+bool S2ConvLayer::supported(int cin, int cout, int hout, int wout) { return cin == 32 && cout == 64 && hout % 20 == 0 && wout % 20 == 0; }
+
+void S2ConvLayer::build(int cin, int cout, int hout, int wout, const std::vector<float>& w_taps, const std::vector<float>& bias) {
+  LP_CHECK(supported(cin, cout, hout, wout), LP_ERR_STATE, "s2conv: unsupported shape %d -> %d @%dx%d", cin, cout, hout, wout);
+  Cin = cin; Cout = cout; H = hout; W = wout;
+  const int spt = cin / 32, nt = S2Cfg32x64::NT;
+  pack_phase(d_w, w_taps, cout, 9 * cin, nt, 9 * spt, [&](int s_, int g, int j) { return (s_ / spt) * cin + 32 * (s_ % spt) + 8 * gam_of(g) + j; });
+  put_bias(d_b, &bias, cout);
+}
+
+void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st) const {
+  LP_CHECK(in.base && out.base && in.H == 2 * H && in.W == 2 * W && in.C >= Cin && out.H == H && out.W == W && out.C >= Cout, LP_ERR_STATE,
+           "s2conv %s: bad views", name.c_str());
+  LP_CHECK((double)N * in.H * in.W * in.pitch * 2.0 < 4294967296.0 && (double)N * H * W * out.pitch * 2.0 < 4294967296.0, LP_ERR_ARG,
+           "s2conv: tensor too large for 32-bit byte offsets");
+  C2fArgs a;
+  memset(&a, 0, sizeof(a));
+  a.s2_in = in.base; a.s2_pitch = in.pitch;
+  a.x = out.base; a.x_pitch = out.pitch;
+  a.w[C2F_W_S2] = d_w.p; a.b[C2F_W_S2] = d_b.as<float>();
+  a.N = N; a.H = H; a.W = W;
+  a.tiles_x = W / 20; a.tiles_y = H / 20;
+  typedef S2Cfg32x64 CFG;
+  set_max_dynamic_lds(reinterpret_cast<const void*>(&s2conv_kernel<CFG>), CFG::WBYTES);
+  hipLaunchKernelGGL(s2conv_kernel<CFG>, dim3(N * a.tiles_x * a.tiles_y), dim3(CFG::NW * 64), CFG::WBYTES, st, a);
+  LP_HIP(hipGetLastError());
 }
 
 std::string C2fLayer::kernel_name() const {

@@ -97,7 +97,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   const size_t es = prec_ == LP_FP16 ? 2 : 4;
 
   tensors_.clear(); blob2tensor_.clear(); buffers_.clear(); convs_.clear(); ops_.clear(); levels_.clear();
-  bnecks_.clear(); dws_.clear(); attns_.clear(); heads_.clear(); c2fs_.clear(); c2f_io_.clear();
+  bnecks_.clear(); dws_.clear(); attns_.clear(); heads_.clear(); c2fs_.clear(); c2f_io_.clear(); s2cs_.clear();
   fused_head_ = false;
   loaded_ = false;
 
@@ -887,6 +887,24 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         }
       }
       ensure_buffer(tout);
+      // a stride-2 conv without a folded tail whose shape the c2f machinery covers: s2conv_kernel (LITEPI_NO_S2C=1: off)
+      if (c2f_on && !getenv("LITEPI_NO_S2C") && tail < 0 && res < 0 && k == 3 && s == 2 && fused_act[i] == ACT_SILU && !l.bias.empty() && tin != input_tensor &&
+          tensors_[tin].Cp == Cin && tensors_[tout].Cp == Cout && tensors_[tout].segs.size() == 1 &&
+          S2ConvLayer::supported(Cin, Cout, tensors_[tout].H, tensors_[tout].W)) {
+        s2cs_.emplace_back(new S2ConvLayer());
+        s2cs_.back()->name = l.name;
+        s2cs_.back()->build(Cin, Cout, tensors_[tout].H, tensors_[tout].W, conv_w(i), l.bias);
+        const Tensor& TI2 = tensors_[tin];
+        const Tensor& TO2 = tensors_[tout];
+        const double macs2 = 9.0 * Cin * Cout * TO2.H * TO2.W;
+        macs_ += macs2;
+        DetOp op;
+        op.kind = DetOp::S2C; op.conv = (int)s2cs_.size() - 1; op.layer = l.name; op.in = tin; op.out = tout;
+        op.flops = 2.0 * macs2;
+        op.bytes = ((double)TI2.C * TI2.H * TI2.W + (double)TO2.C * TO2.H * TO2.W) * esd + (double)l.weight.size() * esd;
+        ops_.push_back(op);
+        continue;
+      }
       const Tensor& TI = tensors_[tin];
       const Tensor& TO = tensors_[tail >= 0 ? tmid : tout];
       double macs = (double)k * k * Cin * Cout * TO.H * TO.W;
@@ -1267,6 +1285,10 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         kname = cl.kernel_name() + sfx;
         break;
       }
+      case DetOp::S2C:
+        s2cs_[op.conv]->launch(view(op.in), view(op.out), B, st);
+        kname = fmt("s2conv<%d,%d>", s2cs_[op.conv]->Cin, s2cs_[op.conv]->Cout) + sfx;
+        break;
       case DetOp::HEAD:
         heads_[op.conv]->launch(view(op.in), B, levels_[op.in2].off, A_, d_anchors_.as<float>(), d_strides_.as<float>(), d_dfl_.as<float>(), out0,
                                 geom, cand, cand_count, conf, st);

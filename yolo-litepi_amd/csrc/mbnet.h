@@ -34,7 +34,7 @@ class MBNetClassifier : public ClassifierBase {
     int pw_expand = -1, dw = -1, se_fc1 = -1, se_fc2 = -1, pw_project = -1;
   };
   Arch arch_;
-  int prec_, impl_, maxR_, ncls_, S_, lpitch_ = 0, act_pw_ = ACT_RELU, act_dw_ = 3, stem_c_ = 32, last_c_ = 1280;
+  int prec_, impl_, maxR_, ncls_, S_, lpitch_ = 0, act_pw_ = ACT_RELU, act_dw_ = 3, stem_c_ = 32;
   bool loaded_ = false;
   std::vector<std::unique_ptr<ConvLayer>> convs_;
   std::vector<Dw> dws_;
