@@ -45,7 +45,7 @@ def main():
             os.environ["LITEPI_NO_C2F"] = "1"
         else:
             os.environ.pop("LITEPI_NO_C2F", None)
-        e = Engine(precision="fp16", max_batch=B)
+        e = Engine(precision="fp16", max_batch=max(B, 4))
         blobs = {}
         try:
             e.load_detector(param, binf)

@@ -396,7 +396,10 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     int t_cat = -1;
     std::vector<int> ys;
   };
-  const bool c2f_on = !getenv("LITEPI_NO_C2F") && prec_ == LP_FP16 && impl_ == IMPL_MFMA;
+  // (handles built for fewer than 4 images keep the layer plan: a whole-C2f launch is one long workgroup chain per tile, and
+  //  with a handful of tiles that chain is the latency -- batch-1 detect 0.475 ms against 0.43 ms; LITEPI_C2F_MIN_BATCH overrides)
+  static const int c2f_min_batch = getenv("LITEPI_C2F_MIN_BATCH") ? atoi(getenv("LITEPI_C2F_MIN_BATCH")) : 4;
+  const bool c2f_on = !getenv("LITEPI_NO_C2F") && prec_ == LP_FP16 && impl_ == IMPL_MFMA && maxB_ >= c2f_min_batch;
   auto is_silu_conv = [&](int j, int k, int s) {
     return j >= 0 && L[j].type == "Convolution" && !is_tail(j) && !done[j] && L[j].ipar(1, 1) == k && L[j].ipar(3, 1) == s &&
            fused_act[j] == ACT_SILU && !L[j].bias.empty() && cinfo[j].tin >= 0 && cinfo[j].tin != input_tensor;
