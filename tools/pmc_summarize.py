@@ -28,6 +28,9 @@ def short(name):
         if tm:
             args = re.findall(r"Li(\d+)E", tm.group(2))
             base += "<" + ("f16" if tm.group(1) == "DF16_" else "f32") + ("," + ",".join(args) if args else "") + ">"
+    elif "s2conv_kernel<" in name:
+        m = re.search(r"S2Cfg<([^>]*)>", name)
+        base = "s2conv_kernel<" + (m.group(1).replace(" ", "") if m else "") + ">"
     elif "c2f_kernel<" in name:   # demangled, anonymous namespace: keep the configuration's template arguments
         m = re.search(r"C2fCfg<([^>]*)>", name)
         base = "c2f_kernel<" + (m.group(1).replace(" ", "") if m else "") + ">"
