@@ -24,7 +24,14 @@ for k, runs in out.items():
     order = np.argsort(a[:, 0])
     dur = (a[:, 15] - a[:, 0]) / 100.0
     first, rest = dur[order[:256]], dur[order[256:]]
-    a2 = a[a[:, 8] > 0]
+    if (a[:, 9] > 0).all() and (a[:, 11] == 0).all():   # s2 phase stamps (s2conv kernel, whole-image kernels)
+        whole = a[:, 3].max() > 0
+        end = a[:, 2] if whole else a[:, 7]
+        start = a[:, 1] if whole else a[:, 2]
+        print("      s2 phase, wave 0 block 0: before K loop %d  K loop %d  epilogue %d  rest of the phase %d%s" % (
+            np.median(a[:, 8] - start), np.median(a[:, 9] - a[:, 8]), np.median(a[:, 10] - a[:, 9]), np.median(end - a[:, 10]),
+            "" if whole else "  (weights staged in %d)" % np.median(a[:, 2] - a[:, 1])))
+    a2 = a[(a[:, 8] > 0) & (a[:, 11] > 0)]
     if len(a2):
         inner = [np.median(a2[:, 8] - a2[:, 2]), np.median(a2[:, 9] - a2[:, 8]), np.median(a2[:, 10] - a2[:, 9]), np.median(a2[:, 3] - a2[:, 10]),
                  np.median(a2[:, 11] - a2[:, 4]), np.median(a2[:, 12] - a2[:, 11]), np.median(a2[:, 13] - a2[:, 12]), np.median(a2[:, 5] - a2[:, 13])]

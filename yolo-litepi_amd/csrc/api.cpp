@@ -374,6 +374,13 @@ void enqueue_detect(lp_handle* h, const uint8_t* src, const std::vector<ImgGeom>
   h->det->forward(img, B, h->d_geom.as<ImgGeom>(), conf, out0, h->d_cand.as<Cand>(), h->d_cand_count.as<int>(), h->stream, prof);
 }
 
+// Diagnostic only (tools/marginal_cost.sh): LITEPI_SKIP_STAGE=nms|roi|cls leaves that stage out of every pass after the handle's
+// first (its outputs stay in the handle's buffers): the marginal cost of the stage in a pipelined step.  Results are stale.
+static bool skip_stage(const lp_handle* h, const char* name, const Profiler* prof) {
+  static const char* s = getenv("LITEPI_SKIP_STAGE");
+  return s && !prof && h->graph_clock > 1 && strcmp(s, name) == 0;
+}
+
 // NMS + ROI rectangles; with_rois: also the batch-wide ROI list the classifier stage consumes
 void enqueue_nms(lp_handle* h, int B, float iou, int min_area, lp_det* dets, int* counts, bool with_rois, Profiler* prof) {
   NmsArgs a;
@@ -384,6 +391,7 @@ void enqueue_nms(lp_handle* h, int B, float iou, int min_area, lp_det* dets, int
   if (with_rois) a.tab = h->roi_table();
   a.max_rois = h->max_rois;
   a.roi_rule = h->cfg.numerics;
+  if (skip_stage(h, "nms", prof)) return;
   if (prof) prof->begin(h->stream);
   launch_nms(a, B, h->stream);
   if (prof) prof->end(h->stream, "nms", "nms", 0.0, 0.0);
@@ -394,7 +402,7 @@ void enqueue_nms(lp_handle* h, int B, float iou, int min_area, lp_det* dets, int
 // 2 = only the classifier (lp_run_batch times the two separately: PipelineMetrics.t_roi_extract / t_classification)
 void enqueue_classify(lp_handle* h, const uint8_t* src, int B, lp_det* dets, float* probs, int* ids, float* conf, Profiler* prof, int stage = 0) {
   RoiTable tab = h->roi_table();
-  if (stage != 2) {
+  if (stage != 2 && !skip_stage(h, "roi", prof)) {
     RoiResizeArgs r;
     r.src = src; r.geom = h->d_geom.as<ImgGeom>(); r.rects = h->d_rects.as<int>(); r.tab = tab;
     r.out = h->d_roi_rgb.as<uint8_t>(); r.max_det = h->cfg.max_det; r.S = h->cfg.cls_input; r.linear = h->cfg.numerics;
@@ -402,7 +410,7 @@ void enqueue_classify(lp_handle* h, const uint8_t* src, int B, lp_det* dets, flo
     launch_roi_resize(r, std::min(h->max_rois, B * h->cfg.max_det), h->stream);
     if (prof) prof->end(h->stream, "roi_resize_pil", "roi_resize", 0.0, (double)r.S * r.S * 3 * 2, true);
   }
-  if (stage == 1) return;
+  if (stage == 1 || skip_stage(h, "cls", prof)) return;
   ClsPost post;
   post.probs = probs; post.ids = ids; post.dets = dets; post.max_det = h->cfg.max_det; post.roi_img = tab.img; post.roi_slot = tab.slot;
   h->cls->forward(h->d_roi_rgb.as<uint8_t>(), tab.total, h->stream, prof, &post);

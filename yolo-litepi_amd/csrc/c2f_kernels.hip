@@ -73,7 +73,11 @@ struct C2fCfg {
   // where one would not fit the register file (cap_pt)
   static constexpr int MAXT = (MODE_ >= 1 && NW_PERIMG == 4) ? 52 : 20;   // accumulator tiles a wave can hold
   static constexpr int cap_pt(int nt, int pt) { return nt * pt > MAXT ? cdiv_c(pt, 2) : pt; }
-  static constexpr int CT1 = 2 * C / 16, NT1 = min_c(CT1, 4), CB1 = CT1 / NT1, PT1 = cap_pt(NT1, cdiv_c(npt(e_cv1), NW / CB1));
+  // (whole-image configurations: cv1's fragments are staged in plane 1, which nothing uses before the first bottleneck conv,
+  //  and a wave holds every output channel of two pixel tiles -- as the entry conv, see WB_S2)
+  static constexpr bool W1_LDS = PERIMG;
+  static constexpr int CT1 = 2 * C / 16, NT1 = W1_LDS ? CT1 : min_c(CT1, 4), CB1 = CT1 / NT1,
+                       PT1 = W1_LDS ? 2 : cap_pt(NT1, cdiv_c(npt(e_cv1), NW / CB1));
   static constexpr int CTM = C / 16, NTM = min_c(CTM, 2), CBM = CTM / NTM;
   static constexpr int ptm(int e) { return cdiv_c(npt(e), NW / CBM); }
   static constexpr int CT2 = COUT / 16, NT2 = CT2 >= 2 ? CT2 / 2 : 1, CB2 = CT2 / NT2, PT2 = cap_pt(NT2, cdiv_c(npt(0), NW / CB2));
@@ -87,7 +91,14 @@ struct C2fCfg {
   static constexpr int c3_steps = C >= 32 ? 9 * (C / 32) : 5;
   static constexpr int WB_CV1 = CT1 * ((KA + KB) / 32) * 1024, WB_M = CTM * c3_steps * 1024, WB_CV2 = CT2 * cdiv_c((2 + NB) * C, 32) * 1024;
   static constexpr int WSLOT = AW ? max_c(WB_CV1, max_c(WB_M, WB_CV2)) : 0;
-  static constexpr int LDS_BYTES = PLANE0 + PLANE + 2 * WSLOT;
+  // whole-image configurations: the entry conv runs before anything lives in the planes, so ALL of its fragments are staged
+  // in LDS (144 KB for 64 -> 128 channels) and a wave holds every output channel of its pixels (NT = all row tiles): each
+  // pixel fragment is gathered from global memory exactly once per workgroup.  With the weights streamed from L2 by every
+  // wave this phase moved 2 MB through the CU's L1 and took 88 k of the kernel's 230 k cycles.
+  static constexpr int NT_S2 = XC / 16, PT_S2 = 2;
+  static constexpr int WB_S2 = PERIMG ? NT_S2 * 9 * (KS2 / 32) * 1024 : 0;
+  static constexpr int LDS_BYTES = max_c(PLANE0 + PLANE + 2 * WSLOT, WB_S2);
+  static_assert(!W1_LDS || WB_CV1 <= PLANE, "cv1's fragments are staged in plane 1");
   static C2fShape shape() {
     C2fShape s;
     s.C = C; s.NB = NB; s.KA = KA; s.KB = KB; s.UP = UP ? 1 : 0; s.COUT = COUT; s.MODE = MODE; s.KS2 = KS2;
@@ -98,6 +109,7 @@ struct C2fCfg {
 struct Ctx {
   int n, oy0, ox0, H, W;
   int lane, wave, g, sig, gam;
+  int dbg;                  // diagnostic flags (C2fArgs::debug_store): bit 1 = the stride-2 gather reads one cache-hot KiB
   unsigned long long* st;   // diagnostic stamps of this workgroup (null on the product path)
 };
 // in-phase stamp (wave 0's first lane), pinned between the surrounding instructions
@@ -293,7 +305,9 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
     floatx4 bv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
-    constexpr int DB = ((NT * PT <= 20 && CFG::C >= 32) || (CFG::WPS == 1 && NT * PT <= 28)) ? 3 : 2;
+    // (whole-image cv1: 8 waves on the CU and a handful of K steps -- the pixel fragments of up to 5 steps ahead are in flight,
+    //  at depth 3 the K loop ran at the L2 round trip: 18 B/clk for the CU)
+    constexpr int DB = (CFG::PERIMG && LDSW) ? min_c(S, 5) : (((NT * PT <= 20 && CFG::C >= 32) || (CFG::WPS == 1 && NT * PT <= 28)) ? 3 : 2);
     constexpr int DA = LDSW ? 2 : DB;
     if (stamp0 >= 0) { C2F_ISTAMP(stamp0) }
     kloop<S, DA, DB, NT, PT>(
@@ -415,6 +429,7 @@ __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char
 template <class CFG, int NT, int CB, int PT, bool LDSW, class EPI>
 __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const char* __restrict__ src, int pitch, const ASrc<LDSW>& wsrc,
                                            const float* __restrict__ bias, EPI&& epi) {
+  // (diagnostic stamps 8 / 9 / 10: wave 0's first block -- K loop start, K loop end, epilogue end)
   constexpr int SPT = CFG::KS2 / 32, S = 9 * SPT;
   const int H2 = 2 * cx.H, W2 = 2 * cx.W;
   const int pixb = pitch * 2, rowb = W2 * pixb;
@@ -433,6 +448,7 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
       const int gy = rg.gy0 + py, gx = rg.gx0 + px;
       base[i] = (unsigned)(((cx.n * H2 + 2 * gy) * W2 + 2 * gx) * pitch) * 2u + (unsigned)cx.gam * 16u;
       fl[i] = (gy == 0 ? 1 : 0) | (gx == 0 ? 2 : 0);
+      if (cx.dbg & 2) { base[i] = (unsigned)(rowb + pixb) + (unsigned)cx.lane * 16u; fl[i] = 0; }
     }
     floatx4 acc[NT][PT];
 #pragma unroll
@@ -444,7 +460,8 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
     floatx4 bv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
-    constexpr int D = (NT * PT <= 20 || (CFG::WPS == 1 && NT * PT <= 28)) ? 3 : 2;
+    constexpr int D = (LDSW && PT <= 2) ? 5 : ((NT * PT <= 20 || (CFG::WPS == 1 && NT * PT <= 28)) ? 3 : 2);
+    if (blk == 0) { C2F_ISTAMP(8) }
     kloop<S, (LDSW ? 2 : D), D, NT, PT>(
         acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
         [&](int s, half8(&bf)[PT]) {
@@ -470,6 +487,7 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
             }
           }
         });
+    if (blk == 0) { C2F_ISTAMP(9) }
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int p0 = (pbk * PT + i) * 16 + cx.sig;
@@ -482,6 +500,7 @@ __device__ __forceinline__ void c3s2_phase(const Ctx& cx, const Rg& rg, const ch
       for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
       epi(cb, ok, py, px, v);
     }
+    if (blk == 0) { C2F_ISTAMP(10) }
   }
 }
 
@@ -633,6 +652,7 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   cx.oy0 = ty * TH; cx.ox0 = tx * TW;
   cx.H = a.H; cx.W = a.W;
   cx.st = a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr;
+  cx.dbg = a.debug_store;
   C2F_STAMP(0)
   C2F_STAMP(1)
 
@@ -652,42 +672,46 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   };
   stage(0);
   stage(1);
+  const char* src1 = reinterpret_cast<const char*>(a.src1);
+  char* cat = reinterpret_cast<char*>(a.cat);
+  const bool dbg = (a.debug_store & 1) != 0;
 
+  // ---- [s2] entry conv -> x (global); its weights occupy the (still unused) planes
+  if constexpr (CFG::MODE >= 1) {
+    stage_weights(cx, a.w[C2F_W_S2], smem, CFG::WB_S2, CFG::NW);
+    const Rg rg = make_region<CFG>(cx, 0);
+    char* xo = reinterpret_cast<char*>(a.x);
+    wg_sync();
+    c3s2_phase<CFG, CFG::NT_S2, 1, CFG::PT_S2, true>(cx, rg, reinterpret_cast<const char*>(a.s2_in), a.s2_pitch, ASrc<true>{smem}, a.b[C2F_W_S2],
+                                                     [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT_S2]) {
+                                                       constexpr int NT = CFG::NT_S2;
+                                                       const int chb = cb * 16 * NT + 4 * NT * cx.g;
+                                                       half_t h[4 * NT];
+                                                       to_half<NT>(v, h);
+                                                       const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+                                                       if (ok) store_h<NT>(xo + (size_t)((unsigned)gpix * (unsigned)a.x_pitch) * 2 + chb * 2, h);
+                                                     });
+    wg_sync();
+  }
   // pixels outside the image must read as zero (the convs' padding): they are never written, so clear the planes once.
   // Interior tiles write every pixel a later phase reads.
   {
     const bool interior = !CFG::PERIMG && cx.oy0 >= F && cx.ox0 >= F && cx.oy0 + TH + F <= a.H && cx.ox0 + TW + F <= a.W;
+    if constexpr (CFG::W1_LDS) stage_weights(cx, a.w[C2F_W_CV1], P1, CFG::WB_CV1, CFG::NW);   // plane 1 is cleared behind cv1
     if (!interior) {
-      for (int i = threadIdx.x; i < (CFG::PLANE0 + CFG::PLANE) / 16; i += CFG::NW * 64) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+      constexpr int NCLR = CFG::W1_LDS ? CFG::PLANE0 : CFG::PLANE0 + CFG::PLANE;
+      for (int i = threadIdx.x; i < NCLR / 16; i += CFG::NW * 64) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
     }
   }
-  const char* src1 = reinterpret_cast<const char*>(a.src1);
-  char* cat = reinterpret_cast<char*>(a.cat);
-  const bool dbg = a.debug_store != 0;
-
-  // ---- [s2] entry conv -> x (global)
-  if constexpr (CFG::MODE >= 1) {
-    const Rg rg = make_region<CFG>(cx, 0);
-    char* xo = reinterpret_cast<char*>(a.x);
-    c3s2_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1, false>(cx, rg, reinterpret_cast<const char*>(a.s2_in), a.s2_pitch,
-                                                 ASrc<false>{reinterpret_cast<const char*>(a.w[C2F_W_S2])}, a.b[C2F_W_S2],
-                                                 [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT1]) {
-                                                   constexpr int NT = CFG::NT1;
-                                                   const int chb = cb * 16 * NT + 4 * NT * cx.g;
-                                                   half_t h[4 * NT];
-                                                   to_half<NT>(v, h);
-                                                   const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
-                                                   if (ok) store_h<NT>(xo + (size_t)((unsigned)gpix * (unsigned)a.x_pitch) * 2 + chb * 2, h);
-                                                 });
-  }
-  wg_sync();
+  wg_sync();   // staged weights landed, planes cleared (cv1's epilogue stores into plane 0)
   C2F_STAMP(2)
 
   // ---- cv1 -> y0 | y1: y1 into plane 0 (whole region); into the concat buffer (tile pixels) whatever cv2 reads from there
   {
     const Rg rg = make_region<CFG>(cx, CFG::e_cv1);
-    pw_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1, CFG::KA, CFG::KB, 0, 0, CFG::UP, AW>(
-        cx, rg, reinterpret_cast<const char*>(a.src0), a.pitch0, src1, a.pitch1, nullptr, nullptr, wsrc(0, C2F_W_CV1), a.b[C2F_W_CV1],
+    pw_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1, CFG::KA, CFG::KB, 0, 0, CFG::UP, AW || CFG::W1_LDS>(
+        cx, rg, reinterpret_cast<const char*>(a.src0), a.pitch0, src1, a.pitch1, nullptr, nullptr,
+        ASrc < AW || CFG::W1_LDS > {CFG::W1_LDS ? P1 : (AW ? wslot(0) : reinterpret_cast<const char*>(a.w[C2F_W_CV1]))}, a.b[C2F_W_CV1],
         [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT1]) {
           constexpr int NT = CFG::NT1;
           const int chb = cb * 16 * NT + 4 * NT * cx.g;
@@ -702,9 +726,13 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
               store_h<NT>(cat + (size_t)((unsigned)gpix * (unsigned)a.cat_pitch) * 2 + chb * 2, h);
             }
           }
-        }, 8);
+        }, CFG::PERIMG ? -1 : 8);
   }
   wg_sync();
+  if constexpr (CFG::W1_LDS) {   // plane 1 held cv1's fragments: now its zero ring
+    for (int i = threadIdx.x; i < CFG::PLANE / 16; i += CFG::NW * 64) reinterpret_cast<u32x4*>(P1)[i] = u32x4{0u, 0u, 0u, 0u};
+    lds_sync();
+  }
   C2F_STAMP(3)
 
   // ---- bottlenecks: a_k: plane 0 -> plane 1; b_k: plane 1 -> y_{k+2} = y_{k+1} + ..
@@ -843,10 +871,14 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2conv_kernel(const C2fArgs a
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   cx.oy0 = ty * CFG::TH; cx.ox0 = tx * CFG::TW;
   cx.H = a.H; cx.W = a.W;
-  cx.st = nullptr;
+  cx.st = a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr;
+  cx.dbg = a.debug_store;
+  C2F_STAMP(0)
+  C2F_STAMP(1)
   stage_weights(cx, a.w[C2F_W_S2], smem, CFG::WBYTES, CFG::NW);
   const Rg rg = make_region<CFG>(cx, 0);
   wg_sync();
+  C2F_STAMP(2)
   char* xo = reinterpret_cast<char*>(a.x);
   c3s2_phase<CFG, CFG::NT, CFG::CB, CFG::PT, true>(cx, rg, reinterpret_cast<const char*>(a.s2_in), a.s2_pitch, ASrc<true>{smem}, a.b[C2F_W_S2],
                                                   [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT]) {
@@ -857,6 +889,8 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2conv_kernel(const C2fArgs a
                                                     const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
                                                     if (ok) store_h<NT>(xo + (size_t)((unsigned)gpix * (unsigned)a.x_pitch) * 2 + chb * 2, h);
                                                   });
+  C2F_STAMP(7)
+  C2F_STAMP(15)
 }
 typedef S2Cfg<32, 64> S2Cfg32x64;   // model.ncnn.param:41 (conv_15: 32 -> 64 @40x40) and :118 (conv_37)
 
@@ -944,6 +978,25 @@ void put_bias(DevBuf& dst, const std::vector<float>* b, int cout) {
 
 }  // namespace
 
+// diagnostic stamps (LITEPI_C2F_STAMPS=<file>): 16 words per workgroup, appended to the file after the launch
+static DevBuf g_stamp_buf;
+static unsigned long long* stamp_buffer(size_t nwg) {
+  if (g_stamp_buf.bytes < nwg * 16 * 8) g_stamp_buf.alloc(nwg * 16 * 8);
+  LP_HIP(hipMemset(g_stamp_buf.p, 0, nwg * 16 * 8));
+  return g_stamp_buf.as<unsigned long long>();
+}
+static void dump_stamps(const char* file, const std::string& name, size_t nwg, hipStream_t st) {
+  LP_HIP(hipStreamSynchronize(st));
+  std::vector<unsigned long long> hst(nwg * 16);
+  LP_HIP(hipMemcpy(hst.data(), g_stamp_buf.p, nwg * 16 * 8, hipMemcpyDeviceToHost));
+  FILE* f = fopen(file, "a");
+  if (!f) return;
+  fprintf(f, "# %s %zu\n", name.c_str(), nwg);
+  for (size_t i = 0; i < nwg; ++i)
+    for (int k = 0; k < 16; ++k) fprintf(f, "%llu%c", hst[i * 16 + k], k == 15 ? '\n' : ' ');
+  fclose(f);
+}
+
 bool C2fLayer::supported(const C2fShape& s, int h, int w) {
   CfgInfo ci;
   if (!cfg_info(s, ci)) return false;
@@ -981,7 +1034,7 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
     }
   };
   const int K1 = s.KA + s.KB;
-  pack_phase(d_w[C2F_W_CV1], *src.cv1, 2 * C, K1, nt_of(2 * C / 16, 4), (K1 + 31) / 32, pw_k(K1));
+  pack_phase(d_w[C2F_W_CV1], *src.cv1, 2 * C, K1, ci.perimg ? 2 * C / 16 : nt_of(2 * C / 16, 4), (K1 + 31) / 32, pw_k(K1));   // NT1
   put_bias(d_b[C2F_W_CV1], src.cv1_b, 2 * C);
   const int ntm = nt_of(C / 16, 2);
   for (int k = 0; k < s.NB; ++k) {
@@ -996,7 +1049,7 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
   put_bias(d_b[C2F_W_CV2], src.cv2_b, s.COUT);
   macs_per_image = ((double)2 * C * K1 + (double)s.NB * 2 * 9 * C * C + (double)s.COUT * K2) * h * w;
   if (s.MODE >= 1) {
-    c3_pack(d_w[C2F_W_S2], *src.s2, 2 * C, s.KS2, nt_of(2 * C / 16, 4));
+    c3_pack(d_w[C2F_W_S2], *src.s2, 2 * C, s.KS2, 2 * C / 16);   // NT_S2: every row tile in one wave
     put_bias(d_b[C2F_W_S2], src.s2_b, 2 * C);
     macs_per_image += 9.0 * s.KS2 * 2 * C * h * w;
   }
@@ -1032,9 +1085,12 @@ void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st)
   a.N = N; a.H = H; a.W = W;
   a.tiles_x = W / 20; a.tiles_y = H / 20;
   typedef S2Cfg32x64 CFG;
+  static const char* stamp_file = getenv("LITEPI_C2F_STAMPS");
+  if (stamp_file) a.stamps = stamp_buffer((size_t)N * a.tiles_x * a.tiles_y);
   set_max_dynamic_lds(reinterpret_cast<const void*>(&s2conv_kernel<CFG>), CFG::WBYTES);
   hipLaunchKernelGGL(s2conv_kernel<CFG>, dim3(N * a.tiles_x * a.tiles_y), dim3(CFG::NW * 64), CFG::WBYTES, st, a);
   LP_HIP(hipGetLastError());
+  if (stamp_file) dump_stamps(stamp_file, name, (size_t)N * a.tiles_x * a.tiles_y, st);
 }
 
 std::string C2fLayer::kernel_name() const {
@@ -1074,14 +1130,10 @@ void C2fLayer::launch(const IO& io, int N, hipStream_t st) const {
   cfg_info(sh, ci);
   a.tiles_x = W / ci.tw; a.tiles_y = H / ci.th;
   static const bool store_all = getenv("LITEPI_C2F_STORE_ALL") != nullptr;   // bisect aid: every y segment goes to the concat buffer
-  a.debug_store = store_all ? 1 : 0;
-  static DevBuf stamp_buf;
+  static const int dbg_flags = getenv("LITEPI_C2F_DEBUG") ? atoi(getenv("LITEPI_C2F_DEBUG")) : 0;   // see Ctx::dbg
+  a.debug_store = (store_all ? 1 : 0) | (dbg_flags & ~1);
   static const char* stamp_file = getenv("LITEPI_C2F_STAMPS");
-  if (stamp_file) {
-    const size_t need = (size_t)N * a.tiles_x * a.tiles_y * 16 * 8;
-    if (stamp_buf.bytes < need) stamp_buf.alloc(need);
-    a.stamps = stamp_buf.as<unsigned long long>();
-  }
+  if (stamp_file) a.stamps = stamp_buffer((size_t)N * a.tiles_x * a.tiles_y);
   const bool ok = try_launch<CfgNeck40>(sh, a, st) || try_launch<CfgNeck80>(sh, a, st) || try_launch<CfgPan40>(sh, a, st) ||
                   try_launch<CfgPan20>(sh, a, st) || try_launch<CfgBb20>(sh, a, st) || try_launch<CfgBb80>(sh, a, st) || try_launch<CfgBb40>(sh, a, st);
   LP_CHECK(ok, LP_ERR_STATE, "c2f %s: no kernel for this shape", name.c_str());
@@ -1090,20 +1142,7 @@ void C2fLayer::launch(const IO& io, int N, hipStream_t st) const {
     try_launch<CfgNeck40>(sh, a, st) || try_launch<CfgNeck80>(sh, a, st) || try_launch<CfgPan40>(sh, a, st) || try_launch<CfgPan20>(sh, a, st) ||
         try_launch<CfgBb20>(sh, a, st) || try_launch<CfgBb80>(sh, a, st) || try_launch<CfgBb40>(sh, a, st);
   }
-  if (stamp_file) {
-    LP_HIP(hipStreamSynchronize(st));
-    const size_t nwg = (size_t)N * a.tiles_x * a.tiles_y;
-    std::vector<unsigned long long> hst(nwg * 16);
-    LP_HIP(hipMemcpy(hst.data(), stamp_buf.p, nwg * 16 * 8, hipMemcpyDeviceToHost));
-    FILE* f = fopen(stamp_file, "a");
-    if (f) {
-      fprintf(f, "# %s %zu\n", name.c_str(), nwg);
-      for (size_t i = 0; i < nwg; ++i) {
-        for (int k = 0; k < 16; ++k) fprintf(f, "%llu%c", hst[i * 16 + k], k == 15 ? '\n' : ' ');
-      }
-      fclose(f);
-    }
-  }
+  if (stamp_file) dump_stamps(stamp_file, name, (size_t)N * a.tiles_x * a.tiles_y, st);
 }
 
 }  // namespace lp

@@ -1203,7 +1203,13 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
   LP_CHECK(loaded_, LP_ERR_STATE, "detector not loaded");
   LP_CHECK(B >= 1 && B <= maxB_, LP_ERR_ARG, "batch %d outside 1..%d", B, maxB_);
   const char* sfx = prec_ == LP_FP16 ? "_f16" : "_f32";
+  // Diagnostic only (tools/marginal_cost.sh): LITEPI_SKIP_OP=<i> leaves launch i out of every pass after this handle's first,
+  // whose outputs stay in its (never re-used) buffers -- the marginal cost of one launch in a pipelined step.  Results are stale.
+  static const int skip_op = getenv("LITEPI_SKIP_OP") ? atoi(getenv("LITEPI_SKIP_OP")) : -1;
+  const bool skipping = skip_op >= 0 && fwd_calls_++ > 0 && !prof;
+  int op_index = -1;
   for (const DetOp& op : ops_) {
+    if (++op_index == skip_op && skipping) continue;
     if (prof) prof->begin(st);
     std::string kname;
     switch (op.kind) {

@@ -64,6 +64,7 @@ class Detector {
  private:
   View view(int t) const;
   int prec_, impl_, maxB_, S_;
+  int fwd_calls_ = 0;   // LITEPI_SKIP_OP diagnostic
   bool loaded_ = false;
   std::vector<Tensor> tensors_;
   std::map<std::string, int> blob2tensor_;   // every blob name (aliases included) -> tensor index
