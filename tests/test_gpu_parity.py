@@ -348,6 +348,52 @@ def test_detector_fp16_other_sizes(tmp_path, size):
     assert err_b.mean() <= 0.5
 
 
+@pytest.mark.parametrize("size,batch", [(320, 5), (640, 7), (800, 4)])
+def test_detector_fp16_c2f_plan_other_sizes(tmp_path, size, batch):
+    """The whole-C2f plan (handles of >= 4 images) on maps other than 80 / 40 / 20: at 320 the 20x20 tile kernels run on a
+    single tile and the 10x10 level falls back to the layer plan; at 640 every module runs fused (an odd batch of 7); at 800 (maps 100 / 50 / 25) the tiles do not divide the maps and every module must fall back.
+    Mixed plans, an odd batch.  The bound is the layer plan's own: the same images through a 3-image handle (layer plan) give
+    the fp16 error of this model at this size, and the whole-C2f plan must stay within 1.25 x of it (and within the documented
+    0.02 / 0.35-cell bounds whenever the layer plan is)."""
+    from litepi import Engine, ncnn_export
+    param, binf = str(tmp_path / "d.param"), str(tmp_path / "d.bin")
+    ncnn_export.export_detector(param, binf, "v1", seed=77, cls_bias=-2.0, size=size)
+    rng = np.random.default_rng(7)
+    imgs = rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
+    ref, _ = _oracle_out0(param, binf, imgs)
+    got, names = {}, {}
+    for plan, cap in (("layer", 3), ("c2f", batch)):
+        e = Engine(precision="fp16", max_batch=cap, det_input=size)
+        try:
+            e.load_detector(param, binf)
+            got[plan] = e.detect_raw(imgs[:cap])
+            e.profile_next(True)
+            e.detect_raw(imgs[:cap])
+            names[plan] = [k["name"] for k in e.profile_read()]
+        finally:
+            e.close()
+    fused = [n for n in names["c2f"] if n.startswith("c2f<") or n.startswith("s2conv<")]
+    print(f"fp16 {size} x{batch}: {len(names['c2f'])} launches ({len(names['layer'])} in the layer plan), whole-C2f / s2conv: {sorted(set(fused))}")
+    assert not any(n.startswith("c2f<") for n in names["layer"])
+    assert (len(fused) > 0) == (size != 800), names["c2f"]
+    n8, n16, n32 = (size // 8) ** 2, (size // 16) ** 2, (size // 32) ** 2
+    stride = np.concatenate([np.full(n8, 8.0), np.full(n16, 16.0), np.full(n32, 32.0)]).astype(np.float32)
+    err = {}
+    for plan in ("layer", "c2f"):
+        g, r = got[plan], ref[:len(got[plan])]
+        es, eb = np.abs(g[:, 4] - r[:, 4]), np.abs(g[:, :4] - r[:, :4])
+        cells = (eb / stride).max()
+        err[plan] = (float(es.max()), float(cells), float(eb.mean()))
+        print(f"   {plan:5s} plan: score err max {es.max():.4f}; box err max {eb.max():.3f} px = {cells:.3f} cells, mean {eb.mean():.4f}")
+    for k, doc in enumerate((0.02, 0.35, 0.5)):   # documented bounds: score, box error in grid cells of the level, mean box error (px)
+        bound = max(doc, 1.25 * err["layer"][k])
+        assert err["c2f"][k] <= bound, f"whole-C2f plan error {err['c2f'][k]} vs layer plan {err['layer'][k]} (metric {k})"
+    # the first three images went through both plans: the two fp16 results agree with each other about as well as with fp32
+    d = np.abs(got["c2f"][:3, 4] - got["layer"][:, 4]).max()
+    print(f"   c2f vs layer plan on the same images: score diff max {d:.4f}")
+    assert d <= max(0.02, 1.5 * err["layer"][0])
+
+
 @pytest.mark.parametrize("cap", [2, 4], ids=["layer_plan", "c2f_plan"])
 @pytest.mark.parametrize("preset", ["v1", "v2"])
 def test_detector_fp16_out0(synth_models, preset, cap):
