@@ -11,6 +11,11 @@ tail -1 "$OUT/bench_n1.log" > "$OUT/bench_n1.json"
 echo "bench done"
 python tools/latency_config1.py > "$OUT/latency_config1.txt" 2>&1 || { echo "latency failed"; exit 1; }
 grep config1 "$OUT/latency_config1.txt"
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rocprof" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 --windows 2 --no-h2d --inflight 1 > "$OUT/rocprof.log" 2>&1) || { echo "rocprof failed"; exit 1; }
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rocprof" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 --windows 2 --no-h2d --no-dropin --inflight 1 > "$OUT/rocprof.log" 2>&1) || { echo "rocprof failed"; exit 1; }
 echo "rocprof done"
 bash tools/pmc_profile.sh "$TAG/pmc" || exit 1
+python bench.py --preset v2 --steps 30 --warmup 5 --no-cpu-baseline --no-dropin > "$OUT/bench_v2.log" 2> "$OUT/bench_v2.err" || { echo "v2 bench failed"; exit 1; }
+tail -1 "$OUT/bench_v2.log" > "$OUT/bench_v2.json"
+bash tools/marginal_cost.sh 16 > "$OUT/marginal_cost.txt" 2>&1 || { echo "marginal cost failed"; exit 1; }
+python tools/h2d_probe.py > "$OUT/h2d_probe.txt" 2>&1
+echo "all done"

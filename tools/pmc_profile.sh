@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/${1:-pmc}
 shift || true
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 --inflight 1 $*"
+BENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 --no-h2d --no-dropin --inflight 1 $*"
 i=0
 for set in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
