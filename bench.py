@@ -287,7 +287,7 @@ def main():
 
     # ---- the drop-in call itself: HybridPipeline.run_batch on B host NumPy images -> per-image result dicts ----------
     dropin = None
-    if rank == 0 and not args.no_dropin:
+    if rank == 0 and world == 1 and not args.no_dropin:   # a single-GPU measurement (as cpu_baseline): the other ranks do not wait for it
         from litepi import HybridPipeline
         cls_path = os.path.join(workdir, "cls.pth")
         torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in cls_state.items()}, cls_path)
