@@ -518,35 +518,47 @@ __device__ __forceinline__ void lds_sync() {
 template <class CFG>
 __device__ __forceinline__ void pool_phase(const Ctx& cx, char* pio, char* ptmp, char* gdst, int gpitch) {
   constexpr int CG = CFG::C / 8, LW = CFG::LW, PS = CFG::PS, F = CFG::F, TH = CFG::TH, TW = CFG::TW;
-  for (int it = threadIdx.x; it < TH * TW * CG; it += CFG::NW * 64) {
-    const int pix = it / CG, cg = it - pix * CG;
-    const int y = pix / TW, x = pix - y * TW;
-    const char* row = pio + ((y + F) * LW + F) * PS + cg * 16;
-    half8 m = *reinterpret_cast<const half8*>(row + x * PS);
+  static_assert(TH == 20 && TW == 20, "pool strips: two strips of 10 outputs per line");
+  // One thread per (line, channel group, half line): its ten 5-maxima from shared pair maxima -- p[j] = max(v[j], v[j+1]),
+  // out[i] = max(p[i], p[i+2], v[i+4]) -- with the window positions clamped onto the line: 18 loads and 36 vector maxima for 10
+  // outputs (a window per output: 50 loads with their index arithmetic and 40 maxima -- that form spent 5 k cycles per pass,
+  // three quarters of the SPPF tail).
+  auto strip = [&](const char* __restrict__ src, char* __restrict__ dst, int step) {   // position 0 of the line; bytes between positions
+    const int half = (threadIdx.x / (20 * CG)) & 1;   // (only threads < 2 * 20 * CG get here)
+    const int x0 = 10 * half;
+    // two sub-strips of five outputs (nine loads each): the SPPF tail's accumulators stay live across the pools, and
+    // fourteen loaded vectors beside them spilled
 #pragma unroll
-    for (int dx = -2; dx <= 2; ++dx) {
-      if (dx == 0) continue;
-      const int xx = min(max(x + dx, 0), TW - 1);
-      m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(row + xx * PS));
-    }
-    *reinterpret_cast<half8*>(ptmp + ((y + F) * LW + x + F) * PS + cg * 16) = m;
-  }
-  lds_sync();
-  for (int it = threadIdx.x; it < TH * TW * CG; it += CFG::NW * 64) {
-    const int pix = it / CG, cg = it - pix * CG;
-    const int y = pix / TW, x = pix - y * TW;
-    const char* colp = ptmp + (F * LW + x + F) * PS + cg * 16;
-    half8 m = *reinterpret_cast<const half8*>(colp + y * LW * PS);
+    for (int sub = 0; sub < 2; ++sub) {
+      half8 v[9];
 #pragma unroll
-    for (int dy = -2; dy <= 2; ++dy) {
-      if (dy == 0) continue;
-      const int yy = min(max(y + dy, 0), TH - 1);
-      m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(colp + yy * LW * PS));
+      for (int j = 0; j < 9; ++j) {
+        const int x = min(max(x0 + 5 * sub - 2 + j, 0), 19);
+        v[j] = *reinterpret_cast<const half8*>(src + x * step);
+      }
+      half8 pm[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pm[j] = __builtin_elementwise_max(v[j], v[j + 1]);
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        *reinterpret_cast<half8*>(dst + (x0 + 5 * sub + i) * step) = __builtin_elementwise_max(__builtin_elementwise_max(pm[i], pm[i + 2]), v[i + 4]);
     }
-    *reinterpret_cast<half8*>(pio + ((y + F) * LW + x + F) * PS + cg * 16) = m;
-    if (gdst) *reinterpret_cast<half8*>(gdst + (size_t)(((cx.n * cx.H + y) * cx.W + x) * gpitch) * 2 + cg * 16) = m;
-  }
+  };
+  const int t = threadIdx.x;
+  const bool work = t < 2 * 20 * CG;
+  const int line = (t % (20 * CG)) / CG, cg = t % CG;
+  if (work) strip(pio + ((line + F) * LW + F) * PS + cg * 16, ptmp + ((line + F) * LW + F) * PS + cg * 16, PS);   // along x
   lds_sync();
+  if (work) strip(ptmp + (F * LW + line + F) * PS + cg * 16, pio + (F * LW + line + F) * PS + cg * 16, LW * PS);   // along y
+  lds_sync();
+  if (gdst) {   // bisect aid: the pooled map also goes to global memory
+    for (int it = threadIdx.x; it < TH * TW * CG; it += CFG::NW * 64) {
+      const int pix = it / CG, g8 = it - pix * CG;
+      const int y = pix / TW, x = pix - y * TW;
+      *reinterpret_cast<half8*>(gdst + (size_t)(((cx.n * cx.H + y) * cx.W + x) * gpitch) * 2 + g8 * 16) =
+          *reinterpret_cast<const half8*>(pio + ((y + F) * LW + x + F) * PS + g8 * 16);
+    }
+  }
 }
 
 // ---- SPPF.cv2 over concat(s, p1, p2, p3) without the concat: out = silu(W0 s + W1 p1 + W2 p2 + W3 p3 + b), the four
@@ -579,9 +591,7 @@ __device__ __forceinline__ void sppf_tail(const Ctx& cx, const Rg& rg, char* P0,
     for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
   int woff = (cb * S * NT * 64 + cx.lane) * 16;
   asm volatile("" : "+v"(woff));
-  floatx4 bv[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+  floatx4 bv[NT];   // requested behind the last pool (live across the pools it would cost the strips their registers)
   half8 af[SPT][NT];
   auto load_a = [&](int seg) {
 #pragma unroll
@@ -593,6 +603,10 @@ __device__ __forceinline__ void sppf_tail(const Ctx& cx, const Rg& rg, char* P0,
 #pragma unroll
   for (int seg = 0; seg < 4; ++seg) {
     if (seg > 0) pool_phase<CFG>(cx, P0, P1, gcat2 ? gcat2 + seg * C * 2 : nullptr, gpitch);
+    if (seg == 3) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+    }
     if (has) {
 #pragma unroll
       for (int s = 0; s < SPT; ++s) {
