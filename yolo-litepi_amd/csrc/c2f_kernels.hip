@@ -147,7 +147,9 @@ __device__ __forceinline__ half8 as_h8(u32x4 v) { return __builtin_bit_cast(half
 // x * sigmoid(x) of (v + b), the arithmetic of act4<T, ACT_SILU> in conv_kernels.hip (hardware exp2 / rcp, two-wide multiplies)
 __device__ __forceinline__ floatx4 silu4(floatx4 v, floatx4 b) {
   v = v + b;
-  const floatx4 t = v * -1.4426950408889634f;
+  float nl2e = -1.4426950408889634f;   // in an SGPR: two v_pk_mul_f32 instead of four v_mul_f32 with a literal (act4, conv_kernels.hip)
+  asm("" : "+s"(nl2e));
+  const floatx4 t = v * floatx4{nl2e, nl2e, nl2e, nl2e};
   floatx4 e;
 #pragma unroll
   for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(t[i]);

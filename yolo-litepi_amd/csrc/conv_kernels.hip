@@ -83,7 +83,11 @@ template <typename T, int ACT> __device__ __forceinline__ float activate_ct(floa
 template <typename T, int ACT> __device__ __forceinline__ floatx4 act4(floatx4 v, floatx4 b) {
   v = v + b;
   if (ACT == ACT_SILU) {
-    const floatx4 t = v * -1.4426950408889634f;
+    // (-log2 e in a scalar register the compiler cannot see through: as a literal it turns the multiply into four
+    //  v_mul_f32 -- VOP3P has no literal operand --, from an SGPR pair it is two v_pk_mul_f32; same product, bit for bit)
+    float nl2e = -1.4426950408889634f;
+    asm("" : "+s"(nl2e));
+    const floatx4 t = v * floatx4{nl2e, nl2e, nl2e, nl2e};
     floatx4 e;
 #pragma unroll
     for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(t[i]);

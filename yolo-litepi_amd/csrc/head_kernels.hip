@@ -44,7 +44,9 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 // x * sigmoid(x) for two values: the multiplies and the add are two-wide (v_pk_*_f32), the exponential and the reciprocal
 // are the hardware transcendentals (1 ulp), as Tr<half>::silu in conv_kernels.hip
 __device__ __forceinline__ floatx2 hd_silu2(floatx2 v) {
-  const floatx2 t = v * floatx2{-1.4426950408889634f, -1.4426950408889634f};
+  float nl2e = -1.4426950408889634f;   // in an SGPR, or the packed multiply becomes two v_mul_f32 with a literal (act4, conv_kernels.hip)
+  asm("" : "+s"(nl2e));
+  const floatx2 t = v * floatx2{nl2e, nl2e};
   floatx2 e;
   e[0] = __builtin_amdgcn_exp2f(t[0]);
   e[1] = __builtin_amdgcn_exp2f(t[1]);
