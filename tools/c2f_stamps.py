@@ -31,7 +31,10 @@ for k, runs in out.items():
         print("      s2 phase, wave 0 block 0: before K loop %d  K loop %d  epilogue %d  rest of the phase %d%s" % (
             np.median(a[:, 8] - start), np.median(a[:, 9] - a[:, 8]), np.median(a[:, 10] - a[:, 9]), np.median(end - a[:, 10]),
             "" if whole else "  (weights staged in %d)" % np.median(a[:, 2] - a[:, 1])))
-    a2 = a[(a[:, 8] > 0) & (a[:, 11] > 0)]
+    if a[:, 14].max() > 0:   # whole-image cv2 (pw_sync_phase): 11 K loop start, 12 K loop end, 13 behind the barrier, 14 epilogue end
+        print("      cv2 (one round): before K loop %d  K loop %d  barrier %d  epilogue %d" % (
+            np.median(a[:, 11] - a[:, 4]), np.median(a[:, 12] - a[:, 11]), np.median(a[:, 13] - a[:, 12]), np.median(a[:, 14] - a[:, 13])))
+    a2 = a[(a[:, 8] > 0) & (a[:, 11] > 0) & (a[:, 14] == 0)]
     if len(a2):
         inner = [np.median(a2[:, 8] - a2[:, 2]), np.median(a2[:, 9] - a2[:, 8]), np.median(a2[:, 10] - a2[:, 9]), np.median(a2[:, 3] - a2[:, 10]),
                  np.median(a2[:, 11] - a2[:, 4]), np.median(a2[:, 12] - a2[:, 11]), np.median(a2[:, 13] - a2[:, 12]), np.median(a2[:, 5] - a2[:, 13])]

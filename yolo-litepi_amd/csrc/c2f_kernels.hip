@@ -81,6 +81,7 @@ struct C2fCfg {
   static constexpr int CTM = C / 16, NTM = min_c(CTM, 2), CBM = CTM / NTM;
   static constexpr int ptm(int e) { return cdiv_c(npt(e), NW / CBM); }
   static constexpr int CT2 = COUT / 16, NT2 = CT2 >= 2 ? CT2 / 2 : 1, CB2 = CT2 / NT2, PT2 = cap_pt(NT2, cdiv_c(npt(0), NW / CB2));
+  static constexpr int PT2W = cdiv_c(npt(0), NW / CB2);   // whole-image cv2: one round of blocks (pw_sync_phase)
   static constexpr int NTS = min_c(C / 16, 2), CBS = (C / 16) / NTS, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
   static constexpr int WPS = NW == 4 && MODE_ >= 1 ? 1 : 2;   // waves per SIMD the register allocation must allow
   // cv2 reads y_NB and y_{NB+1} from the LDS planes (whole K steps need c >= 32); the earlier segments from the concat buffer
@@ -340,6 +341,83 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
       epi(cb, ok, py, px, v);
     }
     if (stamp0 >= 0) { C2F_ISTAMP(stamp0 + 2) }
+  }
+}
+
+// ---- 1x1 conv + SiLU of the whole-image configurations whose epilogue stores into the planes its K loop reads (cv2 -> the
+//      SPPF's input, SPPF.cv1 -> the pools' input): ONE round of blocks (every accumulator tile of the phase lives in the
+//      eight waves' registers), a workgroup barrier between the K loops and the epilogues.  K = KB channels from global srcB
+//      (whole steps), then KL0 from plane 0 and KL1 from plane 1; weights from L2.  With the plain pw_phase these two phases ran
+//      two rounds of blocks and SPPF.cv1 read cv2's output back from global memory: 46 k cycles for 1600 MFMAs per wave-set.
+template <class CFG, int NT, int CB, int PT, int KB, int KL0, int KL1, int DA, class EPI>
+__device__ __forceinline__ void pw_sync_phase(const Ctx& cx, const Rg& rg, const char* __restrict__ srcB, int pitchB, const char* pl0, const char* pl1,
+                                              const char* __restrict__ w, const float* __restrict__ bias, EPI&& epi, int stamp0 = -1) {
+  static_assert(KB % 32 == 0 && KL0 % 32 == 0 && KL1 % 32 == 0, "whole K steps");
+  constexpr int SB = KB / 32, SL0 = KL0 / 32, SL1 = KL1 / 32, S = SB + SL0 + SL1, PS = CFG::PS;
+  static_assert(cdiv_c(CFG::npt(0), PT) * CB <= CFG::NW && NT * PT <= 28, "one round of blocks");
+  const int npt = (rg.R + 15) >> 4;
+  const int nblk = ((npt + PT - 1) / PT) * CB;
+  const bool has = cx.wave < nblk;   // wave-uniform
+  const int blk = has ? cx.wave : 0;
+  const int cb = blk % CB, pbk = blk / CB;
+  floatx4 acc[NT][PT];
+  if (has) {
+    unsigned offB[SB > 0 ? PT : 1];
+    int pb[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      int p = (pbk * PT + i) * 16 + cx.sig;
+      p = p < rg.R ? p : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      if constexpr (SB > 0) offB[i] = (unsigned)(((cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px) * pitchB) * 2u + (unsigned)cx.gam * 16u;
+      pb[i] = ((rg.fy0 + py) * CFG::LW + rg.fx0 + px) * PS + cx.gam * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    int woff = (cb * S * NT * 64 + cx.lane) * 16;
+    asm volatile("" : "+v"(woff));
+    if (stamp0 >= 0) { C2F_ISTAMP(stamp0) }
+    kloop<S, DA, 2, NT, PT>(   // DA: weight fragments (L2) requested DA - 1 steps ahead
+        acc,
+        [&](int s_, half8(&af)[NT]) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) af[t] = as_h8(*reinterpret_cast<const u32x4*>(w + woff + (s_ * NT + t) * 1024));
+        },
+        [&](int s_, half8(&bf)[PT]) {
+#pragma unroll
+          for (int i = 0; i < PT; ++i) {
+            if (s_ < SB) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(srcB + (size_t)offB[SB > 0 ? i : 0] + s_ * 64));
+            else if (s_ < SB + SL0) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl0 + pb[i] + (s_ - SB) * 64));
+            else bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl1 + pb[i] + (s_ - SB - SL0) * 64));
+          }
+        },
+        NoFix{});
+    if (stamp0 >= 0) { C2F_ISTAMP(stamp0 + 1) }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (stamp0 >= 0) { C2F_ISTAMP(stamp0 + 2) }
+  if (has) {
+    floatx4 bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int p0 = (pbk * PT + i) * 16 + cx.sig;
+      const bool ok = p0 < rg.R;
+      const int p = ok ? p0 : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      floatx4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
+      epi(cb, ok, py, px, v);
+    }
+    if (stamp0 >= 0) { C2F_ISTAMP(stamp0 + 3) }
   }
 }
 
@@ -819,19 +897,38 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
           if (ok) store_h<NT>(out + (size_t)((unsigned)gpix * (unsigned)a.out_pitch) * 2 + chb * 2, h);
         };
     // K segments: [concat buffer, K2G channels] [plane 0] [plane 1]; Y01: plane 0 = y0 | y1 (2c), plane 1 = y2 (c)
-    pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, CFG::K2G, (CFG::CV2_LDS ? (CFG::Y01 ? 2 * C : C) : 0), (CFG::CV2_LDS ? C : 0), false, AW,
-             decltype(epi_cv2)&, PS0, PS>(cx, rg, nullptr, 0, cat, a.cat_pitch, P0, P1, wsrc(2 * NB + 1, C2F_W_CV2), a.b[C2F_W_CV2], epi_cv2, 11);
+    if constexpr (CFG::PERIMG) {
+      // one round of blocks; MODE 2: the output (2c = COUT channels) also replaces y_NB | y_{NB+1} in the planes -- SPPF.cv1's input
+      static_assert(CFG::K2G % 32 == 0 && CFG::CV2_LDS && (CFG::MODE != 2 || CFG::COUT == 2 * C), "whole-image cv2");
+      pw_sync_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2W, CFG::K2G, C, C, 2>(
+          cx, rg, cat, a.cat_pitch, P0, P1, reinterpret_cast<const char*>(a.w[C2F_W_CV2]), a.b[C2F_W_CV2],
+          [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT2]) {
+            constexpr int NT = CFG::NT2;
+            const int chb = cb * 16 * NT + 4 * NT * cx.g;
+            half_t h[4 * NT];
+            to_half<NT>(v, h);
+            const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+            if (ok) {
+              store_h<NT>(out + (size_t)((unsigned)gpix * (unsigned)a.out_pitch) * 2 + chb * 2, h);
+              if constexpr (CFG::MODE == 2)
+                store_h<NT>((chb < C ? P0 : P1) + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + (chb < C ? chb : chb - C) * 2, h);
+            }
+          }, 11);
+    } else {
+      pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, CFG::K2G, (CFG::CV2_LDS ? (CFG::Y01 ? 2 * C : C) : 0), (CFG::CV2_LDS ? C : 0), false, AW,
+               decltype(epi_cv2)&, PS0, PS>(cx, rg, nullptr, 0, cat, a.cat_pitch, P0, P1, wsrc(2 * NB + 1, C2F_W_CV2), a.b[C2F_W_CV2], epi_cv2, 11);
+    }
   }
   C2F_STAMP(5)
 
-  // ---- [sppf] cv1 (out -> s, plane 0) -> cv2 accumulated over s and the three cascaded pools (sppf_tail)
+  // ---- [sppf] cv1 (cv2's output in the planes -> s, plane 0) -> cv2 accumulated over s and the three cascaded pools (sppf_tail)
   if constexpr (CFG::MODE == 2) {
-    wg_sync();
+    lds_sync();   // cv2's plane stores
     const Rg rg = make_region<CFG>(cx, 0);
     char* cat2 = reinterpret_cast<char*>(a.cat2);
-    pw_phase<CFG, CFG::NTS, CFG::CBS, CFG::PTS, 0, CFG::COUT, 0, 0, false, false>(
-        cx, rg, nullptr, 0, reinterpret_cast<const char*>(a.out), a.out_pitch, nullptr, nullptr, ASrc<false>{reinterpret_cast<const char*>(a.w[C2F_W_SP1])},
-        a.b[C2F_W_SP1], [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NTS]) {
+    pw_sync_phase<CFG, CFG::NTS, CFG::CBS, CFG::PTS, 0, C, C, 2>(
+        cx, rg, nullptr, 0, P0, P1, reinterpret_cast<const char*>(a.w[C2F_W_SP1]), a.b[C2F_W_SP1],
+        [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NTS]) {
           constexpr int NT = CFG::NTS;
           const int chb = cb * 16 * NT + 4 * NT * cx.g;
           half_t h[4 * NT];
