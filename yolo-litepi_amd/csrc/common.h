@@ -154,7 +154,7 @@ struct BneckArgs {
 // Fused network head: stem 3x3/s2 (uint8 -> 8 ch) + 3x3/s2 conv + its 1x1 tail (stem_block_kernel)
 struct StemBlockArgs {
   const uint8_t* img;
-  const void* afrag;   // stem MFMA A fragments (StemLayer::d_afrag)
+  const void* afrag;   // stem MFMA A fragments (StemLayer::d_afrag_blk)
   const float* sbias;  // stem bias
   const void* w1;      // stride-2 conv fragments [3 steps][64 lanes][16 B] (K = 9 taps x 8 channels)
   const float* b1;

@@ -88,6 +88,7 @@ struct StemLayer {
   int k = 3, stride = 2, pad = 1;  // YOLOv8 family: 3x3/s2/p1 (fast kernels); anything else runs the generic kernel
   DevBuf d_w, d_bias;
   DevBuf d_afrag;  // fp16, 8 channels: MFMA A fragments (stem_mfma_kernel)
+  DevBuf d_afrag_blk;  // the same weights in stem_block_kernel's K-group order
   // w_bgr: fp32 [k*k*3][CO], row = (ky*k+kx)*3 + c with c in BGR order
   void build(int prec, int cout_phys, int act, const std::vector<float>& w_bgr, const std::vector<float>& bias, int k = 3, int stride = 2,
              int pad = 1);

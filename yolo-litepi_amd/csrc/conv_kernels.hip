@@ -1505,7 +1505,7 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
       if (c < SB_ROWW && r < SB_IR) in_tile[r * SB_ROWW + c] = v[k] & m;
     }
   }
-  const half8 af0 = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.afrag)[lane]);
+  const half8 af0 = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.afrag)[lane]);   // StemLayer::d_afrag_blk
   const half8 af1 = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.afrag)[64 + lane]);
   const int c0 = (g & 1) * 4;
   const floatx4 sb4 = *reinterpret_cast<const floatx4*>(a.sbias + c0);
@@ -1515,22 +1515,28 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
   constexpr int NPAIR = SB_SH * SB_PAIRS, NTILE = (NPAIR + 15) / 16;
   // block-uniform: every stem pixel of this tile lies inside the stem map (then no per-pixel test)
   const bool sb_interior = oy0 >= 1 && ox0 >= 1 && 2 * oy0 - 1 + SB_SH <= a.H1 && 2 * ox0 - 1 + SB_SW <= a.W1;
+  // K group -> (window row ky, byte half h) of the 15-byte union window (StemLayer::build packs a_blk to match): step 0 holds
+  // rows 0 and 2, step 1 row 1 (+ two zero-weight groups that re-read it).  The two K groups of a 32-lane ds_read_b32 group then
+  // read rows two apart = 16 banks apart (row pitch 104 dwords): half the bank conflicts of the (ky, h) = (q / 2, q % 2) order
+  // (852 -> 522 LDS cycles per workgroup in a simulation of the access pattern).
+  const int ky0 = 2 * (g & 1), hh = g >> 1;
+  // pair index of this lane's column in tile t, as (row r, pair pp): t advances by 4 tiles = 64 pairs = 1 row + 31 pairs
+  int pi = wave * 16 + col;
+  int r = pi >= SB_PAIRS ? 1 : 0, pp = pi - r * SB_PAIRS;   // wave * 16 + col < 64 < 2 * SB_PAIRS
   for (int t = wave; t < NTILE; t += 4) {
-    int pi = t * 16 + col;
-    pi = pi < NPAIR ? pi : NPAIR - 1;
-    const int r = (pi * 1986) >> 16, pp = pi - r * SB_PAIRS;  // / 33 (exact below 2^11)
+    const bool live = pi < NPAIR;
+    const int rc = live ? r : SB_SH - 1, ppc = live ? pp : SB_PAIRS - 1;
     half8 bf[2];
+    // window byte 3 + 12 pp + 8 h of tile row 2 r + ky: dword (2 r + ky) * ROWW + 3 pp + 2 h, byte 3 of it (32-bit index arithmetic:
+    // as pointer arithmetic on the __shared__ array the compiler built 64-bit products)
+    const int idx0 = 2 * rc * SB_ROWW + 3 * ppc + 2 * hh;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int q = 4 * s + g;
-      const int ky = q >> 1, h = q & 1;
-      const int bo = 3 + 12 * pp + 8 * h;
-      const uint32_t* rw = in_tile + (2 * r + (ky < 3 ? ky : 2)) * SB_ROWW + (bo >> 2);
-      const int sh = bo & 3;
-      const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
-      uint32_t wa = __builtin_amdgcn_alignbyte(d1, d0, sh);
-      uint32_t wb = __builtin_amdgcn_alignbyte(d2, d1, sh);
-      if (q >= 6) { wa = 0u; wb = 0u; }
+      const int idx = idx0 + (s == 0 ? ky0 : 1) * SB_ROWW;
+      const uint32_t d0 = in_tile[idx], d1 = in_tile[idx + 1], d2 = in_tile[idx + 2];
+      const uint32_t wa = __builtin_amdgcn_alignbyte(d1, d0, 3);   // bo & 3 == 3 always
+      const uint32_t wb = __builtin_amdgcn_alignbyte(d2, d1, 3);
+      // (the padded K groups of step 1 carry zero weights: whatever finite bytes they read contribute nothing)
       const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04010400u);
       const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04030402u);
       const uint32_t p2 = __builtin_amdgcn_perm(0x64646464u, wb, 0x04010400u);
@@ -1542,16 +1548,21 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0, bf[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1, bf[1], acc, 0, 0, 0);
-    const int c = 2 * pp + (g >> 1);
-    if (t * 16 + col < NPAIR && c < SB_SW) {
-      const int sy = 2 * oy0 - 1 + r, sx = 2 * ox0 - 1 + c;
+    const int c = 2 * ppc + (g >> 1);
+    if (live && c < SB_SW) {
+      const int sy = 2 * oy0 - 1 + rc, sx = 2 * ox0 - 1 + c;
       const bool inside = sb_interior || (sy >= 0 && sy < a.H1 && sx >= 0 && sx < a.W1);
-      half4 q4;
       const floatx4 y4 = act4<half_t, ACT_SILU>(acc, sb4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q4[j] = inside ? (half_t)y4[j] : (half_t)0.f;
-      *reinterpret_cast<half4*>(st_tile + (r * SB_LW + c) * 16 + c0 * 2) = q4;
+      // two packed converts, then the mask on the packed words (a select per half was four converts, four selects, two packs)
+      const half2v q01 = {(half_t)y4[0], (half_t)y4[1]}, q23 = {(half_t)y4[2], (half_t)y4[3]};
+      const uint32_t m = inside ? 0xffffffffu : 0u;
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<u32x2*>(st_tile + (rc * SB_LW + c) * 16 + c0 * 2) = u32x2{__builtin_bit_cast(uint32_t, q01) & m, __builtin_bit_cast(uint32_t, q23) & m};
     }
+    pi += 64;
+    pp += 31;
+    r += 1;
+    if (pp >= SB_PAIRS) { pp -= SB_PAIRS; r += 1; }
   }
   // ---- 3. stride-2 3x3 conv from the stem tile (K group = tap: 9 of 12 slots), then the 1x1 tail
   half8 a1[3];
@@ -2259,6 +2270,22 @@ void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<floa
       }
     d_afrag.alloc(buf.size());
     LP_HIP(hipMemcpy(d_afrag.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    // stem_block_kernel's order of the K groups: step 0 = (ky 0, h 0) (ky 2, h 0) (ky 0, h 1) (ky 2, h 1), step 1 = (ky 1, h 0)
+    // zero (ky 1, h 1) zero -- the two groups of a 32-lane LDS read group are two tile rows = 16 banks apart
+    std::vector<uint8_t> blk((size_t)2 * 64 * 16, 0);
+    for (int s = 0; s < 2; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, m = lane & 15, par = m >> 3, ch = m & 7;
+        if (s == 1 && (g & 1)) continue;
+        const int ky = s == 0 ? 2 * (g & 1) : 1, h = g >> 1;
+        for (int j = 0; j < 8; ++j) {
+          const int jj = 8 * h + j, jw = jj - 6 * par;
+          if (jw < 0 || jw > 8) continue;
+          put_elem(blk, ((size_t)s * 64 + lane) * 8 + j, LP_FP16, w_bgr[(size_t)(ky * 9 + jw) * CO + ch] / 255.f);
+        }
+      }
+    d_afrag_blk.alloc(blk.size());
+    LP_HIP(hipMemcpy(d_afrag_blk.p, blk.data(), blk.size(), hipMemcpyHostToDevice));
   }
   if (prec == LP_FP16 && CO == 16 && act == ACT_SILU && k == 3 && stride == 2 && pad == 1) {
     // stem_mfma16_kernel A fragment [64 lanes][8]: row m = channel; K group g < 3 = window row g bytes 0..7, group 3 =
@@ -2281,7 +2308,7 @@ void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<floa
 
 
 bool StemLayer::block_supported(const ConvLayer& c1) const {
-  return prec == LP_FP16 && CO == 8 && d_afrag.p && c1.prec == LP_FP16 && c1.impl == IMPL_MFMA && c1.direct && c1.k == 3 && c1.stride == 2 &&
+  return prec == LP_FP16 && CO == 8 && d_afrag_blk.p && c1.prec == LP_FP16 && c1.impl == IMPL_MFMA && c1.direct && c1.k == 3 && c1.stride == 2 &&
          c1.Cin == 8 && c1.NT == 1 && c1.nsplits == 1 && c1.T2 == 1 && c1.act == ACT_SILU && c1.steps == 3;
 }
 
@@ -2289,7 +2316,7 @@ void StemLayer::launch_block(const uint8_t* img, int N, int Hin, int Win, const 
   LP_CHECK(block_supported(c1) && Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0, LP_ERR_STATE, "stem block: unsupported configuration");
   StemBlockArgs a;
   memset(&a, 0, sizeof(a));
-  a.img = img; a.afrag = d_afrag.p; a.sbias = d_bias.as<float>();
+  a.img = img; a.afrag = d_afrag_blk.p; a.sbias = d_bias.as<float>();
   a.w1 = c1.d_w.p; a.b1 = c1.d_bias.as<float>(); a.w2 = c1.d_w2.p; a.b2 = c1.d_bias2.as<float>();
   a.out = out.base; a.N = N; a.Hin = Hin; a.Win = Win; a.H1 = (Hin + 1) / 2; a.W1 = (Win + 1) / 2;
   a.H2 = out.H; a.W2 = out.W; a.out_pitch = out.pitch; a.C2 = c1.Cout2; a.act2 = c1.act2;
