@@ -17,10 +17,13 @@
 //            projection's K order permuted to match (MI355X guide, "an accumulator tile as the next MFMA's operand")
 //   decode   in registers: the projection rows are permuted so that a lane holds the 16 bins of one box side
 // MFMA: v_mfma_f32_32x32x16_f16, D[out-channel][pixel] = W . X.  A wave computes RT (or 2) row tiles x P pixel tiles per
-// K step: (RT + P) KB of LDS operands per RT*P MFMAs of 32 cycles -> 20-45 % of the LDS rate, so the matrix pipe is
-// the limiter.  Weights: every workgroup consumes the same 150-300 fragments (1 KiB each) in the same order, so the
-// host packs them into one stream and the kernel moves it through a two-slot LDS ring by LDS-DMA (global_load_lds),
-// chunk c+1 in flight while chunk c is consumed; the input tile is staged by LDS-DMA too.
+// K step: (RT + P) KiB of LDS operands per RT*P MFMAs of 32 cycles = 0.8 - 2 ds_read_b128 per MFMA (two per MFMA and SIMD
+// saturate the LDS); measured, the K loops run at 37-44 cycles per MFMA and are half of a workgroup's cycles -- the rest is
+// the prologue (tile + first weight chunks) and the SiLU epilogues / decode on the VALU (tools/head_stamps.py).
+// Weights: every workgroup consumes the same 150-370 fragments (1 KiB each) in the same order, so the host packs them into
+// one stream and the kernel moves it through a two-slot LDS ring THROUGH REGISTERS (a global load + ds_write pair per piece
+// behind the MFMAs of a K step, one chunk ahead; the first version used global_load_lds and paid 100+ issue cycles per
+// piece); the input tile is staged through registers too (all rows requested before the first store).
 #include "head.h"
 #include "post_dev.h"
 
