@@ -394,6 +394,43 @@ def test_detector_fp16_c2f_plan_other_sizes(tmp_path, size, batch):
     assert d <= max(0.02, 1.5 * err["layer"][0])
 
 
+@pytest.mark.parametrize("seed,batch", [(11, 4), (23, 6), (37, 9)])
+def test_c2f_plan_vs_layer_plan_random_models(tmp_path, seed, batch):
+    """Whole-C2f plan against the layer plan (LITEPI_NO_C2F / LITEPI_NO_S2C, read when the plan is built) on further random
+    models and batch sizes, no oracle in between: the two fp16 plans sum in different orders, so the same documented fp16
+    bounds apply to their difference; a tile, halo or concat indexing error would show as a difference of whole activations."""
+    from litepi import Engine, ncnn_export
+    param, binf = str(tmp_path / "d.param"), str(tmp_path / "d.bin")
+    ncnn_export.export_detector(param, binf, "v1", seed=seed, cls_bias=-2.0)
+    imgs = np.random.default_rng(seed).integers(0, 256, (batch, 640, 640, 3), dtype=np.uint8)
+    out = {}
+    for plan in ("c2f", "layer"):
+        if plan == "layer":
+            os.environ["LITEPI_NO_C2F"] = "1"
+            os.environ["LITEPI_NO_S2C"] = "1"
+        try:
+            e = Engine(precision="fp16", max_batch=batch)
+            try:
+                e.load_detector(param, binf)
+                out[plan] = e.detect_raw(imgs)
+                e.profile_next(True)
+                e.detect_raw(imgs)
+                names = [k["name"] for k in e.profile_read()]
+            finally:
+                e.close()
+        finally:
+            os.environ.pop("LITEPI_NO_C2F", None)
+            os.environ.pop("LITEPI_NO_S2C", None)
+        assert any(n.startswith("c2f<") for n in names) == (plan == "c2f"), names
+    stride = np.concatenate([np.full(6400, 8.0), np.full(1600, 16.0), np.full(400, 32.0)]).astype(np.float32)
+    ds = np.abs(out["c2f"][:, 4] - out["layer"][:, 4])
+    db = np.abs(out["c2f"][:, :4] - out["layer"][:, :4])
+    print(f"seed {seed} x{batch}: c2f vs layer plan: score diff max {ds.max():.4f}, box diff max {db.max():.3f} px ({(db / stride).max():.3f} cells), mean {db.mean():.4f}")
+    assert ds.max() <= 0.02
+    assert (db <= 0.35 * stride + 0.02 * np.abs(out["layer"][:, :4])).all()
+    assert db.mean() <= 0.5
+
+
 @pytest.mark.parametrize("cap", [2, 4], ids=["layer_plan", "c2f_plan"])
 @pytest.mark.parametrize("preset", ["v1", "v2"])
 def test_detector_fp16_out0(synth_models, preset, cap):
