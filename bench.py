@@ -346,7 +346,8 @@ def main():
                     "algorithmic_bytes_per_launch": f["bytes"] / max(f["launches"], 1),
                     "flop_per_byte": f["flops"] / f["bytes"] if f["bytes"] > 0 else None,
                     "hbm_view": {"achieved_gbs": gbs, "peak_gbs": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS},
-                    "timing": "HIP events on the library's stream around every launch of profiled (eager) passes, this process"}
+                    "timing": "HIP events attached to every launch (hipExtLaunchKernelGGL start / stop events on the library's stream) "
+                              "of profiled (eager) passes, this process"}
         # HBM bytes per launch from the PMC passes (separate rocprofv3 runs, tools/pmc_profile.sh + tools/pmc_traffic.py;
         # committed under profiles/): offline by nature, read here so that the line carries it next to `achieved`
         tfile = os.path.join(_ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic.json")

@@ -1034,7 +1034,7 @@ template <class CFG> bool try_launch(const C2fShape& s, const C2fArgs& a, hipStr
   const size_t lds = cfg_lds<CFG>();
   set_max_dynamic_lds(reinterpret_cast<const void*>(&c2f_kernel<CFG>), (int)lds);
   const int grid = a.N * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL(c2f_kernel<CFG>, dim3(grid), dim3(CFG::NW * 64), lds, st, a);
+  LP_LAUNCH(c2f_kernel<CFG>, dim3(grid), dim3(CFG::NW * 64), lds, st, a);
   return true;
 }
 struct CfgInfo { size_t lds; const char* name; bool perimg; int th, tw; };
@@ -1201,7 +1201,7 @@ void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st)
   static const char* stamp_file = getenv("LITEPI_C2F_STAMPS");
   if (stamp_file) a.stamps = stamp_buffer((size_t)N * a.tiles_x * a.tiles_y);
   set_max_dynamic_lds(reinterpret_cast<const void*>(&s2conv_kernel<CFG>), CFG::WBYTES);
-  hipLaunchKernelGGL(s2conv_kernel<CFG>, dim3(N * a.tiles_x * a.tiles_y), dim3(CFG::NW * 64), CFG::WBYTES, st, a);
+  LP_LAUNCH(s2conv_kernel<CFG>, dim3(N * a.tiles_x * a.tiles_y), dim3(CFG::NW * 64), CFG::WBYTES, st, a);
   LP_HIP(hipGetLastError());
   if (stamp_file) dump_stamps(stamp_file, name, (size_t)N * a.tiles_x * a.tiles_y, st);
 }

@@ -192,7 +192,7 @@ void launch_fused_stage(const FusedStageArgs& a, int max_items, hipStream_t st) 
 #define LP_FS(NW, SM)                                                                                          \
   {                                                                                                            \
     set_max_dynamic_lds(reinterpret_cast<const void*>(shuffle_stage_kernel<NW, SM>), 160 * 1024);                                                                                                \
-    hipLaunchKernelGGL((shuffle_stage_kernel<NW, SM>), dim3(groups), dim3(NW * 64), lds, st, a);                 \
+    LP_LAUNCH((shuffle_stage_kernel<NW, SM>), dim3(groups), dim3(NW * 64), lds, st, a);                 \
   }
   if (Tt <= 4 && S <= 2) LP_FS(4, 2) else if (Tt <= 8 && S <= 4) LP_FS(8, 4) else if (Tt <= 16 && S <= 8) LP_FS(16, 8) else
     throw Error(LP_ERR_STATE, "fused ShuffleNet stage: too many channel tiles");
@@ -343,7 +343,7 @@ void launch_fused_head(const FusedHeadArgs& a, int max_items, hipStream_t st) {
   set_max_dynamic_lds(reinterpret_cast<const void*>(cls_head_kernel), 160 * 1024);
   int groups = (max_items + FH_ROIS - 1) / FH_ROIS;
   if (groups > 512) groups = 512;
-  hipLaunchKernelGGL(cls_head_kernel, dim3(groups), dim3(1024), lds, st, a);
+  LP_LAUNCH(cls_head_kernel, dim3(groups), dim3(1024), lds, st, a);
   LP_HIP(hipGetLastError());
 }
 

@@ -66,9 +66,9 @@ void launch_cls_stem(int prec, const uint8_t* rgb, const float* w, const float* 
   LP_CHECK(CO == 24, LP_ERR_STATE, "classifier stem expects 24 output channels");
   dim3 grid(grid_for((long)max_items * (S / 2) * (S / 2)));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL((cls_stem_kernel<half_t, 24>), grid, dim3(256), 0, st, rgb, (half_t*)out.base, w, bias, S, out.pitch, m_dyn);
+    LP_LAUNCH((cls_stem_kernel<half_t, 24>), grid, dim3(256), 0, st, rgb, (half_t*)out.base, w, bias, S, out.pitch, m_dyn);
   else
-    hipLaunchKernelGGL((cls_stem_kernel<float, 24>), grid, dim3(256), 0, st, rgb, (float*)out.base, w, bias, S, out.pitch, m_dyn);
+    LP_LAUNCH((cls_stem_kernel<float, 24>), grid, dim3(256), 0, st, rgb, (float*)out.base, w, bias, S, out.pitch, m_dyn);
   LP_HIP(hipGetLastError());
 }
 
@@ -137,9 +137,9 @@ void launch_cls_stem7(int prec, const uint8_t* rgb, const float* w, const float*
   long items = (long)max_items * (S / 2);
   dim3 grid((unsigned)(items < 1 ? 1 : (items > 4096 ? 4096 : items)));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(cls_stem7_kernel<half_t>, grid, dim3(256), lds, st, rgb, (half_t*)out.base, w, bias, S, out.pitch, m_dyn);
+    LP_LAUNCH(cls_stem7_kernel<half_t>, grid, dim3(256), lds, st, rgb, (half_t*)out.base, w, bias, S, out.pitch, m_dyn);
   else
-    hipLaunchKernelGGL(cls_stem7_kernel<float>, grid, dim3(256), lds, st, rgb, (float*)out.base, w, bias, S, out.pitch, m_dyn);
+    LP_LAUNCH(cls_stem7_kernel<float>, grid, dim3(256), lds, st, rgb, (float*)out.base, w, bias, S, out.pitch, m_dyn);
   LP_HIP(hipGetLastError());
 }
 
@@ -180,10 +180,10 @@ void launch_maxpool3x3s2(int prec, const View& in, const View& out, const int* m
   const int CG = in.C / G;
   dim3 grid(grid_for((long)max_items * out.H * out.W * CG));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(maxpool3x3s2_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, in.H,
+    LP_LAUNCH(maxpool3x3s2_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, in.H,
                        in.W, CG, in.pitch, out.pitch, m_dyn);
   else
-    hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, in.H, in.W,
+    LP_LAUNCH(maxpool3x3s2_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, in.H, in.W,
                        CG, in.pitch, out.pitch, m_dyn);
   LP_HIP(hipGetLastError());
 }
@@ -233,10 +233,10 @@ void launch_dwconv3x3(int prec, const View& in, const View& out, const float* w,
   const int G = prec == LP_FP16 ? 8 : 4;
   dim3 grid(grid_for((long)max_items * out.H * out.W * (in.C / G)));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(dwconv3x3_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, w, bias,
+    LP_LAUNCH(dwconv3x3_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, w, bias,
                        in.H, in.W, out.H, out.W, in.C, stride, in.pitch, out.pitch, m_dyn);
   else
-    hipLaunchKernelGGL(dwconv3x3_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, w, bias, in.H,
+    LP_LAUNCH(dwconv3x3_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, w, bias, in.H,
                        in.W, out.H, out.W, in.C, stride, in.pitch, out.pitch, m_dyn);
   LP_HIP(hipGetLastError());
 }
@@ -271,10 +271,10 @@ void launch_spatial_mean(int prec, const View& in, const View& out, const int* m
   const int CG = in.C / G;
   dim3 grid(grid_for((long)max_items * CG));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(spatial_mean_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base,
+    LP_LAUNCH(spatial_mean_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base,
                        in.H * in.W, CG, in.pitch, out.pitch, m_dyn);
   else
-    hipLaunchKernelGGL(spatial_mean_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base,
+    LP_LAUNCH(spatial_mean_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base,
                        in.H * in.W, CG, in.pitch, out.pitch, m_dyn);
   LP_HIP(hipGetLastError());
 }
@@ -334,9 +334,9 @@ void launch_cls_stem_act(int prec, const uint8_t* rgb, const float* w, const flo
   LP_CHECK(CO % 8 == 0, LP_ERR_STATE, "classifier stem: output channels must be a multiple of 8");
   dim3 grid(grid_for((long)max_items * (S / 2) * (S / 2) * (CO / 8)));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(cls_stem_act_kernel<half_t>, grid, dim3(256), 0, st, rgb, (half_t*)out.base, w, bias, S, CO, act, out.pitch, m_dyn);
+    LP_LAUNCH(cls_stem_act_kernel<half_t>, grid, dim3(256), 0, st, rgb, (half_t*)out.base, w, bias, S, CO, act, out.pitch, m_dyn);
   else
-    hipLaunchKernelGGL(cls_stem_act_kernel<float>, grid, dim3(256), 0, st, rgb, (float*)out.base, w, bias, S, CO, act, out.pitch, m_dyn);
+    LP_LAUNCH(cls_stem_act_kernel<float>, grid, dim3(256), 0, st, rgb, (float*)out.base, w, bias, S, CO, act, out.pitch, m_dyn);
   LP_HIP(hipGetLastError());
 }
 
@@ -382,10 +382,10 @@ void launch_dwconv_act(int prec, const View& in, const View& out, const float* w
   const int G = prec == LP_FP16 ? 8 : 4;
   dim3 grid(grid_for((long)max_items * out.H * out.W * (in.C / G)));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(dwconv_act_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, w, bias, in.H, in.W,
+    LP_LAUNCH(dwconv_act_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, w, bias, in.H, in.W,
                        out.H, out.W, in.C, k, stride, act, in.pitch, out.pitch, m_dyn);
   else
-    hipLaunchKernelGGL(dwconv_act_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, w, bias, in.H, in.W, out.H,
+    LP_LAUNCH(dwconv_act_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, w, bias, in.H, in.W, out.H,
                        out.W, in.C, k, stride, act, in.pitch, out.pitch, m_dyn);
   LP_HIP(hipGetLastError());
 }
@@ -420,10 +420,10 @@ void launch_mb_eltwise(int prec, const View& x, const View* scale, float cap, co
   const int G = prec == LP_FP16 ? 8 : 4;
   dim3 grid(grid_for((long)max_items * x.H * x.W * (x.C / G)));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(mb_eltwise_kernel<half_t>, grid, dim3(256), 0, st, (half_t*)x.base, scale ? (const half_t*)scale->base : nullptr, x.H * x.W,
+    LP_LAUNCH(mb_eltwise_kernel<half_t>, grid, dim3(256), 0, st, (half_t*)x.base, scale ? (const half_t*)scale->base : nullptr, x.H * x.W,
                        x.C, x.pitch, scale ? scale->pitch : 0, cap, m_dyn);
   else
-    hipLaunchKernelGGL(mb_eltwise_kernel<float>, grid, dim3(256), 0, st, (float*)x.base, scale ? (const float*)scale->base : nullptr, x.H * x.W, x.C,
+    LP_LAUNCH(mb_eltwise_kernel<float>, grid, dim3(256), 0, st, (float*)x.base, scale ? (const float*)scale->base : nullptr, x.H * x.W, x.C,
                        x.pitch, scale ? scale->pitch : 0, cap, m_dyn);
   LP_HIP(hipGetLastError());
 }
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __rest
 void launch_softmax_argmax(const float* logits, int pitch, int nc, float* probs, int* ids, float* conf, lp_det* dets,
                            int max_det, const RoiTable* tab, const int* m_dyn, int max_items, hipStream_t st) {
   dim3 grid(grid_for((long)max_items * 64));
-  hipLaunchKernelGGL(softmax_argmax_kernel, grid, dim3(256), 0, st, logits, pitch, nc, probs, ids, conf, dets, max_det,
+  LP_LAUNCH(softmax_argmax_kernel, grid, dim3(256), 0, st, logits, pitch, nc, probs, ids, conf, dets, max_det,
                      tab ? tab->img : nullptr, tab ? tab->slot : nullptr, m_dyn);
   LP_HIP(hipGetLastError());
 }

@@ -726,7 +726,7 @@ void launch_cls_front(const ClsFrontArgs& a, int max_items, hipStream_t st) {
   set_max_dynamic_lds(reinterpret_cast<const void*>(cls_front_kernel), 160 * 1024);
   int grid = max_items < 512 ? max_items : 512;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(cls_front_kernel, dim3(grid), dim3(CN_THREADS), CF_LDS + CF_DW + CF_BI + CF_S2, st, a);
+  LP_LAUNCH(cls_front_kernel, dim3(grid), dim3(CN_THREADS), CF_LDS + CF_DW + CF_BI + CF_S2, st, a);
   LP_HIP(hipGetLastError());
 }
 
@@ -737,7 +737,7 @@ void launch_cls_back(const ClsBackArgs& a, int max_items, hipStream_t st) {
   int grid = (max_items + 3) / 4;
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(cls_back_kernel, dim3(grid), dim3(CN_THREADS), CB_LDS + CB_DW + CB_BI + CB_S2, st, a);
+  LP_LAUNCH(cls_back_kernel, dim3(grid), dim3(CN_THREADS), CB_LDS + CB_DW + CB_BI + CB_S2, st, a);
   LP_HIP(hipGetLastError());
 }
 

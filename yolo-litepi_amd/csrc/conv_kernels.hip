@@ -1843,17 +1843,17 @@ template <typename T, int NT>
 static void launch3x3(const ConvArgs& a, int stride, dim3 grid, int threads, size_t lds, hipStream_t st) {
   if (stride == 1) {
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_mfma_kernel<T, NT, 1>), 160 * 1024);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, NT, 1>), grid, dim3(threads), lds, st, a);
+    LP_LAUNCH((conv3x3_mfma_kernel<T, NT, 1>), grid, dim3(threads), lds, st, a);
   } else {
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_mfma_kernel<T, NT, 2>), 160 * 1024);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, NT, 2>), grid, dim3(threads), lds, st, a);
+    LP_LAUNCH((conv3x3_mfma_kernel<T, NT, 2>), grid, dim3(threads), lds, st, a);
   }
 }
 
 template <typename T, int NT, int U>
 static void launch_s2_u(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<T, NT, 4, 0, U>), 160 * 1024);
-  hipLaunchKernelGGL((conv3x3s2_direct_kernel<T, NT, 4, 0, U>), grid, dim3(256), lds, st, a);
+  LP_LAUNCH((conv3x3s2_direct_kernel<T, NT, 4, 0, U>), grid, dim3(256), lds, st, a);
 }
 template <typename T, int NT>
 static void launch_s2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
@@ -1864,14 +1864,14 @@ static void launch_s2(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) 
 template <typename T, int NT, int NP, int EPI>
 static void launch1x1_(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   set_max_dynamic_lds(reinterpret_cast<const void*>(conv1x1_mfma_kernel<T, NT, NP, EPI>), 160 * 1024);
-  hipLaunchKernelGGL((conv1x1_mfma_kernel<T, NT, NP, EPI>), grid, dim3(256), lds, st, a);
+  LP_LAUNCH((conv1x1_mfma_kernel<T, NT, NP, EPI>), grid, dim3(256), lds, st, a);
 }
 
 template <typename T, int NT>
 static void launch1x1(const ConvArgs& a, bool shuffle, dim3 grid, size_t lds, hipStream_t st) {
   if (a.up) {
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv1x1_mfma_kernel<T, NT, 4, EPI_PLAIN, true>), 160 * 1024);
-    hipLaunchKernelGGL((conv1x1_mfma_kernel<T, NT, 4, EPI_PLAIN, true>), grid, dim3(256), lds, st, a);
+    LP_LAUNCH((conv1x1_mfma_kernel<T, NT, 4, EPI_PLAIN, true>), grid, dim3(256), lds, st, a);
   } else if (shuffle)
     launch1x1_<T, NT, 4, EPI_SHUFFLE>(a, grid, lds, st);
   else
@@ -1912,9 +1912,9 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
     const long total = (long)a.M * Cout;
     dim3 grid((unsigned)((total + 255) / 256));
     if (f16)
-      hipLaunchKernelGGL(conv_naive_kernel<half_t>, grid, dim3(256), 0, st, a, k, stride);
+      LP_LAUNCH(conv_naive_kernel<half_t>, grid, dim3(256), 0, st, a, k, stride);
     else
-      hipLaunchKernelGGL(conv_naive_kernel<float>, grid, dim3(256), 0, st, a, k, stride);
+      LP_LAUNCH(conv_naive_kernel<float>, grid, dim3(256), 0, st, a, k, stride);
     LP_HIP(hipGetLastError());
     return;
   }
@@ -1935,7 +1935,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
 #define LP_LDT_(TT, N_, T_, U_)                                                                                              \
   {                                                                                                                          \
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_direct_kernel<TT, N_, 4, T_, U_>), 160 * 1024);                                                                                                              \
-    hipLaunchKernelGGL((conv3x3s2_direct_kernel<TT, N_, 4, T_, U_>), grid, dim3(256), lds_bytes, st, a);                      \
+    LP_LAUNCH((conv3x3s2_direct_kernel<TT, N_, 4, T_, U_>), grid, dim3(256), lds_bytes, st, a);                      \
   }
 #define LP_LDT(TT, N_, T_)                               \
   {                                                      \
@@ -1979,7 +1979,7 @@ void ConvLayer::launch(const ConvIO& io, hipStream_t st) const {
 #define LP_L3T(TT, N_, T_)                                                                                              \
   {                                                                                                                     \
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_mfma_kernel<TT, N_, 1, T_>), 160 * 1024);                                                                                                         \
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TT, N_, 1, T_>), grid, dim3(threads), lds_bytes, st, a);                      \
+    LP_LAUNCH((conv3x3_mfma_kernel<TT, N_, 1, T_>), grid, dim3(threads), lds_bytes, st, a);                      \
   }
       if (NT == 4 && T2 == 4) { if (f16) LP_L3T(half_t, 4, 4) else LP_L3T(float, 4, 4) }
       else if (NT == 2 && T2 == 1) { if (f16) LP_L3T(half_t, 2, 1) else LP_L3T(float, 2, 1) }
@@ -2140,7 +2140,7 @@ template <typename T, int NT, int P1, int P2, int T2, int SG>
 static void launch_bneck_sg(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   constexpr bool SEP = NT == 1;
   set_max_dynamic_lds(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2, SG>), 160 * 1024);
-  hipLaunchKernelGGL((bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2, SG>), grid, dim3(256), lds, st, a);
+  LP_LAUNCH((bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2, SG>), grid, dim3(256), lds, st, a);
 }
 // fp16 cv2 tails: the gathered K steps (1..3) are a template parameter (straight-line epilogue, see the kernel)
 template <typename T, int NT, int P1, int P2, int T2>
@@ -2322,7 +2322,7 @@ void StemLayer::launch_block(const uint8_t* img, int N, int Hin, int Win, const 
   a.H2 = out.H; a.W2 = out.W; a.out_pitch = out.pitch; a.C2 = c1.Cout2; a.act2 = c1.act2;
   LP_CHECK(a.H2 == (a.H1 + 1) / 2 && a.W2 == (a.W1 + 1) / 2 && out.C >= c1.Cout2, LP_ERR_STATE, "stem block: output view mismatch");
   dim3 grid(N, ceil_div(a.W2, SB_TW), ceil_div(a.H2, SB_TH));
-  hipLaunchKernelGGL(stem_block_kernel, grid, dim3(256), 0, st, a);
+  LP_LAUNCH(stem_block_kernel, grid, dim3(256), 0, st, a);
   LP_HIP(hipGetLastError());
 }
 
@@ -2332,14 +2332,14 @@ void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& 
   static const bool no_mfma_stem = getenv("LITEPI_NO_MFMA_STEM") != nullptr;
   if (aligned && d_afrag.p && !no_mfma_stem && CO == 16) {
     dim3 g3(N, ceil_div(out.W, STEMM_TW), ceil_div(out.H, STEMM_TH));
-    hipLaunchKernelGGL(stem_mfma16_kernel, g3, dim3(256), 0, st, img, reinterpret_cast<half_t*>(out.base),
+    LP_LAUNCH(stem_mfma16_kernel, g3, dim3(256), 0, st, img, reinterpret_cast<half_t*>(out.base),
                        reinterpret_cast<const u32x4*>(d_afrag.p), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch);
     LP_HIP(hipGetLastError());
     return;
   }
   if (aligned && d_afrag.p && !no_mfma_stem) {
     dim3 g3(N, ceil_div(out.W, STEMM_TW), ceil_div(out.H, STEMM_TH));
-    hipLaunchKernelGGL(stem_mfma_kernel, g3, dim3(256), 0, st, img, reinterpret_cast<half_t*>(out.base),
+    LP_LAUNCH(stem_mfma_kernel, g3, dim3(256), 0, st, img, reinterpret_cast<half_t*>(out.base),
                        reinterpret_cast<const u32x4*>(d_afrag.p), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch);
     LP_HIP(hipGetLastError());
     return;
@@ -2347,7 +2347,7 @@ void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& 
   if (aligned) {
     dim3 g2(ceil_div(out.W, STEM_TW), ceil_div(out.H, STEM_TH), N);
 #define LP_STL(TT, C)                                                                                            \
-  hipLaunchKernelGGL((stem_conv_lds_kernel<TT, C>), g2, dim3(256), 0, st, img, reinterpret_cast<TT*>(out.base), \
+  LP_LAUNCH((stem_conv_lds_kernel<TT, C>), g2, dim3(256), 0, st, img, reinterpret_cast<TT*>(out.base), \
                      d_w.as<float>(), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch, act)
     if (prec == LP_FP16) {
       if (CO == 8) LP_STL(half_t, 8); else if (CO == 16) LP_STL(half_t, 16); else LP_STL(half_t, 32);
@@ -2361,7 +2361,7 @@ void StemLayer::launch(const uint8_t* img, int N, int Hin, int Win, const View& 
   const long total = (long)N * out.H * out.W;
   dim3 grid((unsigned)((total + 255) / 256));
 #define LP_ST(TT, C)                                                                                     \
-  hipLaunchKernelGGL((stem_conv_kernel<TT, C>), grid, dim3(256), 0, st, img, reinterpret_cast<TT*>(out.base), \
+  LP_LAUNCH((stem_conv_kernel<TT, C>), grid, dim3(256), 0, st, img, reinterpret_cast<TT*>(out.base), \
                      d_w.as<float>(), d_bias.as<float>(), N, Hin, Win, out.H, out.W, out.pitch, act, k, stride, pad)
   if (prec == LP_FP16) {
     if (CO == 8) LP_ST(half_t, 8); else if (CO == 16) LP_ST(half_t, 16); else LP_ST(half_t, 32);

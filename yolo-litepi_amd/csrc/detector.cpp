@@ -18,14 +18,21 @@
 namespace lp {
 
 // ---- profiler -------------------------------------------------------------------------
+thread_local LaunchTimer* g_launch_timer = nullptr;
+
 void Profiler::begin(hipStream_t st) {
   if (!enabled) return;
   LP_HIP(hipEventCreate(&cur));
   LP_HIP(hipEventRecord(cur, st));
+  timer = LaunchTimer();
+  LP_HIP(hipEventCreate(&timer.e0));
+  LP_HIP(hipEventCreate(&timer.e1));
+  g_launch_timer = &timer;
 }
 void Profiler::end(hipStream_t st, const std::string& name, const std::string& layer, double flops, double bytes, bool per_roi) {
   if (!enabled) return;
-  Rec r{name, layer, flops, bytes, cur, nullptr, per_roi};
+  g_launch_timer = nullptr;
+  Rec r{name, layer, flops, bytes, cur, nullptr, per_roi, timer.e0, timer.e1, timer.launches};
   LP_HIP(hipEventCreate(&r.e1));
   LP_HIP(hipEventRecord(r.e1, st));
   recs.push_back(r);
@@ -38,19 +45,24 @@ void Profiler::collect(int roi_count) {
     memset(&k, 0, sizeof(k));
     snprintf(k.name, sizeof(k.name), "%s", r.name.c_str());
     snprintf(k.layer, sizeof(k.layer), "%s", r.layer.c_str());
-    float ms = 0.f;
+    float ms = 0.f, kms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+    // one launch inside the bracket: its own start -> stop events (the kernel without the dispatch around it)
+    if (r.launches == 1 && hipEventElapsedTime(&kms, r.k0, r.k1) == hipSuccess && kms > 0.f) ms = kms;
     k.ms = ms;
     k.flops = r.flops * (r.per_roi ? roi_count : 1);
     k.bytes = r.bytes * (r.per_roi ? roi_count : 1);
     results.push_back(k);
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.k0);
+    (void)hipEventDestroy(r.k1);
   }
   recs.clear();
 }
 Profiler::~Profiler() {
-  for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); (void)hipEventDestroy(r.k0); (void)hipEventDestroy(r.k1); }
+  if (g_launch_timer == &timer) g_launch_timer = nullptr;
 }
 
 // ---- tensors ---------------------------------------------------------------------------

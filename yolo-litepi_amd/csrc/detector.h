@@ -10,7 +10,10 @@
 namespace lp {
 
 struct Profiler {
-  struct Rec { std::string name, layer; double flops, bytes; hipEvent_t e0, e1; bool per_roi; };
+  // e0 / e1: events recorded around the op; k0 / k1: events attached to the op's launch itself (LP_LAUNCH); launches: kernel
+  // launches inside the bracket -- exactly one: the time reported is k0 -> k1 (the kernel), otherwise e0 -> e1 (the bracket)
+  struct Rec { std::string name, layer; double flops, bytes; hipEvent_t e0, e1; bool per_roi; hipEvent_t k0, k1; int launches; };
+  LaunchTimer timer;
   bool enabled = false;
   std::vector<Rec> recs;
   std::vector<lp_kernel_time> results;

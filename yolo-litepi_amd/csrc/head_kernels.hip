@@ -682,7 +682,7 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
 #define LP_HEAD(C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_)                                                                          \
   {                                                                                                                               \
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_>), 160 * 1024); \
-    hipLaunchKernelGGL((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_>), grid, dim3(256), lds_bytes, st, a);         \
+    LP_LAUNCH((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_>), grid, dim3(256), lds_bytes, st, a);         \
   }
   if (C3T == 1 && KPT == 2 && SLOTF == 12) LP_HEAD(1, 2, 1, 2, 2, 12, 3)
   else if (C3T == 1 && KPT == 2) LP_HEAD(1, 3, 2, 2, 6, 24, 5)

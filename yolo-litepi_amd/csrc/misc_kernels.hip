@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
 
 void launch_letterbox(const uint8_t* src, const ImgGeom* geom, uint8_t* dst, int B, int S, hipStream_t st) {
   dim3 grid(ceil_div(S * S, 256), B);
-  hipLaunchKernelGGL(letterbox_kernel, grid, dim3(256), 0, st, src, geom, dst, S);
+  LP_LAUNCH(letterbox_kernel, grid, dim3(256), 0, st, src, geom, dst, S);
   LP_HIP(hipGetLastError());
 }
 
@@ -89,10 +89,10 @@ void launch_upsample2x(int prec, const View& in, const View& out, int N, hipStre
   const long total = (long)N * out.H * out.W * CG;
   dim3 grid((unsigned)((total + 255) / 256));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(upsample2x_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, N, in.H,
+    LP_LAUNCH(upsample2x_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, N, in.H,
                        in.W, CG, in.pitch, out.pitch);
   else
-    hipLaunchKernelGGL(upsample2x_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, N, in.H,
+    LP_LAUNCH(upsample2x_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, N, in.H,
                        in.W, CG, in.pitch, out.pitch);
   LP_HIP(hipGetLastError());
 }
@@ -196,10 +196,10 @@ void launch_sppf_pool(int prec, const View& in, const View& o1, const View& o2, 
   if (in.H * in.W <= SPPF_MAX_PIX) {
     dim3 grid((unsigned)(N * CG));
     if (prec == LP_FP16)
-      hipLaunchKernelGGL(sppf_pool_lds_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)o1.base,
+      LP_LAUNCH(sppf_pool_lds_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)o1.base,
                          (half_t*)o2.base, (half_t*)o3.base, in.H, in.W, CG, in.pitch, o1.pitch, o2.pitch, o3.pitch);
     else
-      hipLaunchKernelGGL(sppf_pool_lds_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)o1.base,
+      LP_LAUNCH(sppf_pool_lds_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)o1.base,
                          (float*)o2.base, (float*)o3.base, in.H, in.W, CG, in.pitch, o1.pitch, o2.pitch, o3.pitch);
     LP_HIP(hipGetLastError());
     return;
@@ -207,10 +207,10 @@ void launch_sppf_pool(int prec, const View& in, const View& o1, const View& o2, 
   const long total = (long)N * in.H * in.W * CG;
   dim3 grid((unsigned)((total + 255) / 256));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(sppf_pool_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)o1.base,
+    LP_LAUNCH(sppf_pool_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)o1.base,
                        (half_t*)o2.base, (half_t*)o3.base, N, in.H, in.W, CG, in.pitch, o1.pitch, o2.pitch, o3.pitch);
   else
-    hipLaunchKernelGGL(sppf_pool_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)o1.base,
+    LP_LAUNCH(sppf_pool_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)o1.base,
                        (float*)o2.base, (float*)o3.base, N, in.H, in.W, CG, in.pitch, o1.pitch, o2.pitch, o3.pitch);
   LP_HIP(hipGetLastError());
 }
@@ -240,10 +240,10 @@ void launch_add(int prec, const View& a, const View& b, const View& out, int N, 
   const long npix = (long)N * a.H * a.W;
   dim3 grid((unsigned)((npix * CG + 255) / 256));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL((eltwise_kernel<half_t, true>), grid, dim3(256), 0, st, (const half_t*)a.base, (const half_t*)b.base,
+    LP_LAUNCH((eltwise_kernel<half_t, true>), grid, dim3(256), 0, st, (const half_t*)a.base, (const half_t*)b.base,
                        (half_t*)out.base, npix, CG, a.pitch, b.pitch, out.pitch);
   else
-    hipLaunchKernelGGL((eltwise_kernel<float, true>), grid, dim3(256), 0, st, (const float*)a.base, (const float*)b.base,
+    LP_LAUNCH((eltwise_kernel<float, true>), grid, dim3(256), 0, st, (const float*)a.base, (const float*)b.base,
                        (float*)out.base, npix, CG, a.pitch, b.pitch, out.pitch);
   LP_HIP(hipGetLastError());
 }
@@ -254,10 +254,10 @@ void launch_copy(int prec, const View& in, const View& out, int N, hipStream_t s
   const long npix = (long)N * in.H * in.W;
   dim3 grid((unsigned)((npix * CG + 255) / 256));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL((eltwise_kernel<half_t, false>), grid, dim3(256), 0, st, (const half_t*)in.base, (const half_t*)nullptr,
+    LP_LAUNCH((eltwise_kernel<half_t, false>), grid, dim3(256), 0, st, (const half_t*)in.base, (const half_t*)nullptr,
                        (half_t*)out.base, npix, CG, in.pitch, 0, out.pitch);
   else
-    hipLaunchKernelGGL((eltwise_kernel<float, false>), grid, dim3(256), 0, st, (const float*)in.base, (const float*)nullptr,
+    LP_LAUNCH((eltwise_kernel<float, false>), grid, dim3(256), 0, st, (const float*)in.base, (const float*)nullptr,
                        (float*)out.base, npix, CG, in.pitch, 0, out.pitch);
   LP_HIP(hipGetLastError());
 }
@@ -305,10 +305,10 @@ void launch_dwconv3x3_act(int prec, const View& in, const View& out, const float
   const long npix = (long)N * in.H * in.W;
   dim3 grid((unsigned)((npix * (in.C / G) + 255) / 256));
   if (prec == LP_FP16)
-    hipLaunchKernelGGL(dwconv3x3_act_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, w, bias, npix,
+    LP_LAUNCH(dwconv3x3_act_kernel<half_t>, grid, dim3(256), 0, st, (const half_t*)in.base, (half_t*)out.base, w, bias, npix,
                        in.H, in.W, in.C, in.pitch, out.pitch, act);
   else
-    hipLaunchKernelGGL(dwconv3x3_act_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, w, bias, npix,
+    LP_LAUNCH(dwconv3x3_act_kernel<float>, grid, dim3(256), 0, st, (const float*)in.base, (float*)out.base, w, bias, npix,
                        in.H, in.W, in.C, in.pitch, out.pitch, act);
   LP_HIP(hipGetLastError());
 }
@@ -395,11 +395,11 @@ void launch_psa_attention(int prec, const View& qkv, const View& out, const floa
   dim3 grid(N, heads, (HW + ATT_QB - 1) / ATT_QB);
   if (prec == LP_FP16) {
     set_max_dynamic_lds(reinterpret_cast<const void*>(psa_attention_kernel<half_t>), 160 * 1024);
-    hipLaunchKernelGGL(psa_attention_kernel<half_t>, grid, dim3(256), lds, st, (const half_t*)qkv.base, (half_t*)out.base, pe_w, pe_b, qkv.H,
+    LP_LAUNCH(psa_attention_kernel<half_t>, grid, dim3(256), lds, st, (const half_t*)qkv.base, (half_t*)out.base, pe_w, pe_b, qkv.H,
                        qkv.W, heads, dk, dv, scale, qkv.pitch, out.pitch);
   } else {
     set_max_dynamic_lds(reinterpret_cast<const void*>(psa_attention_kernel<float>), 160 * 1024);
-    hipLaunchKernelGGL(psa_attention_kernel<float>, grid, dim3(256), lds, st, (const float*)qkv.base, (float*)out.base, pe_w, pe_b, qkv.H,
+    LP_LAUNCH(psa_attention_kernel<float>, grid, dim3(256), lds, st, (const float*)qkv.base, (float*)out.base, pe_w, pe_b, qkv.H,
                        qkv.W, heads, dk, dv, scale, qkv.pitch, out.pitch);
   }
   LP_HIP(hipGetLastError());

@@ -89,9 +89,9 @@ void launch_decode(int prec, const DecodeArgs& a, int N, hipStream_t st) {
   dim3 grid(ceil_div(a.A * 4, 256), N);
   LP_CHECK(a.reg_max == 16 || a.reg_max == 8 || a.reg_max == 32, LP_ERR_GRAPH, "reg_max %d unsupported (8, 16, 32)", a.reg_max);
 #define LP_DEC(TT)                                                                           \
-  if (a.reg_max == 16) hipLaunchKernelGGL((decode_kernel<TT, 16>), grid, dim3(256), 0, st, a); \
-  else if (a.reg_max == 8) hipLaunchKernelGGL((decode_kernel<TT, 8>), grid, dim3(256), 0, st, a); \
-  else hipLaunchKernelGGL((decode_kernel<TT, 32>), grid, dim3(256), 0, st, a);
+  if (a.reg_max == 16) LP_LAUNCH((decode_kernel<TT, 16>), grid, dim3(256), 0, st, a); \
+  else if (a.reg_max == 8) LP_LAUNCH((decode_kernel<TT, 8>), grid, dim3(256), 0, st, a); \
+  else LP_LAUNCH((decode_kernel<TT, 32>), grid, dim3(256), 0, st, a);
   if (prec == LP_FP16) { LP_DEC(half_t) } else { LP_DEC(float) }
 #undef LP_DEC
   LP_HIP(hipGetLastError());
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void filter_out0_kernel(const float* __restric
 void launch_filter_out0(const float* out0, int nc, int A, const ImgGeom* geom, Cand* cand, int* cand_count, float conf,
                         int N, hipStream_t st) {
   dim3 grid(ceil_div(A, 256), N);
-  hipLaunchKernelGGL(filter_out0_kernel, grid, dim3(256), 0, st, out0, nc, A, geom, cand, cand_count, conf);
+  LP_LAUNCH(filter_out0_kernel, grid, dim3(256), 0, st, out0, nc, A, geom, cand, cand_count, conf);
   LP_HIP(hipGetLastError());
 }
 
@@ -406,7 +406,7 @@ void launch_nms(const NmsArgs& a, int N, hipStream_t st) {
   const size_t lds = nms_lds_bytes(a.A);
   LP_CHECK(lds <= 150 * 1024, LP_ERR_STATE, "NMS: %d anchors exceed the LDS sort capacity", a.A);
   LP_CHECK(a.A <= 16384, LP_ERR_STATE, "NMS: anchor index needs more than 14 key bits");
-  hipLaunchKernelGGL(nms_kernel, dim3(N), dim3(NMS_THREADS), lds, st, a);
+  LP_LAUNCH(nms_kernel, dim3(N), dim3(NMS_THREADS), lds, st, a);
   LP_HIP(hipGetLastError());
 }
 
@@ -701,7 +701,7 @@ void launch_roi_resize(const RoiResizeArgs& a, int max_items, hipStream_t st) {
   LP_CHECK(lds <= 128 * 1024, LP_ERR_STATE, "ROI resize LDS budget");
   int grid = max_items < 512 ? max_items : 512;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(roi_resize_kernel, dim3(grid), dim3(RR_THREADS), lds, st, a);
+  LP_LAUNCH(roi_resize_kernel, dim3(grid), dim3(RR_THREADS), lds, st, a);
   LP_HIP(hipGetLastError());
 }
 
