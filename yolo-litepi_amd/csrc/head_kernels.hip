@@ -110,18 +110,26 @@ __device__ __forceinline__ void lds_barrier() {
 //    from chunk to chunk; such chunks run stand-alone, FIRST && LAST.)
 //  * side(j), j < SLOTF / 4: the weight ring's store + reload of piece j (see the kernel).
 //  * SLOTF: fragments (KiB) per ring slot, 24 or 12; a wave owns SLOTF / 4 pieces of every chunk.
+//  * SLOTF == 8 (three workgroups per CU): a ring slot is 64 bytes short of 8 KiB -- the LDS granule is 1280 B and 42 granules
+//    per workgroup are the limit -- and lanes 60..63 of fragment 7 live in four padding slots of MID instead: f7[parity] is
+//    this lane's address of fragment 7, f7_0 / f7_1 by slot parity (only the box tower's chunks have eight fragments).
 template <int NA, int NB, int KS, bool FIRST, bool LAST, int SLOTF, typename F, typename G>
 __device__ __forceinline__ void kchunk(const char* ring, int c, int lane16, const char* img, const int (&pix)[NB], F&& next_boff, G&& side,
-                                       floatx16 (&acc)[NA][NB], half8 (&af)[2][NA], half8 (&bf)[2][NB]) {
+                                       floatx16 (&acc)[NA][NB], half8 (&af)[2][NA], half8 (&bf)[2][NB], const char* f7_0, const char* f7_1) {
   static_assert(KS % 2 == 0 || (FIRST && LAST), "an odd chunk cannot hand its register sets to the next one");
   static_assert(KS >= 2 && NA * KS <= SLOTF, "the ring pieces ride on steps 0 .. KS-2; a chunk fits one slot");
-  constexpr int SLOT = SLOTF * 1024, NPW = SLOTF / 4;
+  constexpr int SLOT = SLOTF == 8 ? 8192 - 64 : SLOTF * 1024, NPW = SLOTF / 4;
   const char* wb = ring + (c & 1) * SLOT + lane16;
   const char* wbn = ring + ((c + 1) & 1) * SLOT + lane16;
+  const char* f7b = (c & 1) ? f7_1 : f7_0;
+  const char* f7n = (c & 1) ? f7_0 : f7_1;
   auto ld = [&](int set, const char* w, int s) {
     const int boff = next_boff();
 #pragma unroll
-    for (int rt = 0; rt < NA; ++rt) af[set][rt] = lds_h8(w + (s * NA + rt) * 1024);
+    for (int rt = 0; rt < NA; ++rt) {
+      if (SLOTF == 8 && s * NA + rt == 7) af[set][rt] = lds_h8(w == wb ? f7b : f7n);
+      else af[set][rt] = lds_h8(w + (s * NA + rt) * 1024);
+    }
 #pragma unroll
     for (int p = 0; p < NB; ++p) bf[set][p] = lds_h8(img + pix[p] + boff);
   };
@@ -152,10 +160,13 @@ __device__ __forceinline__ void kchunk(const char* ring, int c, int lane16, cons
 
 // NPC: 64-slot pieces per input-tile row, KSA: K steps per stage-A chunk (both fixed by the level's tile shape, see host)
 // SLOTF: fragments per weight-ring slot (24; 12 for the two-workgroups-per-CU shape), NRW: input-tile rows per wave = ceil((TH+4)/4)
-template <int C3T, int PA, int PB, int NPC, int KSA, int SLOTF, int NRW>
-__global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(const HeadArgs a) {
+template <int C3T, int PA, int PB, int NPC, int KSA, int SLOTF, int NRW, bool OV = (SLOTF == 8)>
+__global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void head_fused_kernel(const HeadArgs a) {
+  // SLOTF == 8: THREE workgroups per CU -- MID overlays the input tile (dead after stage A's K loops: one more barrier), 8 KiB
+  // ring slots (the projections are then two chunks), <= 168 registers: 54,272 B of LDS.
   constexpr int RT = 2 + C3T;       // row tiles (32 channels) of the merged first convs: box 2 | class C3T
-  constexpr int SLOT = SLOTF * 1024, NPW = SLOTF / 4;   // ring slot bytes; 1 KiB pieces per wave and chunk
+  constexpr int SLOT = SLOTF * 1024, NPW = SLOTF / 4;   // chunk stride in the weight stream; 1 KiB pieces per wave and chunk
+  constexpr int SLOTB = SLOTF == 8 ? 8192 - 64 : SLOT;   // ring slot stride in LDS (see kchunk)
   constexpr int SPM = 4 * RT + 1;   // 16-byte slots per MID pixel, one of them padding (odd: conflict-free pixel stride)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -168,9 +179,15 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
   const int RWin = TW + 4, IHin = TH + 4, SPin = 2 * KPT + 1, RSin = RWin * SPin;
   const int RW1 = TW + 2, R1 = (TH + 2) * RW1, R2 = TH * TW;
   const int nA = (R1 + 31) >> 5, nB = (R2 + 31) >> 5;
+  constexpr bool OVL = OV;   // MID overlays the input tile
   char* IN = smem;
-  char* MID = smem + ((IHin * RSin * 16 + 1023) & ~1023);
-  char* RING = MID + ((R1 * SPM * 16 + 1023) & ~1023);
+  const int in_al = (IHin * RSin * 16 + 1023) & ~1023, mid_al = (R1 * SPM * 16 + 1023) & ~1023;
+  char* MID = OVL ? smem : smem + in_al;
+  char* RING = OVL ? smem + (IHin * RSin > R1 * SPM ? IHin * RSin : R1 * SPM) * 16 : MID + mid_al;
+  // fragment 7 of ring slot `par`, this lane: inside the slot, or (SLOTF == 8, lanes 60..63) the padding slot of MID pixel
+  // 172 + 4 par + lane - 60 -- beyond the input tile, never written by the MID stores
+  const char* f7_0 = (SLOTF == 8 && lane >= 60) ? MID + ((R1 - 8 + lane - 60) * SPM + 4 * RT) * 16 : RING + 7 * 1024 + lane * 16;
+  const char* f7_1 = (SLOTF == 8 && lane >= 60) ? MID + ((R1 - 4 + lane - 60) * SPM + 4 * RT) * 16 : RING + SLOTB + 7 * 1024 + lane * 16;
   const char* wstream = reinterpret_cast<const char*>(a.wstream) + lane * 16;
   const int nch = a.nchunks;
   HD_STAMP(0)
@@ -191,7 +208,9 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
   auto wsource = [&](int c) { wsrc = wstream + (size_t)c * SLOT + wave * 1024; };
   auto wload1 = [&](int j) { wreg[j] = *reinterpret_cast<const u32x4*>(wsrc + j * 4096); };
   auto wstore1 = [&](int c, int j) {
-    *reinterpret_cast<u32x4*>(RING + (c & 1) * SLOT + lane * 16 + (wave + 4 * j) * 1024) = wreg[j];
+    char* dst = RING + (c & 1) * SLOTB + lane * 16 + (wave + 4 * j) * 1024;
+    if (SLOTF == 8 && j == 1 && wave == 3) dst = const_cast<char*>((c & 1) ? f7_1 : f7_0);   // piece 7
+    *reinterpret_cast<u32x4*>(dst) = wreg[j];
   };
   // ---- input tile (halo 2) -> IN through registers: rows of RSin 16-byte slots = (pixel, channel group); pad slots, pixels
   //      outside the image and the row's tail are zeros (= the conv's zero padding).  A wave takes rows wave, wave + 4, ..;
@@ -239,7 +258,11 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
       }
     }
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) *reinterpret_cast<u32x4*>(RING + lane * 16 + (wave + 4 * j) * 1024) = w0[j];
+    for (int j = 0; j < NPW; ++j) {
+      char* dst = RING + lane * 16 + (wave + 4 * j) * 1024;
+      if (SLOTF == 8 && j == 1 && wave == 3) dst = const_cast<char*>(f7_0);
+      *reinterpret_cast<u32x4*>(dst) = w0[j];
+    }
   }
   HD_STAMP(2)
 
@@ -252,28 +275,6 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
     const int ry = idx / RW1, rx = idx - ry * RW1;
     pixA[p] = (ry * RWin + rx) * SPin * 16 + h * 16;
   }
-  int pixB[PB];
-  float anc_x[PB], anc_y[PB], anc_s[PB];   // requested now, used by the decode at the very end
-  int anchor_i[PB];
-  bool pvalid[PB];
-#pragma unroll
-  for (int p = 0; p < PB; ++p) {
-    const int pt = wave + 4 * p;
-    const int idx0 = 32 * pt + r;
-    const int idx = idx0 < R2 ? idx0 : R2 - 1;
-    const int ty = idx / TW, tx = idx - ty * TW;
-    pixB[p] = (ty * RW1 + tx) * SPM * 16 + h * 16;
-    const int gy = oy0 + ty, gx = ox0 + tx;
-    pvalid[p] = pt < nB && idx0 < R2 && gy < a.H && gx < a.W;
-    anchor_i[p] = a.anchor_off + (pvalid[p] ? gy * a.W + gx : 0);
-    anc_x[p] = a.anchors[anchor_i[p]];
-    anc_y[p] = a.anchors[a.A + anchor_i[p]];
-    anc_s[p] = a.strides[anchor_i[p]];
-  }
-  const ImgGeom gm = a.geom[n];
-  float dflw[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) dflw[i] = a.dfl_w[i];
   const int lane16 = lane * 16;
   int c = 0;
   auto ring_side = [&](int j) {
@@ -304,23 +305,23 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
       return boff;
     };
     // stream = A chunks | box-B chunks | class-B chunks | 1 C
-    const int ncA = nch - (36 / (SLOTF / 2)) - (C3T == 2 ? 36 / (SLOTF / 2) : 18 / (SLOTF >= 18 ? 18 : 6)) - 1;
+    const int ncA = nch - (36 / (SLOTF / 2)) - (C3T == 2 ? 36 / (SLOTF / 2) : 18 / (SLOTF >= 18 ? 18 : 6)) - (SLOTF == 8 ? 2 : 1);
     half8 af[2][RT], bf[2][PA];
     if constexpr (KSA % 2 == 0) {   // one operand pipeline over all of stage A (ncA >= 2, host-checked)
       wsource(c + 2);
-      kchunk<RT, PA, KSA, true, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+      kchunk<RT, PA, KSA, true, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
       HD_STAMP(3)
       for (++c; c < ncA - 1; ++c) {
         wsource(c + 2);
-        kchunk<RT, PA, KSA, false, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+        kchunk<RT, PA, KSA, false, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
       }
       wsource(c + 2);
-      kchunk<RT, PA, KSA, false, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+      kchunk<RT, PA, KSA, false, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
       ++c;
     } else {
       for (; c < ncA; ++c) {
         wsource(c + 2);
-        kchunk<RT, PA, KSA, true, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+        kchunk<RT, PA, KSA, true, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
         if (c == 0) { HD_STAMP(3) }
       }
     }
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
   // ---- SiLU, fp16, -> MID (zero outside the image: stage B's padding).  The weight rows are permuted at pack time
   //      so that this lane holds channels 32*rt + 16*h .. +15 of its pixel: two 16-byte stores per row tile.
   {
+    if (OVL) lds_barrier();   // MID overlays the input tile: every wave has read its last stage-A operands
     const bool interior = oy0 >= 1 && ox0 >= 1 && oy0 + TH + 1 <= a.H && ox0 + TW + 1 <= a.W;  // block-uniform
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
@@ -357,6 +359,32 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
   }
   HD_STAMP(5)
 
+  // ---- this lane's stage-B pixels; what only the decode needs (anchors, geometry, DFL weights) is requested here, behind
+  //      stage A -- live across it these 30 registers were the difference to the three-workgroup shape's 168 -- and arrives
+  //      during stage B
+  int pixB[PB];
+  float anc_x[PB], anc_y[PB], anc_s[PB];
+  int anchor_i[PB];
+  bool pvalid[PB];
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int pt = wave + 4 * p;
+    const int idx0 = 32 * pt + r;
+    const int idx = idx0 < R2 ? idx0 : R2 - 1;
+    const int ty = idx / TW, tx = idx - ty * TW;
+    pixB[p] = (ty * RW1 + tx) * SPM * 16 + h * 16;
+    const int gy = oy0 + ty, gx = ox0 + tx;
+    pvalid[p] = pt < nB && idx0 < R2 && gy < a.H && gx < a.W;
+    anchor_i[p] = a.anchor_off + (pvalid[p] ? gy * a.W + gx : 0);
+    anc_x[p] = a.anchors[anchor_i[p]];
+    anc_y[p] = a.anchors[a.A + anchor_i[p]];
+    anc_s[p] = a.strides[anchor_i[p]];
+  }
+  const ImgGeom gm = a.geom[n];
+  float dflw[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dflw[i] = a.dfl_w[i];
+
   // ======================= stage B, box tower: 64 x (9 * 64) x tile pixels =======================
   floatx16 accB[2][PB];
 #pragma unroll
@@ -382,7 +410,7 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
     static_for<0, NCB>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       wsource(c + 2);
-      kchunk<2, PB, KSB, i == 0, i == NCB - 1, SLOTF>(RING, c, lane16, MID, pixB, next_boff, ring_side, accB, af, bf);
+      kchunk<2, PB, KSB, i == 0, i == NCB - 1, SLOTF>(RING, c, lane16, MID, pixB, next_boff, ring_side, accB, af, bf, f7_0, f7_1);
       ++c;
     });
   }
@@ -409,14 +437,29 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
     static_for<0, NCC>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       wsource(c + 2);
-      kchunk<C3T, PB, KSC, i == 0, i == NCC - 1, SLOTF>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf);
+      kchunk<C3T, PB, KSC, i == 0, i == NCC - 1, SLOTF>(RING, c, lane16, MID, pixB, next_boff, ring_side, accC, af, bf, f7_0, f7_1);
       ++c;
     });
   }
   // ======================= stage C: the 1x1 projections from the accumulators, then decode =======================
   HD_STAMP(7)
   half8 wcb[2][4], wcc[2 * C3T];
-  {
+  if constexpr (SLOTF == 8) {
+    // two projection chunks: the class projection (chunk c, stored behind the class tower's steps), then the box projection
+    // (chunk c + 1: its pieces are in wreg; the slot it goes to held the class tower's last chunk, which every wave has left)
+    lds_barrier();
+    const char* wc = RING + (c & 1) * SLOTB + lane16;
+#pragma unroll
+    for (int q = 0; q < 2 * C3T; ++q) wcc[q] = lds_h8(wc + q * 1024);
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) wstore1(c + 1, j);
+    lds_barrier();
+    const char* wb = RING + ((c + 1) & 1) * SLOTB + lane16;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wcb[rt][q] = lds_h8(rt * 4 + q == 7 ? (((c + 1) & 1) ? f7_1 : f7_0) : wb + (rt * 4 + q) * 1024);
+  } else {
     lds_barrier();   // the projection chunk was stored behind the class tower's steps
     const char* wb = RING + (c & 1) * SLOT + lane16;
 #pragma unroll
@@ -518,9 +561,14 @@ __global__ __launch_bounds__(256, (SLOTF == 12 ? 2 : 1)) void head_fused_kernel(
 // half h then holds channels 16*h .. 16*h+15 in its 16 registers
 static inline int row_channel(int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); }
 
-static size_t head_lds(int th, int tw, int kpt, int c3t, int slotf) {
+static size_t head_lds(int th, int tw, int kpt, int c3t, int slotf, int ovl) {
   const size_t in = ((size_t)(th + 4) * (tw + 4) * (2 * kpt + 1) * 16 + 1023) & ~(size_t)1023;
   const size_t mid = ((size_t)(th + 2) * (tw + 2) * (4 * (2 + c3t) + 1) * 16 + 1023) & ~(size_t)1023;
+  if (slotf == 8) {   // MID overlays the input tile; slots 64 B short of 8 KiB (kchunk): 53,696 B = 42 LDS granules of 1280 B
+    const size_t in_b = (size_t)(th + 4) * (tw + 4) * (2 * kpt + 1) * 16, mid_b = (size_t)(th + 2) * (tw + 2) * (4 * (2 + c3t) + 1) * 16;
+    return (in_b > mid_b ? in_b : mid_b) + 2 * (size_t)(8192 - 64);
+  }
+  if (ovl) return (in > mid ? in : mid) + 2 * (size_t)slotf * 1024;
   return in + mid + 2 * (size_t)slotf * 1024;
 }
 
@@ -528,24 +576,30 @@ static size_t head_lds(int th, int tw, int kpt, int c3t, int slotf) {
 // A / B (ceil((TH+2)(TW+2)/32) <= 4*PA, ceil(TH*TW/32) <= 4*PB), 64-slot pieces per input-tile row, K steps per stage-A chunk
 // (a divisor of 9*KPT with (2+C3T)*KSA <= 24 fragments).  Chosen for LDS (input tile + first-conv image + 48 KiB ring <= 160
 // KiB) and for whole tiles on the 80 / 40 / 20 maps of a 640 input; other map sizes run the same shapes with masked edges.
-// slotf: fragments per weight-ring slot.  The first v1 P3 entry is the TWO-WORKGROUPS-PER-CU shape: an 8 x 16 tile, 12-fragment
-// slots and one pixel tile per wave in stage B make the kernel fit 80 KiB of LDS and 256 registers, so that two workgroups share
-// a CU and the VALU phases (SiLU epilogues, decode: two thirds of a tile's cycles, transcendental-bound) of one overlap the MFMA
-// phases of the other -- with one workgroup per CU the matrix pipe idles through them.  LITEPI_HEAD_1WG=1: the 16 x 16 shape.
-struct HeadCfg { int c3t, kpt, th, tw, pa, pb, npc, ksa, slotf; };
+// slotf: fragments per weight-ring slot.  The v1 P3 entries with an 8 x 16 tile and one pixel tile per wave in stage B share a
+// CU: the VALU phases (SiLU epilogues, decode: transcendental-bound) and the prologue of one workgroup run under the MFMA phases
+// of the others -- with one workgroup per CU the matrix pipe idles through them.  slotf 12: two per CU (80 KiB, <= 256
+// registers; round 2).  slotf 8: THREE per CU (round 3: 98 us per launch against 112): MID overlays the input tile, 8-fragment
+// slots 64 bytes short of 8 KiB (the LDS granule is 1280 B: 42 granules = 53,760 B per workgroup is the limit, measured with
+// tools/ubench/lds_occupancy.hip; MID + two whole slots would be 53,824), the projections as two chunks, and 168 registers --
+// reached by requesting what only the decode needs (anchors, geometry, DFL weights) after stage A instead of before it.
+struct HeadCfg { int c3t, kpt, th, tw, pa, pb, npc, ksa, slotf, ovl; };
 static const HeadCfg kHeadCfg[] = {
-    {1, 2, 8, 16, 2, 1, 2, 2, 12},    // v1 P3: Cin 32, two workgroups per CU
-    {1, 2, 16, 16, 3, 2, 2, 6, 24},   // v1 P3: Cin 32
-    {1, 4, 10, 20, 3, 2, 4, 6, 24},   // v1 P4: Cin 64
-    {1, 8, 10, 10, 2, 1, 4, 8, 24},   // v1 P5: Cin 128
-    {2, 3, 10, 20, 3, 2, 3, 3, 24},   // v2 P3: Cin 48
-    {2, 6, 10, 10, 2, 1, 3, 6, 24},   // v2 P4: Cin 96
-    {2, 12, 8, 8, 1, 1, 5, 6, 24},    // v2 P5: Cin 192
+    {1, 2, 8, 16, 2, 1, 2, 2, 8, 1},     // v1 P3: Cin 32, THREE workgroups per CU
+    {1, 2, 8, 16, 2, 1, 2, 2, 12, 0},    // v1 P3: Cin 32, two workgroups per CU (LITEPI_HEAD_2WG=1)
+    {1, 2, 16, 16, 3, 2, 2, 6, 24, 0},   // v1 P3: Cin 32
+    {1, 4, 10, 20, 3, 2, 4, 4, 12, 1},   // v1 P4: Cin 64, TWO workgroups per CU (MID over the input tile: 79.5 KB)
+    {1, 4, 10, 20, 3, 2, 4, 6, 24, 0},   // v1 P4: Cin 64 (LITEPI_HEAD_2WG=1 / LITEPI_HEAD_1WG=1)
+    {1, 8, 10, 10, 2, 1, 4, 8, 24, 0},   // v1 P5: Cin 128 (256 workgroups: the overlay shape at 76 KB changed nothing end to end)
+    {2, 3, 10, 20, 3, 2, 3, 3, 24, 0},   // v2 P3: Cin 48
+    {2, 6, 10, 10, 2, 1, 3, 6, 24, 0},   // v2 P4: Cin 96
+    {2, 12, 8, 8, 1, 1, 5, 6, 24, 0},    // v2 P5: Cin 192
 };
 static const HeadCfg* find_cfg(int c3t, int kpt) {
-  static const bool one_wg = getenv("LITEPI_HEAD_1WG") != nullptr;
+  static const bool one_wg = getenv("LITEPI_HEAD_1WG") != nullptr;   // A/B switches: the 16 x 16 one-workgroup shape,
+  static const bool two_wg = getenv("LITEPI_HEAD_2WG") != nullptr;   // the two-workgroup shape of round 2
   for (auto& c : kHeadCfg)
-    if (c.c3t == c3t && c.kpt == kpt && !(one_wg && c.slotf == 12)) return &c;
+    if (c.c3t == c3t && c.kpt == kpt && !(one_wg && c.slotf <= 12) && !(c.ovl && two_wg)) return &c;
   return nullptr;
 }
 
@@ -562,14 +616,16 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   KPT = Cin / 16;
   const HeadCfg* cfg = find_cfg(C3T, KPT);
   LP_CHECK(cfg, LP_ERR_STATE, "Detect head %s: no kernel configuration for Cin %d", name.c_str(), Cin);
-  TH = cfg->th; TW = cfg->tw; PA = cfg->pa; PB = cfg->pb; NPC = cfg->npc; KSA = cfg->ksa; SLOTF = cfg->slotf;
-  lds_bytes = head_lds(TH, TW, KPT, C3T, SLOTF);
+  TH = cfg->th; TW = cfg->tw; PA = cfg->pa; PB = cfg->pb; NPC = cfg->npc; KSA = cfg->ksa; SLOTF = cfg->slotf; OVL = cfg->ovl;
+  lds_bytes = head_lds(TH, TW, KPT, C3T, SLOTF, OVL);
   const int RT = 2 + C3T, CM = 32 * C3T;
   // chunks hold at most 24 fragments (one ring slot): stage A KSA K steps x RT row tiles, stage B box 12 x 2, class 18 x 1
   // (12 x 2 for two class row tiles), projections 10 (12)
   LP_CHECK(KSA % 2 != 0 || 9 * KPT / KSA >= 2, LP_ERR_STATE, "Detect head %s: stage A needs two chunks", name.c_str());
-  LP_CHECK(lds_bytes <= (SLOTF == 12 ? 80 : 160) * 1024 && ((TW + 4) * (2 * KPT + 1) + 63) / 64 == NPC && (9 * KPT) % KSA == 0 && RT * KSA <= SLOTF &&
-               TH + 4 <= (SLOTF == 12 ? 12 : 20) && (SLOTF == 12 || SLOTF == 24) && 8 + 2 * C3T <= SLOTF &&
+  LP_CHECK(lds_bytes <= (SLOTF == 8 ? 53760u : (SLOTF == 12 ? 80u * 1024 : 160u * 1024)) && ((TW + 4) * (2 * KPT + 1) + 63) / 64 == NPC &&
+               (9 * KPT) % KSA == 0 && RT * KSA <= SLOTF && TH + 4 <= (SLOTF <= 12 && !(OVL && SLOTF == 12) ? 12 : (OVL ? 16 : 20)) &&
+               (SLOTF == 8 || SLOTF == 12 || SLOTF == 24) &&
+               (SLOTF == 8 ? C3T == 1 : 8 + 2 * C3T <= SLOTF) &&
                (TH + 2) * (TW + 2) <= 128 * PA && TH * TW <= 128 * PB, LP_ERR_STATE, "Detect head %s: inconsistent configuration", name.c_str());
   (void)batch_hint;
   std::vector<uint16_t> stream;
@@ -625,21 +681,29 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
     }
   }
   // ---- stage C: K step (mt, s): element e of lane half hh = mid channel 32*mt + 16*hh + 8*s + (e & 7), hh = e >> 3
-  begin_chunk();
-  for (int rt = 0; rt < 2; ++rt)
-    for (int q = 0; q < 4; ++q)
+  auto box_proj = [&]() {
+    for (int rt = 0; rt < 2; ++rt)
+      for (int q = 0; q < 4; ++q)
+        frag([&](int rho, int e) {
+          const int mt = q >> 1, sq = q & 1;
+          const int ci = 32 * mt + 16 * (e >> 3) + 8 * sq + (e & 7);
+          return (*s.wpb)[(size_t)(rt * 32 + row_channel(rho)) * 64 + ci];
+        });
+  };
+  auto cls_proj = [&]() {
+    for (int q = 0; q < 2 * C3T; ++q)
       frag([&](int rho, int e) {
         const int mt = q >> 1, sq = q & 1;
-        const int ci = 32 * mt + 16 * (e >> 3) + 8 * sq + (e & 7);
-        return (*s.wpb)[(size_t)(rt * 32 + row_channel(rho)) * 64 + ci];
+        const int ci = 32 * mt + 16 * (e >> 3) + 8 * sq + (e & 7), co = row_channel(rho);
+        return (co < nc && ci < c3) ? (*s.wpc)[(size_t)co * c3 + ci] : 0.f;
       });
-  for (int q = 0; q < 2 * C3T; ++q)
-    frag([&](int rho, int e) {
-      const int mt = q >> 1, sq = q & 1;
-      const int ci = 32 * mt + 16 * (e >> 3) + 8 * sq + (e & 7), co = row_channel(rho);
-      return (co < nc && ci < c3) ? (*s.wpc)[(size_t)co * c3 + ci] : 0.f;
-    });
-  end_chunk(0);
+  };
+  if (SLOTF == 8) {   // 8-fragment slots: the class projection (needed first) and the box projection are two chunks
+    begin_chunk(); cls_proj(); end_chunk(0);
+    begin_chunk(); box_proj(); end_chunk(0);
+  } else {
+    begin_chunk(); box_proj(); cls_proj(); end_chunk(0);
+  }
   nchunks = (int)coff.size();
   LP_CHECK(nchunks <= 64 && stream.size() / 512 < 65536, LP_ERR_STATE, "Detect head: weight stream too long (%d chunks)", nchunks);
   stream.resize(stream.size() + (size_t)2 * SLOTF * 512, 0);   // the ring requests two chunks past the end
@@ -684,8 +748,15 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_>), 160 * 1024); \
     LP_LAUNCH((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_>), grid, dim3(256), lds_bytes, st, a);         \
   }
-  if (C3T == 1 && KPT == 2 && SLOTF == 12) LP_HEAD(1, 2, 1, 2, 2, 12, 3)
+#define LP_HEAD2(C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_)                                                                          \
+  {                                                                                                                                    \
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_>), 160 * 1024); \
+    LP_LAUNCH((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_>), grid, dim3(256), lds_bytes, st, a);                 \
+  }
+  if (C3T == 1 && KPT == 2 && SLOTF == 8) LP_HEAD(1, 2, 1, 2, 2, 8, 3)
+  else if (C3T == 1 && KPT == 2 && SLOTF == 12) LP_HEAD(1, 2, 1, 2, 2, 12, 3)
   else if (C3T == 1 && KPT == 2) LP_HEAD(1, 3, 2, 2, 6, 24, 5)
+  else if (C3T == 1 && KPT == 4 && SLOTF == 12) LP_HEAD2(1, 3, 2, 4, 4, 12, 4, true)
   else if (C3T == 1 && KPT == 4) LP_HEAD(1, 3, 2, 4, 6, 24, 5)
   else if (C3T == 1 && KPT == 8) LP_HEAD(1, 2, 1, 4, 8, 24, 5)
   else if (C3T == 2 && KPT == 3) LP_HEAD(2, 3, 2, 3, 3, 24, 5)
@@ -693,6 +764,7 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
   else if (C3T == 2 && KPT == 12) LP_HEAD(2, 1, 1, 5, 6, 24, 5)
   else throw Error(LP_ERR_STATE, "Detect head: no kernel configuration");
 #undef LP_HEAD
+#undef LP_HEAD2
   LP_HIP(hipGetLastError());
   if (a.stamps) {  // diagnostic: dump [grid][16] stamps, one record per launch
     LP_HIP(hipStreamSynchronize(st));
