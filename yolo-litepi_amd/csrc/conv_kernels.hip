@@ -1468,9 +1468,10 @@ __global__ __launch_bounds__(256) void stem_mfma16_kernel(const uint8_t* __restr
 #define SB_TW 32
 #define SB_SH (2 * SB_TH + 1)       /* stem rows  */
 #define SB_SW (2 * SB_TW + 1)       /* stem cols  */
-#define SB_LW 66                    /* stem tile row pitch, pixels (16 B each) */
+#define SB_LW 65                    /* stem tile row pitch, pixels (16 B each) */
 #define SB_IR (2 * SB_SH + 1)       /* input rows */
-#define SB_ROWW 104                 /* dwords per staged input row: 3 + 131*3 bytes + the lanes' 3rd dword */
+#define SB_ROWW 102                 /* dwords per staged input row: 3 + 131*3 bytes + the lanes' 3rd dword (<= 101); with SB_LW 65 the
+                                       kernel's 31,968 B of LDS are 25 granules of 1280 B: FIVE workgroups per CU (32,512 B: four) */
 #define SB_PAIRS ((SB_SW + 1) / 2)  /* pixel pairs per stem row */
 __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) {
   __shared__ uint32_t in_tile[SB_IR * SB_ROWW];
