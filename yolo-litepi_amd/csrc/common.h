@@ -45,9 +45,15 @@ struct LaunchTimer {
   int launches = 0;                        // launches seen inside the bracket
 };
 extern thread_local LaunchTimer* g_launch_timer;
+bool print_launches();
 #define LP_LAUNCH(kernel, grid, block, lds, st, ...)                                                       \
   do {                                                                                                     \
     lp::LaunchTimer* lt_ = lp::g_launch_timer;                                                             \
+    if (lt_ && lp::print_launches()) {  /* LITEPI_PRINT_LAUNCH=1: grid / block / LDS of every profiled launch */ \
+      const dim3 g_ = (grid), b_ = (block);                                                                \
+      fprintf(stderr, "[launch] %-60.60s grid %5u block %4u lds %6zu B = %3zu granules of 1280\n", #kernel, g_.x * g_.y * g_.z, b_.x,     \
+              (size_t)(lds), ((size_t)(lds) + 1279) / 1280);                                               \
+    }                                                                                                      \
     if (lt_ && lt_->launches++ == 0 && lt_->e0)                                                            \
       hipExtLaunchKernelGGL(kernel, grid, block, lds, st, lt_->e0, lt_->e1, 0, __VA_ARGS__);              \
     else                                                                                                   \

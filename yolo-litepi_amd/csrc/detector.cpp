@@ -19,6 +19,10 @@ namespace lp {
 
 // ---- profiler -------------------------------------------------------------------------
 thread_local LaunchTimer* g_launch_timer = nullptr;
+bool print_launches() {
+  static const bool on = getenv("LITEPI_PRINT_LAUNCH") != nullptr;
+  return on;
+}
 
 void Profiler::begin(hipStream_t st) {
   if (!enabled) return;
