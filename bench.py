@@ -53,7 +53,7 @@ PEAK_HBM_GBS = 8000.0
 CONF, IOU, MIN_AREA = 0.25, 0.45, 50
 NUM_CLASSES = 91            # TT100K classifier head
 TARGET_CANDIDATES = 8       # anchors per image above conf after calibration
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def parse_args():
@@ -61,7 +61,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="BASELINE.json configuration: 2 = 640x640 batch 64 (the metric's configuration; configs[3] at N > 1), "
+                         "4 = TT100K-shape 2048x2048 frames, letterboxed to 640 ON THE DEVICE inside the timed step, batch 32 per GPU "
+                         "(256 over 8 GPUs)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 64; 32 for --config 4)")
     ap.add_argument("--preset", default="v1", choices=["v1", "v2"])
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--max-det", type=int, default=300)
@@ -143,6 +147,12 @@ def cpu_baseline(param, binf, cls_state, imgs_np, n_images):
 def main():
     args = parse_args()
     run_conf = CONF if args.conf is None else args.conf   # (the calibration always targets CONF)
+    SRC = 2048 if args.config == 4 else 640               # side of the input frames (uint8 BGR, resident in HBM)
+    if args.batch is None:
+        args.batch = 32 if args.config == 4 else 64
+    if args.config == 4:
+        args.nbatches = min(args.nbatches, 2)             # 2 x 32 x 12.6 MB of frames per rank
+        args.cpu_images = min(args.cpu_images, 24)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -162,8 +172,12 @@ def main():
     from litepi.distributed import Gatherer, alloc_result_buffers
 
     B, NB, K = args.batch, max(1, args.nbatches), args.steps
-    rng = np.random.default_rng(1 + rank)
-    imgs_np = rng.integers(0, 256, (NB, B, 640, 640, 3), dtype=np.uint8)
+    if args.config == 4:
+        from litepi.synth import config4_images
+        imgs_np = config4_images(NB * B, seed=2 + rank).reshape(NB, B, SRC, SRC, 3)
+    else:
+        rng = np.random.default_rng(1 + rank)
+        imgs_np = rng.integers(0, 256, (NB, B, 640, 640, 3), dtype=np.uint8)
     imgs = torch.from_numpy(imgs_np).to(dev)
 
     def engine_factory():
@@ -172,7 +186,11 @@ def main():
 
     workdir = tempfile.mkdtemp(prefix=f"litepi_bench_r{rank}_")
     # every rank calibrates on rank 0's images so that all replicas are identical
-    cal_imgs = np.random.default_rng(1).integers(0, 256, (8, 640, 640, 3), dtype=np.uint8)
+    if args.config == 4:
+        from litepi.synth import config4_images
+        cal_imgs = config4_images(8, seed=2)
+    else:
+        cal_imgs = np.random.default_rng(1).integers(0, 256, (8, 640, 640, 3), dtype=np.uint8)
     param, binf, cls_state, spec = build_models(args, workdir, engine_factory, cal_imgs)
 
     # args.inflight pipeline handles, each with its own (non-default torch) stream and buffers:
@@ -198,7 +216,7 @@ def main():
         i, j = k % NH, k % NB
         d, c = outs[i]
         with torch.cuda.stream(streams[i]):
-            engs[i].run_batch_device(imgs[j].data_ptr(), B, 640, 640, run_conf, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
+            engs[i].run_batch_device(imgs[j].data_ptr(), B, SRC, SRC, run_conf, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
             if use_gather:
                 return gatherers[i].gather(outs[i])
         return d, c.view(1, -1)
@@ -249,7 +267,7 @@ def main():
     if not args.no_h2d:
         host = [torch.from_numpy(imgs_np[j]).pin_memory() for j in range(NB)]
         NS = 2 * NH
-        stage = [torch.empty((B, 640, 640, 3), dtype=torch.uint8, device=dev) for _ in range(NS)]
+        stage = [torch.empty((B, SRC, SRC, 3), dtype=torch.uint8, device=dev) for _ in range(NS)]
         host_out = [torch.empty_like(outs[i].payload, device="cpu").pin_memory() for i in range(NH)]
         copy_stream = torch.cuda.Stream(device=dev)
         copied = [torch.cuda.Event() for _ in range(NS)]
@@ -268,7 +286,7 @@ def main():
                 copied[sidx].record(copy_stream)
             with torch.cuda.stream(streams[i]):
                 streams[i].wait_event(copied[sidx])
-                engs[i].run_batch_device(stage[sidx].data_ptr(), B, 640, 640, run_conf, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
+                engs[i].run_batch_device(stage[sidx].data_ptr(), B, SRC, SRC, run_conf, IOU, MIN_AREA, d.data_ptr(), c.data_ptr())
                 freed[sidx].record(streams[i])
                 if use_gather:
                     r = gatherers[i].gather(outs[i])
@@ -278,10 +296,10 @@ def main():
         for _ in range(2 * lcm_h + args.warmup):
             hstep()
         hel, _ = timed(hstep, K)
-        nbytes = B * 640 * 640 * 3
+        nbytes = B * SRC * SRC * 3
         h2d = {"value": world * B * K / hel, "unit": "images/sec", "ms_per_step": hel / K * 1e3,
                "upload_gbs": nbytes * K / hel / 1e9,
-               "note": "host to host: the batch starts in pinned host memory (hipMemcpyAsync of 78.6 MB per step on a dedicated "
+               "note": f"host to host: the batch starts in pinned host memory (hipMemcpyAsync of {nbytes / 1e6:.1f} MB per step on a dedicated "
                        "copy stream into double-buffered staging, overlapping the kernels of the steps in flight), the same "
                        "pipeline, then the records + counts (0.61 MB) back into pinned host memory by an async D2H"}
 
@@ -323,7 +341,7 @@ def main():
         launches = []
         for _ in range(args.profile_steps):
             eng.profile_next(True)
-            eng.run_batch_device(imgs[0].data_ptr(), B, 640, 640, run_conf, IOU, MIN_AREA, dets.data_ptr(), counts.data_ptr())
+            eng.run_batch_device(imgs[0].data_ptr(), B, SRC, SRC, run_conf, IOU, MIN_AREA, dets.data_ptr(), counts.data_ptr())
             torch.cuda.synchronize()
             launches.append(eng.profile_read())
         for run in launches:
@@ -386,6 +404,29 @@ def main():
             "family": domf, "ms": fam_ms[domf], "achieved": fam_fl[domf] / (fam_ms[domf] * 1e-3) / 1e12, "unit": "TFLOP/s",
             "frac": fam_fl[domf] / (fam_ms[domf] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS,
             "hbm_view_gbs": fam_by[domf] / (fam_ms[domf] * 1e-3) / 1e9}
+        if args.config == 4 and "letterbox_u8" in families:
+            # configs[4]: the letterbox (cv2.resize INTER_LINEAR + 114 border, e2e.py:66-86) is a byte mover -> HBM roof.
+            # Algorithmic bytes per image: the 2048 x 2048 x 3 source read once + the 640 x 640 x 3 letterboxed image written once.
+            lb = families["letterbox_u8"]
+            lb_bytes = float(B) * (SRC * SRC * 3 + 640 * 640 * 3)
+            lb_gbs = lb_bytes / (lb["ms"] * 1e-3) / 1e9
+            conv_view = {k: roofline[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
+            conv_view["bound"] = "mfma"
+            roofline.update({"bound": "hbm", "kernel": "letterbox_u8", "achieved": lb_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": lb_gbs / PEAK_HBM_GBS, "traffic": None, "launches_per_step": lb["launches"],
+                             "avg_launch_ms": lb["ms"] / max(lb["launches"], 1), "algorithmic_bytes_per_launch": lb_bytes,
+                             "algorithmic_flops_per_launch": 0.0, "flop_per_byte": None,
+                             "hbm_view": {"achieved_gbs": lb_gbs, "peak_gbs": PEAK_HBM_GBS, "frac": lb_gbs / PEAK_HBM_GBS},
+                             "dominant_conv_kernel": conv_view,
+                             "note": "configs[4]: the on-device letterbox is the kernel this configuration adds; 13.81 MB algorithmic "
+                                     "per image (12.58 MB source read once + 1.23 MB written)"})
+            lbt = os.path.join(_ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic_config4.json")
+            if os.path.exists(lbt):
+                with open(lbt) as fh:
+                    fam4 = json.load(fh).get("families", {}).get("letterbox_u8")
+                if fam4:
+                    roofline["traffic"] = fam4["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = f"profiles/{PROFILE_ROUND}_pmc_traffic_config4.json"
         if args.dump_profile:
             with open(args.dump_profile, "w") as fh:
                 json.dump({"families": families, "launches": launches[-1]}, fh, indent=1)
@@ -403,7 +444,8 @@ def main():
             roofline["step_hbm_frac"] = roofline["step_hbm_gbs"] / PEAK_HBM_GBS
         wm = np.array(window_ms)
         line = {
-            "metric": "images/sec end-to-end (det+NMS+clf) 640x640 batch64",
+            "metric": "images/sec end-to-end (det+NMS+clf) 640x640 batch64" if args.config == 2 else
+                      "images/sec end-to-end (letterbox+det+NMS+clf) 2048x2048 -> 640x640 batch32 (configs[4])",
             "value": total_images / elapsed,
             "unit": "images/sec",
             "n_gpus": world,
@@ -416,9 +458,12 @@ def main():
             "dtype": "f16" if args.precision == "fp16" else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[2]: full det+NMS+ROI+ShuffleNetV2 pipeline, {args.precision}, batch={B}/GPU, 640x640, "
-                            f"inputs resident in HBM" + (f"; configs[3]-style sharding over {world} GPUs, one RCCL gather of "
-                                                         f"records per step" if world > 1 else ""),
+                "workload": (f"configs[4]: TT100K-shape {SRC}x{SRC} uint8 frames resident in HBM, letterboxed to 640 on the device "
+                             f"inside the step, full det+NMS+ROI+ShuffleNetV2 pipeline, {args.precision}, batch={B}/GPU"
+                             if args.config == 4 else
+                             f"configs[2]: full det+NMS+ROI+ShuffleNetV2 pipeline, {args.precision}, batch={B}/GPU, 640x640, "
+                             f"inputs resident in HBM") + (f"; configs[3]-style sharding over {world} GPUs, one RCCL gather of "
+                                                           f"records per step" if world > 1 else ""),
                 "detector": f"YOLO-LitePi {args.preset} architecture, seeded random weights (LSUV-scaled), "
                             f"{flop_img / 1e9:.3f} GFLOP/image, class bias calibrated to ~{TARGET_CANDIDATES} candidates/image",
                 "classifier": f"ShuffleNetV2 x1.0, {NUM_CLASSES} classes, seeded random weights, 64x64 ROIs",
@@ -437,6 +482,9 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        diag = {k: os.environ[k] for k in ("LITEPI_SKIP_STAGE", "LITEPI_SKIP_OP") if os.environ.get(k)}
+        if diag:   # tools/marginal_cost.sh: a launch is left out of the timed passes -- NOT a valid bench line
+            line["INVALID_diagnostic_skip"] = diag
         print(json.dumps(line), flush=True)
     for e in engs:
         e.close()

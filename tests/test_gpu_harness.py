@@ -113,8 +113,9 @@ def test_harness_main_two_passes_csv_and_keep_all(tmp_path, monkeypatch, capsys)
     assert (out / "synthetic.ncnn+shufflenetv2").is_dir()
     # equal thresholds: ONE pass per chunk (e2e.py:983-984), and the row is appended
     calls.clear()
-    assert e2e.main(argv + ["--yolo_conf", "0.25", "--num_samples", "2", "--save_viz", "1"]) == 0
-    assert [c[1] for c in calls] == [0.25]
+    # (+ e2e_optimize.py's extras: --warmup N = N passes at conf 0.5 on a random frame before the loop, --no_jit accepted and ignored)
+    assert e2e.main(argv + ["--yolo_conf", "0.25", "--num_samples", "2", "--save_viz", "1", "--warmup", "2", "--no_jit"]) == 0
+    assert [(c[0], c[1]) for c in calls] == [(1, 0.5), (1, 0.5), (2, 0.25)]
     df = pd.read_csv(summary)
     assert len(df) == 2 and df.loc[1, "num_test_images"] == 2
     # ---- --save_viz: one overlay per processed image (e2e.py:1003-1009), readable, the image's size, and drawn on

@@ -349,12 +349,15 @@ def test_detector_fp16_other_sizes(tmp_path, size):
 
 
 @pytest.mark.parametrize("size,batch", [(320, 5), (640, 7), (800, 4)])
-def test_detector_fp16_c2f_plan_other_sizes(tmp_path, size, batch):
+def test_detector_fp16_c2f_plan_other_sizes(tmp_path, monkeypatch, size, batch):
     """The whole-C2f plan (handles of >= 4 images) on maps other than 80 / 40 / 20: at 320 the 20x20 tile kernels run on a
-    single tile and the 10x10 level falls back to the layer plan; at 640 every module runs fused (an odd batch of 7); at 800 (maps 100 / 50 / 25) the tiles do not divide the maps and every module must fall back.
-    Mixed plans, an odd batch.  The bound is the layer plan's own: the same images through a 3-image handle (layer plan) give
-    the fp16 error of this model at this size, and the whole-C2f plan must stay within 1.25 x of it (and within the documented
-    0.02 / 0.35-cell bounds whenever the layer plan is)."""
+    single tile and the 10x10 level falls back to the layer plan; at 640 every module runs fused (an odd batch of 7); at 800
+    (maps 100 / 50 / 25) the tiles do not divide the maps and every module must fall back.  Mixed plans, an odd batch.
+    The bound is plan against plan AT THE SAME CAPACITY: the same images through a handle of the same size built with
+    LITEPI_NO_C2F=1 (every other heuristic -- tile shapes, channel splits -- depends on the capacity only, so the two handles
+    differ in nothing but the whole-C2f / s2conv launches) give the fp16 error of this model at this size, and the whole-C2f
+    plan must stay within 1.25 x of it (round 3 compared against a 3-image handle, whose other tile shapes forced a loose
+    bound).  The documented absolute bounds (0.02 / 0.35 cells / 0.5 px mean) are asserted for both plans at 320 and 640."""
     from litepi import Engine, ncnn_export
     param, binf = str(tmp_path / "d.param"), str(tmp_path / "d.bin")
     ncnn_export.export_detector(param, binf, "v1", seed=77, cls_bias=-2.0, size=size)
@@ -362,34 +365,40 @@ def test_detector_fp16_c2f_plan_other_sizes(tmp_path, size, batch):
     imgs = rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
     ref, _ = _oracle_out0(param, binf, imgs)
     got, names = {}, {}
-    for plan, cap in (("layer", 3), ("c2f", batch)):
-        e = Engine(precision="fp16", max_batch=cap, det_input=size)
+    for plan in ("layer", "c2f"):
+        if plan == "layer":
+            monkeypatch.setenv("LITEPI_NO_C2F", "1")
+        else:
+            monkeypatch.delenv("LITEPI_NO_C2F", raising=False)
+        e = Engine(precision="fp16", max_batch=batch, det_input=size)
         try:
             e.load_detector(param, binf)
-            got[plan] = e.detect_raw(imgs[:cap])
+            got[plan] = e.detect_raw(imgs)
             e.profile_next(True)
-            e.detect_raw(imgs[:cap])
+            e.detect_raw(imgs)
             names[plan] = [k["name"] for k in e.profile_read()]
         finally:
             e.close()
     fused = [n for n in names["c2f"] if n.startswith("c2f<") or n.startswith("s2conv<")]
     print(f"fp16 {size} x{batch}: {len(names['c2f'])} launches ({len(names['layer'])} in the layer plan), whole-C2f / s2conv: {sorted(set(fused))}")
-    assert not any(n.startswith("c2f<") for n in names["layer"])
+    assert not any(n.startswith("c2f<") or n.startswith("s2conv<") for n in names["layer"])
     assert (len(fused) > 0) == (size != 800), names["c2f"]
     n8, n16, n32 = (size // 8) ** 2, (size // 16) ** 2, (size // 32) ** 2
     stride = np.concatenate([np.full(n8, 8.0), np.full(n16, 16.0), np.full(n32, 32.0)]).astype(np.float32)
     err = {}
     for plan in ("layer", "c2f"):
-        g, r = got[plan], ref[:len(got[plan])]
-        es, eb = np.abs(g[:, 4] - r[:, 4]), np.abs(g[:, :4] - r[:, :4])
+        g = got[plan]
+        es, eb = np.abs(g[:, 4] - ref[:, 4]), np.abs(g[:, :4] - ref[:, :4])
         cells = (eb / stride).max()
         err[plan] = (float(es.max()), float(cells), float(eb.mean()))
         print(f"   {plan:5s} plan: score err max {es.max():.4f}; box err max {eb.max():.3f} px = {cells:.3f} cells, mean {eb.mean():.4f}")
-    for k, doc in enumerate((0.02, 0.35, 0.5)):   # documented bounds: score, box error in grid cells of the level, mean box error (px)
-        bound = max(doc, 1.25 * err["layer"][k])
-        assert err["c2f"][k] <= bound, f"whole-C2f plan error {err['c2f'][k]} vs layer plan {err['layer'][k]} (metric {k})"
-    # the first three images went through both plans: the two fp16 results agree with each other about as well as with fp32
-    d = np.abs(got["c2f"][:3, 4] - got["layer"][:, 4]).max()
+    if names["c2f"] == names["layer"]:   # (800: every module fell back) the same launches must give the same bits
+        assert np.array_equal(got["c2f"], got["layer"])
+    for k, (doc, floor) in enumerate(((0.02, 1e-3), (0.35, 0.01), (0.5, 0.01))):   # score, box error in grid cells of the level, mean box error (px)
+        assert err["c2f"][k] <= 1.25 * err["layer"][k] + floor, f"whole-C2f plan error {err['c2f'][k]} vs layer plan {err['layer'][k]} (metric {k})"
+        if size != 800:
+            assert err["c2f"][k] <= doc and err["layer"][k] <= doc, f"metric {k}: {err['c2f'][k]} / {err['layer'][k]} against the documented {doc}"
+    d = np.abs(got["c2f"][:, 4] - got["layer"][:, 4]).max()
     print(f"   c2f vs layer plan on the same images: score diff max {d:.4f}")
     assert d <= max(0.02, 1.5 * err["layer"][0])
 
@@ -834,38 +843,32 @@ def test_head_projection_logits_fp32(synth_models):
         print(f"{preset} fp32 head logits: max abs err {worst:.2e}")
 
 
-def test_config4_large_images_map_vs_cpu(tmp_path):
-    """configs[4]: 2048x2048 inputs, letterboxed to 640 on the device (r = 0.3125), fp16.  There are no labels here, so the
-    CPU fp32 path's confident detections serve as pseudo ground truth and the HIP predictions are scored with the port of
-    the reference's evaluate_predictions (e2e.py:656-824).  Bounds: every confident CPU box is found (IoU >= 0.5), and
-    mAP@0.5 -- which also needs the classifier arg-max to agree -- stays high."""
+@pytest.mark.parametrize("n_img", [3, 32], ids=["cap3", "cap32"])
+def test_config4_large_images_map_vs_cpu(tmp_path, n_img):
+    """configs[4]: 2048x2048 inputs, letterboxed to 640 on the device (r = 0.3125), fp16; cap32 = the per-GPU batch of
+    `bench.py --config 4` (256 images over 8 GPUs) on a handle of that capacity (the whole-C2f plan).  There are no labels
+    here, so the CPU fp32 path's confident detections serve as pseudo ground truth and the HIP predictions are scored with
+    the port of the reference's evaluate_predictions (e2e.py:656-824).  Bounds: every confident CPU box is found (IoU >= 0.5,
+    at most one miss per 24 boxes), and mAP@0.5 / mAP@0.5:0.95 -- which also need the classifier arg-max to agree -- stay high."""
     from litepi import HybridPipeline, ncnn_export
     from litepi.e2e import evaluate_predictions
+    from litepi.synth import config4_images
     from oracle import ncnn_ref, pipeline_ref, shufflenet_ref as S
     p, b = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
     ncnn_export.export_detector(p, b, "v1", seed=77, cls_bias=0.0)
-    rng = np.random.default_rng(2)
-    imgs = []
-    for _ in range(3):  # low-frequency noise + pasted 40-80 px discs (BASELINE.json configs[4] recipe)
-        low = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
-        img = np.repeat(np.repeat(low, 32, axis=0), 32, axis=1).copy()
-        yy, xx = np.mgrid[0:2048, 0:2048]
-        for _d in range(6):
-            cy, cx, rad = rng.integers(100, 1948), rng.integers(100, 1948), rng.integers(20, 41)
-            img[(yy - cy) ** 2 + (xx - cx) ** 2 <= rad * rad] = rng.integers(0, 256, 3, dtype=np.uint8)
-        imgs.append(img)
+    imgs = list(config4_images(n_img, seed=2))   # low-frequency noise + pasted 40-80 px discs (BASELINE.json configs[4] recipe)
     layers = ncnn_ref.load_model(p, b)
     sd = S.seeded_state_dict(91)
     cpu = pipeline_ref.CpuPipeline(layers, S.build(91, sd))
-    scores = np.concatenate([cpu.detect_raw(im)[0][4].astype(np.float64) for im in imgs])
+    scores = np.concatenate([cpu.detect_raw(im)[0][4].astype(np.float64) for im in imgs[:3]])   # calibrated on the first three
     s = np.sort(scores)[::-1]
-    k = 60 * len(imgs)  # candidates cluster on a random-weight detector: NMS keeps a fraction of them
+    k = 60 * 3  # candidates cluster on a random-weight detector: NMS keeps a fraction of them
     logit = 0.5 * (np.log(s[k - 1] / (1 - s[k - 1])) + np.log(s[k] / (1 - s[k])))
     ncnn_export.shift_cls_bias(p, b, float(np.log(0.25 / 0.75) - logit))
     cpu = pipeline_ref.CpuPipeline(ncnn_ref.load_model(p, b), S.build(91, sd))
     cls_path = str(tmp_path / "cls.pth")
     torch.save(sd, cls_path)
-    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=3, max_det=300)
+    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=n_img, max_det=300)
     try:
         outs = pipe.run_batch(imgs, 0.25, 0.45, 50)
     finally:
@@ -888,9 +891,9 @@ def test_config4_large_images_map_vs_cpu(tmp_path):
             total += 1
     assert total >= 6, "calibration produced too few confident detections"
     m = evaluate_predictions(all_preds, all_gts, 91)
-    print(f"config4: {found}/{total} confident CPU boxes found; mAP50 {m['mAP50']:.3f} mAP50-95 {m['mAP50_95']:.3f}")
-    assert found >= total - 1
-    assert m["mAP50"] >= 0.6
+    print(f"config4, {n_img} images: {found}/{total} confident CPU boxes found; mAP50 {m['mAP50']:.3f} mAP50-95 {m['mAP50_95']:.3f}")
+    assert found >= total - max(1, total // 24)
+    assert m["mAP50"] >= 0.6 and m["mAP50_95"] >= 0.4
 
 
 def test_empty_and_error_behaviour(synth_models, tmp_path):
@@ -1210,6 +1213,18 @@ def test_capacity_128_matches_capacity_64(tmp_path):
     # the last fp16 bits (printed).  A box may therefore exist in one list only when its score is within BAND of the
     # threshold (or, through NMS, when the box that suppresses it is); everything else must agree box for box.
     BAND = 0.01
+
+    def iou(p, q):
+        iw, ih = max(0, min(p[2], q[2]) - max(p[0], q[0])), max(0, min(p[3], q[3]) - max(p[1], q[1]))
+        return iw * ih / ((p[2] - p[0]) * (p[3] - p[1]) + (q[2] - q[0]) * (q[3] - q[1]) - iw * ih + 1e-6)
+
+    def excused(box, score, both):
+        """a one-sided box: its own score is within BAND of conf, or a box that OVERLAPS it beyond the NMS threshold (so one of
+        the two suppresses the other) has a score within BAND of conf or within BAND of this box's score (greedy order swap)"""
+        if score <= 0.25 + BAND:
+            return True
+        return any(iou(box, bx) > 0.45 - 0.02 and (sx <= 0.25 + BAND or abs(sx - score) <= BAND) for bx, sx in both if bx != box)
+
     max_ds, flips = 0.0, 0
     for i, (a, c) in enumerate(zip(res[64], res[128][:64])):
         for (ba, sa) in a:
@@ -1218,13 +1233,14 @@ def test_capacity_128_matches_capacity_64(tmp_path):
                 max_ds = max(max_ds, min(abs(sa - x) for x in m))
             else:
                 flips += 1
-                assert sa <= 0.25 + BAND or any(sx <= 0.25 + BAND for _, sx in a + c), f"image {i}: box {ba} ({sa:.4f}) only at capacity 64"
+                assert excused(ba, sa, a + c), f"image {i}: box {ba} ({sa:.4f}) only at capacity 64"
         for (bc, sc) in c:
             if not any(np.abs(np.array(bc) - np.array(ba)).max() <= 2 for (ba, _) in a):
                 flips += 1
-                assert sc <= 0.25 + BAND or any(sx <= 0.25 + BAND for _, sx in a + c), f"image {i}: box {bc} ({sc:.4f}) only at capacity 128"
+                assert excused(bc, sc, a + c), f"image {i}: box {bc} ({sc:.4f}) only at capacity 128"
+    assert flips <= max(4, nbox // 100), f"{flips} one-sided boxes of {nbox}"
     print(f"capacity 64 vs 128: {nbox} boxes in 64 images, {same}/64 images with identical box lists, {flips} boxes in one list only "
-          f"(all within {BAND} of conf, directly or through NMS), max score difference of matched boxes {max_ds:.5f}; "
+          f"(each within {BAND} of conf itself or overlapping such a box beyond the NMS threshold; capped at 1 %), max score difference of matched boxes {max_ds:.5f}; "
           f"{sum(len(x) for x in res[128])} boxes in 128 images")
     assert nbox >= 64 and max_ds <= 5e-3
     assert sum(len(x) for x in res[128][64:]) >= 32
@@ -1257,7 +1273,7 @@ def test_mbnet_classifier_matches_oracle(tmp_path, precision, arch):
     eids, eprobs = M.predict_batch(model, rois)
     err = float(np.abs(probs - eprobs).max())
     print(f"{arch} {precision}: max prob err {err:.2e}")
-    tol = 2e-4 if precision == "fp32" else 4e-2
+    tol = 2e-4 if precision == "fp32" else 1.5e-2   # fp16: ~2x the measured 7e-3 (round 3 allowed 4e-2)
     assert probs.shape == eprobs.shape and err <= tol
     for i in range(len(rois)):
         top2 = np.sort(eprobs[i])[-2:]

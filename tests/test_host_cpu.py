@@ -238,3 +238,120 @@ def test_evaluate_predictions_matches_reference_goldens(golden_dir):
             assert np.allclose(m[k], g[f"c{i}_{k}"], rtol=0, atol=1e-12), (i, k)
         assert np.allclose([m["mAP50"], m["mAP50_95"]], g[f"c{i}_map"], atol=1e-12)
         assert np.array_equal(m["classes_present"], g[f"c{i}_present"])
+
+
+# ---- litepi/e2e.py --gpus N: shard + merge under gloo (world 2, CPU, fake engine) --------------------------------------
+class _FakeMetrics:
+    def __init__(self, t):
+        self.t_total = t
+
+
+class _FakePipeline:
+    """Stands in for litepi.backend.HybridPipeline in the CPU tests of the harness: deterministic detections computed from
+    the image bytes (so every rank and the single-process run agree on what an image yields), more of them at a lower conf."""
+
+    def __init__(self, *a, **k):
+        self.engine = self
+
+    def close(self):
+        pass
+
+    def run_batch(self, imgs, conf, iou, min_area):
+        out = []
+        for im in imgs:
+            seed = int(im[:4, :4].astype(np.int64).sum())
+            rng = np.random.default_rng(seed)
+            n = int(rng.integers(0, 4)) + (3 if conf < 0.01 else 0)
+            res = []
+            for _ in range(n):
+                x1, y1 = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+                res.append({"bbox": (x1, y1, x1 + int(rng.integers(8, 20)), y1 + int(rng.integers(8, 20))),
+                            "det_conf": float(np.float32(rng.uniform(max(conf, 0.01), 1.0))), "cls_class": int(rng.integers(0, 3)),
+                            "det_class": 0, "cls_conf": 0.9})
+            out.append((res, _FakeMetrics(1.0 + 0.01 * (seed % 7))))
+        return out
+
+
+def _make_eval_set(root, n):
+    from PIL import Image
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    os.makedirs(os.path.join(root, "labels"), exist_ok=True)
+    rng = np.random.default_rng(5)
+    for i in range(n):
+        im = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+        Image.fromarray(im).save(os.path.join(root, "images", f"img_{i:03d}.png"))
+        with open(os.path.join(root, "labels", f"img_{i:03d}.txt"), "w") as f:
+            for _ in range(int(rng.integers(0, 3))):
+                f.write(f"{int(rng.integers(0, 3))} {rng.uniform(0.3, 0.7):.4f} {rng.uniform(0.3, 0.7):.4f} 0.2 0.25\n")
+    with open(os.path.join(root, "classes.json"), "w") as f:
+        f.write('{"0": "a", "1": "b", "2": "c"}')
+
+
+def _eval_args(root, out, gpus):
+    sys.path.insert(0, os.path.join(ROOT, "yolo-litepi_amd"))
+    from litepi import e2e
+    return e2e.build_parser().parse_args(["--input", os.path.join(root, "images"), "--labels", os.path.join(root, "labels"),
+                                          "--classes", os.path.join(root, "classes.json"), "--output", out, "--batch_images", "3",
+                                          "--gpus", str(gpus), "--detector_param", "fake.param"])
+
+
+def _eval_worker(rank, world, port, root, q):
+    sys.path.insert(0, os.path.join(ROOT, "yolo-litepi_amd"))
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LITEPI_DIST_BACKEND": "gloo"})
+    import litepi.backend as backend
+    from litepi import e2e
+    backend.HybridPipeline = _FakePipeline
+    r = e2e.run_evaluation(_eval_args(root, os.path.join(root, f"out_w{world}"), world))
+    if rank == 0:
+        q.put({"preds": r["all_preds"], "gts": r["all_gts"], "mAP50": r["metrics"]["mAP50"], "mAP50_95": r["metrics"]["mAP50_95"],
+               "times": r["rank_bench_times"], "fps": r["fps"]})
+    else:
+        q.put({"rank": r["rank"], "n_files": len(r["files"])})
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_e2e_harness_shards_and_merges_under_gloo(tmp_path, monkeypatch):
+    """`litepi.e2e --gpus 2` on CPU: 11 images (uneven shards of 6 + 5, chunks of 3), a fake engine, backend gloo.  Rank 0's
+    merged predictions, ground truths and metric equal the single-process run's exactly; the other rank returns early."""
+    import torch.multiprocessing as mp
+    root = str(tmp_path)
+    _make_eval_set(root, 11)
+    # single process
+    import litepi.backend as backend
+    from litepi import e2e
+    monkeypatch.setattr(backend, "HybridPipeline", _FakePipeline)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    one = e2e.run_evaluation(_eval_args(root, os.path.join(root, "out_w1"), 1))
+    assert len(one["all_preds"]) == 11 and sum(len(p) for p in one["all_preds"]) > 20
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, root, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0 = next(r for r in res if "preds" in r)
+    r1 = next(r for r in res if "rank" in r)
+    assert r1 == {"rank": 1, "n_files": 5}
+    assert r0["preds"] == one["all_preds"] and r0["gts"] == one["all_gts"]
+    assert r0["mAP50"] == one["metrics"]["mAP50"] and r0["mAP50_95"] == one["metrics"]["mAP50_95"]
+    # the sharded job's FPS: images / the slowest rank's summed benchmark time
+    assert len(r0["times"]) == 2 and abs(sum(r0["times"]) - one["rank_bench_times"][0]) < 1e-9
+    assert abs(r0["fps"] - 11 / max(r0["times"])) < 1e-9
+
+
+def test_eval_row_packing_round_trips():
+    from litepi.distributed import pack_eval_rows, unpack_eval_rows
+    preds = [[{"bbox": (1, 2, 30, 40), "conf": float(np.float32(0.123456789)), "cls_class": 7}], [],
+             [{"bbox": (0, 0, 2048, 2047), "conf": float(np.float32(0.001)), "cls_class": -1}] * 2]
+    gts = [[(3, 1, 1, 9, 9)], [(0, 5, 6, 7, 8), (1, 0, 0, 1, 1)], []]
+    p2, g2 = unpack_eval_rows(pack_eval_rows(preds, gts), 3)
+    assert p2 == preds and g2 == gts
+    p3, g3 = unpack_eval_rows(pack_eval_rows([[]], [[]]), 1)
+    assert p3 == [[]] and g3 == [[]]

@@ -127,6 +127,32 @@ def test_oracle_forward_on_real_weights_is_stable(golden_dir):
         assert np.allclose(out.mean(axis=1), g[f"s{seed}_mean"], rtol=1e-4)
 
 
+@needs_ref
+def test_two_reference_graph_descriptions_agree_on_real_weights():
+    """The reference's ONNX export of the v1 checkpoint (yolo_plus.onnx, opset 12), walked node by node with the ONNX
+    specification's operator semantics (oracle/onnx_ref.py), against oracle/ncnn_ref.py's reading of the NCNN graph of the
+    same checkpoint: identical out0 on the same inputs.  A cross-check of two reference-held graph descriptions (Slice,
+    Interp/Resize, Pooling pad mode, Permute and the DFL ordering are read twice, from two formats); it pins no output of
+    the reference's engines -- forward parity stays UNPINNED."""
+    import torch
+    from oracle import ncnn_ref, onnx_ref
+    layers = ncnn_ref.load_model(os.path.join(V1_DIR, "yolo_plus_ncnn_model/model.ncnn.param"),
+                                 os.path.join(V1_DIR, "yolo_plus_ncnn_model/model.ncnn.bin"))
+    nodes, init, g_in, g_out = onnx_ref.read_graph(os.path.join(V1_DIR, "yolo_plus.onnx"))
+    assert len(nodes) == 238 and sum(n.op == "Conv" for n in nodes) == 64 and g_in == ["images"] and g_out == ["output0"]
+    yy, xx = np.mgrid[0:640, 0:640].astype(np.float32)
+    structured = np.stack([0.5 + 0.5 * np.sin(xx / 37.0 + c) * np.cos(yy / 53.0 - c) for c in range(3)])[None]
+    inputs = [torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(s)) for s in (0, 1)]
+    inputs.append(torch.from_numpy(structured.astype(np.float32)))
+    for x in inputs:
+        with torch.no_grad():
+            a = onnx_ref.run(nodes, init, {"images": x}, g_out)["output0"].numpy()
+        b = ncnn_ref.run_graph(layers, x)["out0"].numpy()
+        assert a.shape == b.shape == (1, 5, 8400)
+        assert np.abs(a[:, 4] - b[:, 4]).max() <= 1e-6                      # scores
+        assert np.allclose(a[:, :4], b[:, :4], rtol=1e-6, atol=2e-4)        # boxes in pixels, up to 640: a few fp32 ulps (6e-5 each) between two op orders
+
+
 def test_synthetic_models_have_the_reference_architecture(synth_models):
     """The exporter reproduces the reference graphs' MAC counts and the oracle
     interpreter runs them."""

@@ -213,6 +213,17 @@ int lp_create(const lp_config* cfg, lp_handle** out) {
   LP_HIP(hipGetDeviceProperties(&prop, cfg->device));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     throw Error(LP_ERR_NODEVICE, fmt("device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName));
+  // the two measurement diagnostics make every pass after a handle's first return STALE results with LP_OK: never silently
+  {
+    static bool warned = false;
+    const char *ss = getenv("LITEPI_SKIP_STAGE"), *so = getenv("LITEPI_SKIP_OP");
+    if ((ss || so) && !warned) {
+      warned = true;
+      fprintf(stderr, "[litepi] WARNING: LITEPI_SKIP_STAGE=%s LITEPI_SKIP_OP=%s -- diagnostic mode (tools/marginal_cost.sh): a pipeline stage / "
+                      "detector launch is LEFT OUT of every pass after a handle's first; results are stale and must not be used\n",
+              ss ? ss : "", so ? so : "");
+    }
+  }
   std::unique_ptr<lp_handle> h(new lp_handle());
   h->cfg = *cfg;
   // every kept box is a ROI (the reference classifies all of them, e2e.py:493-497): the default capacity can not overflow

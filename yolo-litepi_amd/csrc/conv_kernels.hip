@@ -1518,7 +1518,8 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
   const bool sb_interior = oy0 >= 1 && ox0 >= 1 && 2 * oy0 - 1 + SB_SH <= a.H1 && 2 * ox0 - 1 + SB_SW <= a.W1;
   // K group -> (window row ky, byte half h) of the 15-byte union window (StemLayer::build packs a_blk to match): step 0 holds
   // rows 0 and 2, step 1 row 1 (+ two zero-weight groups that re-read it).  The two K groups of a 32-lane ds_read_b32 group then
-  // read rows two apart = 16 banks apart (row pitch 104 dwords): half the bank conflicts of the (ky, h) = (q / 2, q % 2) order
+  // read rows two apart = 2 x 102 = 204 dwords = 12 banks apart (row pitch SB_ROWW = 102 dwords; 16 banks at round 3's first pitch of
+  // 104, for which the simulation below was run): about half the bank conflicts of the (ky, h) = (q / 2, q % 2) order
   // (852 -> 522 LDS cycles per workgroup in a simulation of the access pattern).
   const int ky0 = 2 * (g & 1), hh = g >> 1;
   // pair index of this lane's column in tile t, as (row r, pair pp): t advances by 4 tiles = 64 pairs = 1 row + 31 pairs

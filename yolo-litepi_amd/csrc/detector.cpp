@@ -531,6 +531,13 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         if (L[jn].inputs.size() != 2 || get(L[jn].inputs[0]) != tx || !zero_copy_concat(jn) || tensors_[tx].buf != tensors_[tcat_in].buf ||
             tensors_[tx].off != tensors_[tcat_in].off || tensors_[tcat_in].parent >= 0)
           return false;
+        // the launch is emitted HERE, at the stride-2 conv's position, and cv1 reads the whole Concat(x, other): `other` must
+        // have been produced by then.  Layers are emitted in file order, so its producer has to precede this conv (true for
+        // the reference's graphs: P5 / F4 come earlier); otherwise the module is retried at its cv1, behind the Concat.
+        {
+          auto po = producer.find(L[jn].inputs[1]);
+          if (po != producer.end() && po->second >= i) return false;
+        }
         xcat = jn;
         jn = sole_consumer(tcat_in);
       }
@@ -630,6 +637,24 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         tensors_[cinfo[js1].tout].materialised = true;
       }
       bytes += ((double)tensors_[io.out2].C - (double)tensors_[tout].C) * Hh * Ww * esd;
+    }
+    if (!getenv("LITEPI_C2F_STORE_ALL")) {
+      // every tensor between the module's input and its output: lp_debug_blob must not hand out their (possibly never
+      // written) storage -- which of them a configuration stores is the kernel's business (c2f_kernels.hip)
+      auto inside = [&](int t) { if (t >= 0 && t != tout && (mode != 2 || t != io.out2)) tensors_[t].in_c2f = true; };
+      inside(cinfo[m.cv1].tout);
+      inside(m.t_cat);
+      for (int t : m.ys) inside(t);
+      for (int k = 0; k < m.nb; ++k) {
+        inside(cinfo[m.a[k]].tout); inside(cinfo[m.b[k]].tout);
+        for (auto& o : L[m.add[k]].outputs) inside(get(o));
+      }
+      if (mode >= 1) inside(io.x);
+      if (mode == 2) {
+        tensors_[tout].in_c2f = true;   // the C2f's own output: SPPF.cv1 reads it from LDS
+        inside(cinfo[js1].tout); inside(io.cat2);
+        for (int q = 0; q < 3; ++q) inside(get(L[pools[q]].outputs[0]));
+      }
     }
     c2f_io_.push_back(io);
     macs_ += cl.macs_per_image;
@@ -1348,6 +1373,9 @@ void Detector::fetch_blob(const std::string& name, int B, std::vector<float>& ou
   const Tensor& T = tensors_[it->second];
   // a blob that a fused kernel keeps in registers / LDS has storage reserved (e.g. its concat slot) but is never written
   LP_CHECK(T.materialised || T.parent >= 0 || T.segs.size() > 1, LP_ERR_ARG, "blob %s is fused away (never stored)", name.c_str());
+  LP_CHECK(!T.in_c2f && !(T.parent >= 0 && tensors_[T.parent].in_c2f), LP_ERR_ARG,
+           "blob %s is fused away: it lives inside a whole-C2f launch (set LITEPI_C2F_STORE_ALL=1 before loading the model to have the "
+           "module store its intermediates)", name.c_str());
   const View v = view(it->second);
   C = T.C; H = T.H; W = T.W;
   const size_t es = prec_ == LP_FP16 ? 2 : 4;

@@ -34,6 +34,7 @@ struct Tensor {
   int buf = -1, off = 0;         // buffer index, physical channel offset inside it
   int parent = -1, parent_seg = -1;  // Slice outputs: view of parent's segment
   bool materialised = false;
+  bool in_c2f = false;           // lives inside a whole-C2f launch (LDS / registers, or a concat slot the launch may never write)
   int phys(int c) const;         // logical channel -> physical channel inside the view
 };
 

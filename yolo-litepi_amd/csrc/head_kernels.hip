@@ -191,6 +191,10 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
   const char* wstream = reinterpret_cast<const char*>(a.wstream) + lane * 16;
   const int nch = a.nchunks;
   HD_STAMP(0)
+  if ((a.flags & 4) && blockIdx.x < 768u) {   // experiment: de-lockstep the workgroups that start together on a CU
+    const unsigned slot = __builtin_amdgcn_s_getreg(6148) % 3u;   // HW_ID.WAVE_ID
+    for (unsigned i = 0; i < slot; ++i) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+  }
   HD_STAMP(1)
 
   // ---- weight ring, two 24 KiB slots, filled THROUGH REGISTERS: a wave owns pieces wave, wave + 4, .. (six 1 KiB
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
     }
   }
   HD_STAMP(2)
+  if (a.flags & 1) __builtin_amdgcn_s_setprio(1);
 
   // ---- this lane's pixels
   int pixA[PA];   // byte offset of the lane's stage-A pixel (region-1 pixel (ry, rx) -> IN pixel (ry, rx)), + its K half
@@ -327,6 +332,8 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
     }
   }
   HD_STAMP(4)
+  if (a.flags & 1) __builtin_amdgcn_s_setprio(0);
+  if (a.flags & 2) __builtin_amdgcn_s_setprio(1);
   // ---- SiLU, fp16, -> MID (zero outside the image: stage B's padding).  The weight rows are permuted at pack time
   //      so that this lane holds channels 32*rt + 16*h .. +15 of its pixel: two 16-byte stores per row tile.
   {
@@ -358,6 +365,8 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
     }
   }
   HD_STAMP(5)
+  if (a.flags & 1) __builtin_amdgcn_s_setprio(1);
+  if (a.flags & 2) __builtin_amdgcn_s_setprio(0);
 
   // ---- this lane's stage-B pixels; what only the decode needs (anchors, geometry, DFL weights) is requested here, behind
   //      stage A -- live across it these 30 registers were the difference to the three-workgroup shape's 168 -- and arrives
@@ -443,6 +452,8 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
   }
   // ======================= stage C: the 1x1 projections from the accumulators, then decode =======================
   HD_STAMP(7)
+  if (a.flags & 1) __builtin_amdgcn_s_setprio(0);
+  if (a.flags & 2) __builtin_amdgcn_s_setprio(1);
   half8 wcb[2][4], wcc[2 * C3T];
   if constexpr (SLOTF == 8) {
     // two projection chunks: the class projection (chunk c, stored behind the class tower's steps), then the box projection
@@ -737,6 +748,8 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
   LP_CHECK(in.C == Cin && in.H == H && in.W == W && (int)coff.size() <= 64, LP_ERR_STATE,
            "Detect head %s: view does not match the plan", name.c_str());
   const dim3 grid((unsigned)(a.ntiles * N));
+  static const int head_flags = getenv("LITEPI_HEAD_FLAGS") ? atoi(getenv("LITEPI_HEAD_FLAGS")) : 0;
+  a.flags = head_flags;
   static const char* stamp_path = getenv("LITEPI_HEAD_STAMPS");
   DevBuf d_stamps;
   if (stamp_path && *stamp_path) {

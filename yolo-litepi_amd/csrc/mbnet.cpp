@@ -88,6 +88,8 @@ void MBNetClassifier::load(const std::map<std::string, NamedTensor>& sd) {
   const Stage* stages = arch_ == MOBILENET_V2 ? mbv2 : effb0;
   int cin = 32, H = S_ / 2, fidx = 1;
   size_t widest = (size_t)32 * H * H;
+  // per-role maxima (elements per ROI): block inputs / outputs, the expanded tensor in front of the depthwise conv, behind it
+  size_t w_io = (size_t)32 * H * H, w_t = 0, w_u = 0;
   for (int si = 0; si < 7; ++si) {
     for (int r = 0; r < stages[si].n; ++r) {
       Block B;
@@ -142,6 +144,9 @@ void MBNetClassifier::load(const std::map<std::string, NamedTensor>& sd) {
         B.pw_project = add_pw(p + "project", B.exp, B.cout, ACT_NONE, q.w, q.b, B.hout);
       }
       widest = std::max(widest, std::max((size_t)B.exp * B.hin * B.hin, (size_t)B.cout * B.hout * B.hout));
+      w_io = std::max(w_io, (size_t)B.cout * B.hout * B.hout);
+      if (expand) w_t = std::max(w_t, (size_t)B.exp * B.hin * B.hin);
+      w_u = std::max(w_u, (size_t)B.exp * B.hout * B.hout);
       blocks_.push_back(B);
       cin = B.cout;
       H = B.hout;
@@ -155,6 +160,7 @@ void MBNetClassifier::load(const std::map<std::string, NamedTensor>& sd) {
     last_ = add_pw(lastp, cin, 1280, act_pw_, f.w, f.b, H);
     last_cin_ = cin; last_h_ = H;
     widest = std::max(widest, (size_t)1280 * H * H);
+    w_t = std::max(w_t, (size_t)1280 * H * H);   // the last 1x1 conv's output shares the expand buffer
   }
   {
     const NamedTensor& fw = need(sd, "classifier.1.weight");
@@ -172,7 +178,13 @@ void MBNetClassifier::load(const std::map<std::string, NamedTensor>& sd) {
     d_logits_.alloc((size_t)maxR_ * lpitch_ * 4);
   }
   LP_CHECK((double)widest * maxR_ < 2147483648.0, LP_ERR_ARG, "%s: max_rois = %d makes an activation exceed 2^31 elements", arch_name(arch_), maxR_);
-  for (auto& a : a_x_) a.alloc((size_t)maxR_ * widest * es, false);
+  // Buffers by ROLE, not four of the widest (with the default max_rois = max_batch x max_det = 19,200 ROIs four 96 x 32 x 32
+  // buffers were 15 GB in fp16): [0], [1] block inputs / outputs (ping-pong: a residual block reads x while it writes y),
+  // [2] the expanded tensor (and the last conv's 1280 channels), [3] the depthwise conv's output.
+  a_x_[0].alloc((size_t)maxR_ * w_io * es, false);
+  a_x_[1].alloc((size_t)maxR_ * w_io * es, false);
+  a_x_[2].alloc((size_t)maxR_ * std::max(w_t, (size_t)1) * es, false);
+  a_x_[3].alloc((size_t)maxR_ * w_u * es, false);
   a_mean_.alloc((size_t)maxR_ * 1280 * es);
   a_se_m_.alloc((size_t)maxR_ * 1152 * es);
   a_se_q_.alloc((size_t)maxR_ * 64 * es);
@@ -218,7 +230,7 @@ void MBNetClassifier::forward(const uint8_t* rgb, const int* d_R, hipStream_t st
   launch_cls_stem_act(prec_, rgb, stem_w_.as<float>(), stem_b_.as<float>(), stem_c_, act_dw_, x, S_, d_R, maxR_, st);
   P1("cls_stem_act", "features.0", 2.0 * 27 * stem_c_ * H1 * H1, (double)S_ * S_ * 3 + (double)H1 * H1 * stem_c_ * esd);
   for (const Block& B : blocks_) {
-    const int it = (cur + 1) % 4, iu = (cur + 2) % 4, iy = (cur + 3) % 4;
+    const int it = 2, iu = 3, iy = cur ^ 1;   // roles: see load()
     View t = x;
     if (B.pw_expand >= 0) {
       t = view(a_x_[it], B.exp, B.hin);
@@ -246,7 +258,7 @@ void MBNetClassifier::forward(const uint8_t* rgb, const int* d_R, hipStream_t st
     x = y;
     cur = iy;
   }
-  const View z = view(a_x_[(cur + 1) % 4], 1280, last_h_);
+  const View z = view(a_x_[2], 1280, last_h_);
   pw(last_, x, z, nullptr);
   cap6(z, "features.last");
   const View mean = view(a_mean_, 1280, 1);

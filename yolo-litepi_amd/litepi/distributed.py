@@ -107,3 +107,63 @@ def records_to_numpy(dets: torch.Tensor) -> np.ndarray:
     """[..., max_det, 32] uint8 tensor -> structured lp_det array."""
     a = dets.detach().cpu().numpy()
     return np.ascontiguousarray(a).view(DET_DTYPE).reshape(a.shape[:-1])
+
+
+# ---- the evaluation harness across ranks (litepi/e2e.py --gpus N) -------------------------------------------------------
+# Each rank evaluates a contiguous shard of the sorted image list (shard_range) and keeps, per image, the predictions and
+# the ground truths the metric consumes; ONE variable-length gather at the end moves them to rank 0, which scores the whole
+# set (evaluate_predictions needs every prediction: it ranks them globally by confidence).  Rows are packed as float64
+# [image index in the shard, kind (0 = prediction, 1 = ground truth), class, x1, y1, x2, y2, conf] -- exact for the int
+# pixel boxes and for the fp32 confidences.
+PRED_COLS = 8
+
+
+def pack_eval_rows(all_preds: Sequence[Sequence[dict]], all_gts: Sequence[Sequence[tuple]]) -> np.ndarray:
+    rows = []
+    for i, (preds, gts) in enumerate(zip(all_preds, all_gts)):
+        for p in preds:
+            x1, y1, x2, y2 = p["bbox"]
+            rows.append((i, 0, p["cls_class"], x1, y1, x2, y2, p["conf"]))
+        for g in gts:
+            rows.append((i, 1, g[0], g[1], g[2], g[3], g[4], 0.0))
+    return np.asarray(rows, dtype=np.float64).reshape(-1, PRED_COLS)
+
+
+def unpack_eval_rows(rows: np.ndarray, n_images: int):
+    preds: List[List[dict]] = [[] for _ in range(n_images)]
+    gts: List[List[tuple]] = [[] for _ in range(n_images)]
+    for r in rows:   # row order within an image is the packing order, i.e. the pipeline's result order
+        i = int(r[0])
+        if int(r[1]) == 0:
+            preds[i].append({"bbox": (int(r[3]), int(r[4]), int(r[5]), int(r[6])), "conf": float(np.float32(r[7])), "cls_class": int(r[2])})
+        else:
+            gts[i].append((int(r[2]), int(r[3]), int(r[4]), int(r[5]), int(r[6])))
+    return preds, gts
+
+
+def gather_eval_shards(all_preds, all_gts, bench_time: float, device="cpu", dst: int = 0, group: Optional[dist.ProcessGroup] = None):
+    """Shards (in rank order = image order, shard_range is contiguous) -> rank dst: (all_preds, all_gts, [bench_time per rank]);
+    other ranks: None.  Two collectives for the whole evaluation: an all-gather of (rows, images, time) per rank and one padded
+    gather of the rows (backend nccl = RCCL with `device` the rank's GPU, gloo with "cpu")."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(all_preds), list(all_gts), [bench_time]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rows = pack_eval_rows(all_preds, all_gts)
+    meta = torch.tensor([float(len(rows)), float(len(all_preds)), float(bench_time)], dtype=torch.float64, device=device)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    metas = [m.cpu().numpy() for m in metas]
+    cap = max(1, int(max(m[0] for m in metas)))
+    send = torch.zeros((cap, PRED_COLS), dtype=torch.float64, device=device)
+    if len(rows):
+        send[:len(rows)] = torch.from_numpy(rows).to(device)
+    slots = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, gather_list=slots, dst=dst, group=group)
+    if rank != dst:
+        return None
+    preds_all, gts_all = [], []
+    for m, slot in zip(metas, slots):
+        p, g = unpack_eval_rows(slot[:int(m[0])].cpu().numpy(), int(m[1]))
+        preds_all.extend(p)
+        gts_all.extend(g)
+    return preds_all, gts_all, [float(m[2]) for m in metas]

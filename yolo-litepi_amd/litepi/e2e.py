@@ -4,7 +4,13 @@
 backend.  Same two passes per image (benchmark pass at ``--benchmark_conf`` whose time feeds the
 FPS figure, evaluation pass at ``--yolo_conf`` that feeds mAP; e2e.py:955-1011), same
 Ultralytics-style metric (e2e.py:656-824) and the same appended ``comparison_summary.csv`` schema
-(e2e.py:1166-1184).  New flags: ``--batch_images``, ``--precision``, ``--hip_device``.
+(e2e.py:1166-1184).  New flags: ``--batch_images``, ``--precision``, ``--hip_device``, ``--gpus``.
+
+``--gpus N`` (launched as ``python -m torch.distributed.run --nproc-per-node N -m litepi.e2e ... --gpus N``): one process
+per GPU, the sorted image list is sharded contiguously (``distributed.shard_range``), every rank runs both passes on its
+shard with a full weight replica, the per-image predictions and ground truths are gathered to rank 0 once
+(``distributed.gather_eval_shards``, backend nccl = RCCL), and rank 0 alone scores, prints and writes the CSV.  The FPS
+figure of a multi-rank run is images / the slowest rank's summed benchmark time (the wall time of the sharded job).
 
 Differences, on purpose: images are decoded with Pillow (cv2 is not a dependency);
 ``--detector_threads`` and ``--device`` are accepted and ignored (everything runs on the GPU);
@@ -51,6 +57,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--batch_images", type=int, default=1, help="images per GPU call")
     p.add_argument("--precision", type=str, choices=["fp16", "fp32"], default="fp16")
     p.add_argument("--hip_device", type=int, default=0)
+    p.add_argument("--gpus", type=int, default=1,
+                   help="GPUs of this node to shard the image list over: one process per GPU under torch.distributed.run "
+                        "(WORLD_SIZE must equal --gpus; the rank's GPU is LOCAL_RANK and overrides --hip_device)")
     p.add_argument("--max_det", type=int, default=0,
                    help="detections kept per image; 0 = one slot per anchor, i.e. nothing is ever dropped (what the reference does: "
                         "e2e.py:280-296 keeps every NMS survivor, and the evaluation pass at --yolo_conf 0.001 produces thousands)")
@@ -58,6 +67,12 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--numerics", type=str, choices=["e2e", "e2e_optimize"], default="e2e",
                    help="which reference pipeline's ROI stage to follow: e2e.py (PIL antialiased resize) or e2e_optimize.py "
                         "(cv2-linear resize, its own clip rule)")
+    # e2e_optimize.py's extras (e2e_optimize.py:882-885)
+    p.add_argument("--warmup", type=int, default=None,
+                   help="warm-up passes on a random 640x640 frame before the timed loop (e2e_optimize.py:552-570 warmup_pipeline); "
+                        "default 10 under --numerics e2e_optimize as there, 0 otherwise (e2e.py has none).  Here they also take "
+                        "the hipGraph capture of the benchmark pass out of the first timed image")
+    p.add_argument("--no_jit", action="store_true", help="accepted and ignored: there is no TorchScript on this path (e2e_optimize.py:884)")
     return p
 
 
@@ -255,17 +270,44 @@ def run_evaluation(args) -> Dict:
     --yolo_conf whose detections feed the metric (process_image, e2e.py:953-1011).  Returns everything main() prints/writes."""
     from .backend import HybridPipeline
 
+    from . import distributed as D
+
+    rank, local_rank, world = D.env_rank_world()
+    if args.gpus > 1 or world > 1:
+        import torch
+        import torch.distributed as dist
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run --nproc-per-node "
+                             f"{args.gpus} (WORLD_SIZE is {world})")
+        backend = os.environ.get("LITEPI_DIST_BACKEND", "nccl")   # "gloo": the CPU tests of the shard / merge logic
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        args.hip_device = local_rank
+        gather_device = torch.device("cuda", local_rank) if backend == "nccl" else "cpu"
+    else:
+        gather_device = "cpu"
+    say = print if rank == 0 else (lambda *a, **k: None)
+
     class_names = load_class_names(args.classes)
     num_classes = len(class_names)
     detector_name = Path(args.detector_param).stem
     combo = f"{detector_name}+{args.clf_arch}"
-    print(f"\n{'=' * 60}\nMODEL COMBINATION: {combo}\n{'=' * 60}")
+    say(f"\n{'=' * 60}\nMODEL COMBINATION: {combo}\n{'=' * 60}")
     nb = max(1, args.batch_images)
     max_det = args.max_det if args.max_det > 0 else num_anchors(args.det_input_size)
-    pipeline = HybridPipeline(args.detector_param, args.detector_bin, args.classifier, args.clf_arch, num_classes,
-                              args.det_input_size, args.cls_input_size, False, args.detector_threads, args.device,
-                              args.batch_size, precision=args.precision, max_batch=nb, max_det=max_det,
-                              device=args.hip_device, max_rois=args.max_rois, numerics=args.numerics)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()) if rank != 0 else contextlib.nullcontext():   # one banner, rank 0's
+        pipeline = HybridPipeline(args.detector_param, args.detector_bin, args.classifier, args.clf_arch, num_classes,
+                                  args.det_input_size, args.cls_input_size, False, args.detector_threads, args.device,
+                                  args.batch_size, precision=args.precision, max_batch=nb, max_det=max_det,
+                                  device=args.hip_device, max_rois=args.max_rois, numerics=args.numerics)
     out_dir = Path(args.output) / combo
     out_dir.mkdir(parents=True, exist_ok=True)
 
@@ -278,10 +320,19 @@ def run_evaluation(args) -> Dict:
         files = sorted(list(inp.glob("*.jpg")) + list(inp.glob("*.png")) + list(inp.glob("*.jpeg")))
         if args.num_samples:
             files = sample_images(files, args.num_samples, args.seed)
-    print(f"\nFound {len(files)} images for processing")
+    say(f"\nFound {len(files)} images for processing" + (f" ({world} ranks, contiguous shards)" if world > 1 else ""))
+    n_total = len(files)
+    lo, hi = D.shard_range(n_total, rank, world)
+    files = files[lo:hi]
 
     all_preds, all_gts, bench_time, names = [], [], 0.0, []
     try:
+        n_warm = args.warmup if args.warmup is not None else (10 if args.numerics == "e2e_optimize" else 0)
+        if n_warm > 0:   # warmup_pipeline (e2e_optimize.py:552-570): random frame, conf 0.5
+            dummy = np.random.randint(0, 255, (640, 640, 3), dtype=np.uint8)
+            for _ in range(n_warm):
+                pipeline.run(dummy, conf_threshold=0.5)
+            say(f"Warmup complete ({n_warm} passes)")
         for i in range(0, len(files), nb):
             chunk, imgs = [], []
             for f in files[i:i + nb]:
@@ -307,10 +358,20 @@ def run_evaluation(args) -> Dict:
                 names.append(f.name)
     finally:
         pipeline.engine.close()
+    rank_times = [bench_time]
+    if world > 1:   # the one exchange of the sharded evaluation: every rank's predictions + ground truths -> rank 0
+        import torch.distributed as dist
+        got = D.gather_eval_shards(all_preds, all_gts, bench_time, device=gather_device)
+        dist.barrier()
+        if rank != 0:
+            return {"rank": rank, "files": names}
+        all_preds, all_gts, rank_times = got
     m = evaluate_predictions(all_preds, all_gts, num_classes, args.iou_threshold)
-    avg = bench_time / len(all_preds) if all_preds else 0.0
+    # one rank: the reference's figure, mean per-image benchmark time; N ranks: the sharded job takes as long as its slowest rank
+    avg = max(rank_times) / len(all_preds) if all_preds else 0.0
     return {"combo": combo, "detector": detector_name, "class_names": class_names, "metrics": m, "avg_time": avg,
-            "fps": 1.0 / avg if avg > 0 else 0.0, "all_preds": all_preds, "all_gts": all_gts, "files": names, "max_det": max_det}
+            "fps": 1.0 / avg if avg > 0 else 0.0, "all_preds": all_preds, "all_gts": all_gts, "files": names, "max_det": max_det,
+            "rank": 0, "world": world, "rank_bench_times": rank_times}
 
 
 def main(argv=None) -> int:
@@ -318,6 +379,8 @@ def main(argv=None) -> int:
 
     args = build_parser().parse_args(argv)
     r = run_evaluation(args)
+    if r.get("rank", 0) != 0:   # --gpus N: rank 0 alone scores, prints and writes
+        return 0
     combo, m, class_names, fps, avg = r["combo"], r["metrics"], r["class_names"], r["fps"], r["avg_time"]
     print("\n" + "=" * 80 + f"\nEVALUATION RESULTS - {combo}\n" + "=" * 80)
     print(f"\nPerformance Metrics (at conf={args.benchmark_conf}):\n  Avg Inference Time: {avg * 1000:.2f} ms\n  Real FPS:           {fps:.2f} FPS")
