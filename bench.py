@@ -99,6 +99,8 @@ def build_models(args, workdir, engine_factory, cal_imgs):
     eng = engine_factory()
     eng.load_detector(param, binf)
     nb = min(8, cal_imgs.shape[0])
+    if cal_imgs.shape[1] != 640:   # configs[4]: the calibration sees what the detector sees, the frames letterboxed on the device
+        cal_imgs = np.stack([eng.test_letterbox(im)[0] for im in cal_imgs[:nb]])
     out0 = eng.detect_raw(cal_imgs[:nb])
     eng.close()
     s = np.sort(out0[:, 4].astype(np.float64).ravel())[::-1]

@@ -1311,3 +1311,46 @@ def test_mbnet_pipeline_end_to_end(tmp_path, arch):
             assert abs(r["cls_conf"] - float(pr[r["cls_class"]])) <= 5e-3
             total += 1
     assert total >= 4
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+def test_nms_single_wave_path_equals_general_path(eng32, monkeypatch, nc):
+    """Images with at most 64 candidates take a one-wave register path in nms_kernel (round 4); LITEPI_NMS_NO_SMALL=1 sends
+    them through the general (LDS sort, sixteen-wave) path.  Same boxes, same order, same rectangles, same counts -- bit for
+    bit -- on 60 random cases incl. empty, single, exactly 64, score ties and boxes the area filter drops; and both equal the
+    oracle's NMS."""
+    from oracle import postprocess_ref as P
+    rng = np.random.default_rng(40 + nc)
+    for case in range(60):
+        n = [0, 1, 2, 64, 63][case] if case < 5 else int(rng.integers(1, 65))
+        xy = rng.uniform(0, 560, (n, 2)).astype(np.float32)
+        wh = rng.uniform(2, 90, (n, 2)).astype(np.float32)
+        if n > 8:   # clusters: plenty of suppression
+            xy[: n // 2] = xy[0] + rng.uniform(-6, 6, (n // 2, 2)).astype(np.float32)
+            wh[: n // 2] = wh[0] + rng.uniform(-3, 3, (n // 2, 2)).astype(np.float32)
+        boxes = np.concatenate([xy, xy + np.abs(wh) + 1], 1).astype(np.float32)
+        scores = rng.uniform(0.26, 0.99, n).astype(np.float32)
+        if n > 4 and case % 3 == 0:
+            scores[1] = scores[0]   # a tie: decided by the anchor index (documented rule)
+        classes = rng.integers(0, nc, n).astype(np.int32)
+        got = {}
+        for mode in ("small", "general"):
+            if mode == "general":
+                monkeypatch.setenv("LITEPI_NMS_NO_SMALL", "1")
+            else:
+                monkeypatch.delenv("LITEPI_NMS_NO_SMALL", raising=False)
+            got[mode] = eng32.test_nms_boxes(boxes, scores, classes, (640, 640), 0.45, 50, 0)
+        monkeypatch.delenv("LITEPI_NMS_NO_SMALL", raising=False)
+        a, b = got["small"], got["general"]
+        assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), f"case {case} (n = {n}): the two paths differ"
+        # and against the oracle (per class in ascending order, e2e.py:280-284), when no two scores tie
+        if n and len(np.unique(scores)) == n:   # (n = 0: the C-ABI is given one dummy slot with count 0)
+            keep = []
+            for c in np.unique(classes):
+                m = np.where(classes == c)[0]
+                keep.extend(m[P.nms(boxes[m], scores[m], 0.45)])
+            _, valid = P.roi_rects(boxes[keep], 640, 640, 50)
+            dets = a[0]
+            assert len(dets) == len(valid)
+            for d, k in zip(dets, [keep[v] for v in valid]):
+                assert d["x1"] == boxes[k, 0] and d["y2"] == boxes[k, 3] and d["det_conf"] == scores[k] and d["det_class"] == classes[k]

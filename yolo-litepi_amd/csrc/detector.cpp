@@ -1343,7 +1343,7 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         heads_[op.conv]->launch(view(op.in), B, levels_[op.in2].off, A_, d_anchors_.as<float>(), d_strides_.as<float>(), d_dfl_.as<float>(), out0,
                                 geom, cand, cand_count, conf, st);
         kname = fmt("head_fused<%d,%d,%d,%d,%d,%d>", heads_[op.conv]->C3T, heads_[op.conv]->PA, heads_[op.conv]->PB, heads_[op.conv]->NPC,
-                    heads_[op.conv]->KSA, heads_[op.conv]->SLOTF) + sfx;   // = the leading template arguments of head_fused_kernel
+                    heads_[op.conv]->KSA, heads_[op.conv]->SLOTF) + (heads_[op.conv]->A16 ? "a16" : "") + sfx;   // = the leading template arguments of head_fused_kernel
         break;
     }
     if (prof) prof->end(st, kname, op.layer, op.flops * B, op.bytes * B);

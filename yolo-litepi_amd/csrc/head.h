@@ -37,6 +37,7 @@ struct HeadLayer {
   int Cin = 0, H = 0, W = 0, c3 = 0, C3T = 1, nc = 1, TH = 16, TW = 16, PA = 3, PB = 2;
   int KPT = 0, KSA = 6, NPC = 2, SLOTF = 24, nchunks = 0;   // SLOTF: fragments per weight-ring slot
   int OVL = 0;                                              // MID overlays the input tile in LDS
+  int A16 = 0;                                              // stage A on 16x16x32 MFMAs (16-pixel tiles)
   std::vector<unsigned short> coff;
   std::vector<unsigned char> csz, cks;
   DevBuf d_stream, d_biasA, d_biasB, d_biasC;

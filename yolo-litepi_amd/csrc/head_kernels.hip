@@ -72,6 +72,7 @@ __device__ __forceinline__ half8 silu_h8(const floatx16& acc, int base) {
 }
 __device__ __forceinline__ half8 lds_h8(const char* p) { return __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(p)); }
 __device__ __forceinline__ floatx16 mfma32(half8 a, half8 b, floatx16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ floatx4 mfma16(half8 a, half8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 // accumulator tile initialised with the bias of this lane's 16 channels (bias + 0 ..15)
 __device__ __forceinline__ floatx16 bias16(const float* __restrict__ b) {
   floatx16 v;
@@ -158,9 +159,62 @@ __device__ __forceinline__ void kchunk(const char* ring, int c, int lane16, cons
   }
 }
 
+// Stage A on v_mfma_f32_16x16x32_f16 (round 4): the (TH+2) x (TW+2) region costs ceil(pixels / 16) pixel tiles instead of
+// 32-pixel slots (80^2: 12 x 16 = 192 slots for 180 pixels instead of 256; 40^2: 17 x 16 for 264 instead of 384; 20^2: 144 =
+// 9 x 16 instead of 256), a quarter to almost a half fewer matrix cycles in the stage that holds 54 - 81 % of a level's MFMAs, and
+// as many fewer SiLUs in its epilogue.  A wave owns ALL 2*RT row tiles (16 channels each) of NB pixel tiles.  A chunk is KS
+// HALF-steps: half-step s multiplies the RT row tiles of row half s & 1 with the pixel fragments of K step s >> 1 (32 channels
+// of one tap), so a K step's pixel fragments are read once and used by both halves, while its 2*RT weight fragments arrive
+// RT at a time (6 KiB per K step at C3T = 1: what an 8 KiB ring slot holds).  Operand pipeline, ring barrier inside the last
+// half-step and the ring's side stores as in kchunk; BSET0 = register set of the chunk's first pixel fragments (the sets
+// alternate per K step, so with an odd number of K steps per chunk the parity alternates per chunk: chunks are unrolled).
+template <int RT, int NB, int KS, bool FIRST, bool LAST, int BSET0, int SLOTF, typename F, typename G>
+__device__ __forceinline__ void kchunkA16(const char* ring, int c, int lane16, const char* img, const int (&pix)[NB], F&& next_boff, G&& side,
+                                          floatx4 (&acc)[2 * RT][NB], half8 (&af)[2][RT], half8 (&bf)[2][NB]) {
+  static_assert(KS % 2 == 0 && RT * KS <= (SLOTF == 8 ? 7 : SLOTF), "whole K steps; a chunk fits one slot (fragment 7 of an 8-fragment slot lives elsewhere)");
+  constexpr int SLOT = SLOTF == 8 ? 8192 - 64 : SLOTF * 1024, NPW = SLOTF / 4;
+  const char* wb = ring + (c & 1) * SLOT + lane16;
+  const char* wbn = ring + ((c + 1) & 1) * SLOT + lane16;
+  auto ldA = [&](int set, const char* w, int s) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) af[set][rt] = lds_h8(w + (s * RT + rt) * 1024);
+  };
+  auto ldB = [&](int set) {
+    const int boff = next_boff();
+#pragma unroll
+    for (int p = 0; p < NB; ++p) bf[set][p] = lds_h8(img + pix[p] + boff);
+  };
+  constexpr int PPS = (NPW + KS - 2) / (KS - 1);   // ring pieces per half-step (they ride on half-steps 0 .. KS-2)
+  if (FIRST) {
+    lds_barrier();
+    ldA(0, wb, 0);
+    ldB(BSET0);
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (s + 1 < KS) {
+      ldA((s + 1) & 1, wb, s + 1);
+      if ((s + 1) % 2 == 0) ldB((BSET0 + (s + 1) / 2) & 1);
+    } else if (!LAST) {
+      lds_barrier();
+      ldA(0, wbn, 0);
+      ldB((BSET0 + KS / 2) & 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int bs = (BSET0 + s / 2) & 1, rh = s & 1;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int p = 0; p < NB; ++p) acc[rh * RT + rt][p] = mfma16(af[s & 1][rt], bf[bs][p], acc[rh * RT + rt][p]);
+#pragma unroll
+    for (int j = s * PPS; j < (s + 1) * PPS && j < NPW; ++j) side(j);
+  }
+}
+
 // NPC: 64-slot pieces per input-tile row, KSA: K steps per stage-A chunk (both fixed by the level's tile shape, see host)
 // SLOTF: fragments per weight-ring slot (24; 12 for the two-workgroups-per-CU shape), NRW: input-tile rows per wave = ceil((TH+4)/4)
-template <int C3T, int PA, int PB, int NPC, int KSA, int SLOTF, int NRW, bool OV = (SLOTF == 8)>
+// A16: stage A on 16x16x32 MFMAs (kchunkA16): PA = 16-pixel tiles per wave, KSA = half-steps per chunk (one tap per chunk)
+template <int C3T, int PA, int PB, int NPC, int KSA, int SLOTF, int NRW, bool OV = (SLOTF == 8), bool A16 = false>
 __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void head_fused_kernel(const HeadArgs a) {
   // SLOTF == 8: THREE workgroups per CU -- MID overlays the input tile (dead after stage A's K loops: one more barrier), 8 KiB
   // ring slots (the projections are then two chunks), <= 168 registers: 54,272 B of LDS.
@@ -178,7 +232,7 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
   const int TH = a.TH, TW = a.TW, KPT = a.KPT;
   const int RWin = TW + 4, IHin = TH + 4, SPin = 2 * KPT + 1, RSin = RWin * SPin;
   const int RW1 = TW + 2, R1 = (TH + 2) * RW1, R2 = TH * TW;
-  const int nA = (R1 + 31) >> 5, nB = (R2 + 31) >> 5;
+  const int nA = A16 ? (R1 + 15) >> 4 : (R1 + 31) >> 5, nB = (R2 + 31) >> 5;
   constexpr bool OVL = OV;   // MID overlays the input tile
   char* IN = smem;
   const int in_al = (IHin * RSin * 16 + 1023) & ~1023, mid_al = (R1 * SPM * 16 + 1023) & ~1023;
@@ -193,7 +247,8 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
   HD_STAMP(0)
   if ((a.flags & 4) && blockIdx.x < 768u) {   // experiment: de-lockstep the workgroups that start together on a CU
     const unsigned slot = __builtin_amdgcn_s_getreg(6148) % 3u;   // HW_ID.WAVE_ID
-    for (unsigned i = 0; i < slot; ++i) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+    const unsigned units = slot * ((unsigned)a.flags >> 8);        // flags >> 8: delay per slot in units of 512 cycles
+    for (unsigned i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);
   }
   HD_STAMP(1)
 
@@ -273,12 +328,18 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
 
   // ---- this lane's pixels
   int pixA[PA];   // byte offset of the lane's stage-A pixel (region-1 pixel (ry, rx) -> IN pixel (ry, rx)), + its K half
+  // A16: lane = (column col, K group kg); column col of a 16-pixel tile holds pixel offset sig(col) -- even offsets for the lanes
+  // {0-3, 12-15}, odd for {4-11} -- and K group kg reads channel slot gam(kg) = {0, 2, 1, 3} of the step's four: with the odd
+  // pixel pitch every ds_read_b128 lane group then hits 16 distinct 16-byte slots (as c2f_kernels.hip; tiles that wrap a
+  // region row still collide two-way).  The weights are packed to match (HeadLayer::build).
+  const int col16 = lane & 15, kg16 = lane >> 4;
+  const int sig16 = col16 < 4 ? 2 * col16 : (col16 < 12 ? 2 * (col16 - 4) + 1 : 2 * (col16 - 8));
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
-    int idx = 32 * (wave + 4 * p) + r;
+    int idx = A16 ? 16 * (wave + 4 * p) + sig16 : 32 * (wave + 4 * p) + r;
     idx = idx < R1 ? idx : R1 - 1;
     const int ry = idx / RW1, rx = idx - ry * RW1;
-    pixA[p] = (ry * RWin + rx) * SPin * 16 + h * 16;
+    pixA[p] = (ry * RWin + rx) * SPin * 16 + (A16 ? ((kg16 & 1) * 2 + (kg16 >> 1)) * 16 : h * 16);
   }
   const int lane16 = lane * 16;
   int c = 0;
@@ -288,78 +349,147 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
   };
 
   // ======================= stage A: [64 + 32*C3T] x (9 * Cin) x region-1 pixels =======================
-  floatx16 accA[RT][PA];
+  if constexpr (A16) {
+    floatx4 accA[2 * RT][PA];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const floatx16 b = bias16(a.biasA + rt * 32 + h * 16);
+    for (int t = 0; t < RT; ++t) {   // row tiles 2t, 2t+1 hold channels 32t + 8 kg + {0..3}, {4..7} of this lane's pixel
+      const floatx4 b0 = *reinterpret_cast<const floatx4*>(a.biasA + 32 * t + 8 * kg16);
+      const floatx4 b1 = *reinterpret_cast<const floatx4*>(a.biasA + 32 * t + 8 * kg16 + 4);
 #pragma unroll
-    for (int p = 0; p < PA; ++p) accA[rt][p] = b;
-  }
-  {
-    // K offset of the running step = (tap row * RWin + tap column) pixels + channel-group pair, kept incrementally
-    int cg = 0, dx = 0, boff_run = 0;
-    const int d_tap = SPin * 16 - 32 * (KPT - 1), d_row = (RWin - 2) * SPin * 16 - 32 * (KPT - 1);
-    auto next_boff = [&]() {
-      const int boff = boff_run;
-      if (++cg == KPT) {
-        cg = 0;
-        if (++dx == 3) { dx = 0; boff_run += d_row; } else boff_run += d_tap;
-      } else {
-        boff_run += 32;
-      }
-      return boff;
-    };
-    // stream = A chunks | box-B chunks | class-B chunks | 1 C
-    const int ncA = nch - (36 / (SLOTF / 2)) - (C3T == 2 ? 36 / (SLOTF / 2) : 18 / (SLOTF >= 18 ? 18 : 6)) - (SLOTF == 8 ? 2 : 1);
-    half8 af[2][RT], bf[2][PA];
-    if constexpr (KSA % 2 == 0) {   // one operand pipeline over all of stage A (ncA >= 2, host-checked)
-      wsource(c + 2);
-      kchunk<RT, PA, KSA, true, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
-      HD_STAMP(3)
-      for (++c; c < ncA - 1; ++c) {
+      for (int p = 0; p < PA; ++p) { accA[2 * t][p] = b0; accA[2 * t + 1][p] = b1; }
+    }
+    {
+      // K step = (tap, 32-channel block): KPT / 2 steps per tap, the byte offset kept incrementally
+      int cg = 0, dx = 0, boff_run = 0;
+      const int SPT = KPT >> 1;
+      const int d_tap = SPin * 16 - 64 * (SPT - 1), d_row = (RWin - 2) * SPin * 16 - 64 * (SPT - 1);
+      auto next_boff = [&]() {
+        const int boff = boff_run;
+        if (++cg == SPT) {
+          cg = 0;
+          if (++dx == 3) { dx = 0; boff_run += d_row; } else boff_run += d_tap;
+        } else {
+          boff_run += 64;
+        }
+        return boff;
+      };
+      half8 af[2][RT], bf[2][PA];
+      constexpr int NCA = 9;   // one tap per chunk (host-checked: KSA / 2 = KPT / 2 K steps)
+      static_for<0, NCA>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
         wsource(c + 2);
-        kchunk<RT, PA, KSA, false, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
-      }
-      wsource(c + 2);
-      kchunk<RT, PA, KSA, false, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
-      ++c;
-    } else {
-      for (; c < ncA; ++c) {
-        wsource(c + 2);
-        kchunk<RT, PA, KSA, true, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
-        if (c == 0) { HD_STAMP(3) }
+        kchunkA16<RT, PA, KSA, i == 0, i == NCA - 1, (i * (KSA / 2)) & 1, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf);
+        if (i == 0) { HD_STAMP(3) }
+        ++c;
+      });
+    }
+    HD_STAMP(4)
+    if (a.flags & 1) __builtin_amdgcn_s_setprio(0);
+    if (a.flags & 2) __builtin_amdgcn_s_setprio(1);
+    // ---- SiLU, fp16, -> MID: this lane holds channels 32t + 8 kg .. + 7 of its pixel in row tiles 2t | 2t+1: one 16-byte store each
+    {
+      if (OVL) lds_barrier();   // MID overlays the input tile: every wave has read its last stage-A operands
+      const bool interior = oy0 >= 1 && ox0 >= 1 && oy0 + TH + 1 <= a.H && ox0 + TW + 1 <= a.W;  // block-uniform
+#pragma unroll
+      for (int p = 0; p < PA; ++p) {
+        const int pt = wave + 4 * p;
+        const int idx = 16 * pt + sig16;
+        if (pt < nA && idx < R1) {
+          bool inside = true;
+          if (!interior) {
+            const int ry = idx / RW1, rx = idx - ry * RW1;
+            const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
+            inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+          }
+          char* dst = MID + idx * SPM * 16 + kg16 * 16;
+#pragma unroll
+          for (int t = 0; t < RT; ++t) {
+            const floatx2 y0 = hd_silu2(floatx2{accA[2 * t][p][0], accA[2 * t][p][1]}), y1 = hd_silu2(floatx2{accA[2 * t][p][2], accA[2 * t][p][3]});
+            const floatx2 y2 = hd_silu2(floatx2{accA[2 * t + 1][p][0], accA[2 * t + 1][p][1]}), y3 = hd_silu2(floatx2{accA[2 * t + 1][p][2], accA[2 * t + 1][p][3]});
+            half8 q = {(half_t)y0[0], (half_t)y0[1], (half_t)y1[0], (half_t)y1[1], (half_t)y2[0], (half_t)y2[1], (half_t)y3[0], (half_t)y3[1]};
+            if (!inside) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) q[j] = (half_t)0.f;
+            }
+            *reinterpret_cast<half8*>(dst + t * 64) = q;
+          }
+        }
       }
     }
-  }
-  HD_STAMP(4)
-  if (a.flags & 1) __builtin_amdgcn_s_setprio(0);
-  if (a.flags & 2) __builtin_amdgcn_s_setprio(1);
-  // ---- SiLU, fp16, -> MID (zero outside the image: stage B's padding).  The weight rows are permuted at pack time
-  //      so that this lane holds channels 32*rt + 16*h .. +15 of its pixel: two 16-byte stores per row tile.
-  {
-    if (OVL) lds_barrier();   // MID overlays the input tile: every wave has read its last stage-A operands
-    const bool interior = oy0 >= 1 && ox0 >= 1 && oy0 + TH + 1 <= a.H && ox0 + TW + 1 <= a.W;  // block-uniform
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int pt = wave + 4 * p;
-      const int idx = 32 * pt + r;
-      if (pt < nA && idx < R1) {
-        bool inside = true;
-        if (!interior) {
-          const int ry = idx / RW1, rx = idx - ry * RW1;
-          const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
-          inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+  } else {
+    floatx16 accA[RT][PA];
+  #pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const floatx16 b = bias16(a.biasA + rt * 32 + h * 16);
+  #pragma unroll
+      for (int p = 0; p < PA; ++p) accA[rt][p] = b;
+    }
+    {
+      // K offset of the running step = (tap row * RWin + tap column) pixels + channel-group pair, kept incrementally
+      int cg = 0, dx = 0, boff_run = 0;
+      const int d_tap = SPin * 16 - 32 * (KPT - 1), d_row = (RWin - 2) * SPin * 16 - 32 * (KPT - 1);
+      auto next_boff = [&]() {
+        const int boff = boff_run;
+        if (++cg == KPT) {
+          cg = 0;
+          if (++dx == 3) { dx = 0; boff_run += d_row; } else boff_run += d_tap;
+        } else {
+          boff_run += 32;
         }
-        char* dst = MID + idx * SPM * 16 + h * 32;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          half8 q0 = silu_h8(accA[rt][p], 0), q1 = silu_h8(accA[rt][p], 8);
-          if (!inside) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { q0[j] = (half_t)0.f; q1[j] = (half_t)0.f; }
+        return boff;
+      };
+      // stream = A chunks | box-B chunks | class-B chunks | 1 C
+      const int ncA = nch - (36 / (SLOTF / 2)) - (C3T == 2 ? 36 / (SLOTF / 2) : 18 / (SLOTF >= 18 ? 18 : 6)) - (SLOTF == 8 ? 2 : 1);
+      half8 af[2][RT], bf[2][PA];
+      if constexpr (KSA % 2 == 0) {   // one operand pipeline over all of stage A (ncA >= 2, host-checked)
+        wsource(c + 2);
+        kchunk<RT, PA, KSA, true, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
+        HD_STAMP(3)
+        for (++c; c < ncA - 1; ++c) {
+          wsource(c + 2);
+          kchunk<RT, PA, KSA, false, false, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
+        }
+        wsource(c + 2);
+        kchunk<RT, PA, KSA, false, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
+        ++c;
+      } else {
+        for (; c < ncA; ++c) {
+          wsource(c + 2);
+          kchunk<RT, PA, KSA, true, true, SLOTF>(RING, c, lane16, IN, pixA, next_boff, ring_side, accA, af, bf, f7_0, f7_1);
+          if (c == 0) { HD_STAMP(3) }
+        }
+      }
+    }
+    HD_STAMP(4)
+    if (a.flags & 1) __builtin_amdgcn_s_setprio(0);
+    if (a.flags & 2) __builtin_amdgcn_s_setprio(1);
+    // ---- SiLU, fp16, -> MID (zero outside the image: stage B's padding).  The weight rows are permuted at pack time
+    //      so that this lane holds channels 32*rt + 16*h .. +15 of its pixel: two 16-byte stores per row tile.
+    {
+      if (OVL) lds_barrier();   // MID overlays the input tile: every wave has read its last stage-A operands
+      const bool interior = oy0 >= 1 && ox0 >= 1 && oy0 + TH + 1 <= a.H && ox0 + TW + 1 <= a.W;  // block-uniform
+  #pragma unroll
+      for (int p = 0; p < PA; ++p) {
+        const int pt = wave + 4 * p;
+        const int idx = 32 * pt + r;
+        if (pt < nA && idx < R1) {
+          bool inside = true;
+          if (!interior) {
+            const int ry = idx / RW1, rx = idx - ry * RW1;
+            const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
+            inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
           }
-          *reinterpret_cast<half8*>(dst + rt * 64) = q0;
-          *reinterpret_cast<half8*>(dst + rt * 64 + 16) = q1;
+          char* dst = MID + idx * SPM * 16 + h * 32;
+  #pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            half8 q0 = silu_h8(accA[rt][p], 0), q1 = silu_h8(accA[rt][p], 8);
+            if (!inside) {
+  #pragma unroll
+              for (int j = 0; j < 8; ++j) { q0[j] = (half_t)0.f; q1[j] = (half_t)0.f; }
+            }
+            *reinterpret_cast<half8*>(dst + rt * 64) = q0;
+            *reinterpret_cast<half8*>(dst + rt * 64 + 16) = q1;
+          }
         }
       }
     }
@@ -594,23 +724,28 @@ static size_t head_lds(int th, int tw, int kpt, int c3t, int slotf, int ovl) {
 // slots 64 bytes short of 8 KiB (the LDS granule is 1280 B: 42 granules = 53,760 B per workgroup is the limit, measured with
 // tools/ubench/lds_occupancy.hip; MID + two whole slots would be 53,824), the projections as two chunks, and 168 registers --
 // reached by requesting what only the decode needs (anchors, geometry, DFL weights) after stage A instead of before it.
-struct HeadCfg { int c3t, kpt, th, tw, pa, pb, npc, ksa, slotf, ovl; };
+struct HeadCfg { int c3t, kpt, th, tw, pa, pb, npc, ksa, slotf, ovl, a16; };
+// a16 (round 4): stage A on 16x16x32 MFMAs -- pa counts 16-pixel tiles per wave, ksa half-steps per chunk (one tap per chunk)
 static const HeadCfg kHeadCfg[] = {
-    {1, 2, 8, 16, 2, 1, 2, 2, 8, 1},     // v1 P3: Cin 32, THREE workgroups per CU
-    {1, 2, 8, 16, 2, 1, 2, 2, 12, 0},    // v1 P3: Cin 32, two workgroups per CU (LITEPI_HEAD_2WG=1)
-    {1, 2, 16, 16, 3, 2, 2, 6, 24, 0},   // v1 P3: Cin 32
-    {1, 4, 10, 20, 3, 2, 4, 4, 12, 1},   // v1 P4: Cin 64, TWO workgroups per CU (MID over the input tile: 79.5 KB)
-    {1, 4, 10, 20, 3, 2, 4, 6, 24, 0},   // v1 P4: Cin 64 (LITEPI_HEAD_2WG=1 / LITEPI_HEAD_1WG=1)
-    {1, 8, 10, 10, 2, 1, 4, 8, 24, 0},   // v1 P5: Cin 128 (256 workgroups: the overlay shape at 76 KB changed nothing end to end)
-    {2, 3, 10, 20, 3, 2, 3, 3, 24, 0},   // v2 P3: Cin 48
-    {2, 6, 10, 10, 2, 1, 3, 6, 24, 0},   // v2 P4: Cin 96
-    {2, 12, 8, 8, 1, 1, 5, 6, 24, 0},    // v2 P5: Cin 192
+    {1, 2, 8, 16, 3, 1, 2, 2, 8, 1, 1},      // v1 P3: Cin 32, THREE workgroups per CU, stage A on 16-pixel tiles (12 for 180 pixels)
+    {1, 4, 10, 20, 5, 2, 4, 4, 12, 1, 1},    // v1 P4: Cin 64, TWO workgroups per CU, 17 tiles of 16 for 264 pixels
+    {1, 8, 10, 10, 3, 1, 4, 8, 24, 0, 1},    // v1 P5: Cin 128, 9 tiles of 16 for 144 pixels
+    {1, 2, 8, 16, 2, 1, 2, 2, 8, 1, 0},      // v1 P3, round 3's shape: stage A on 32-pixel slots (LITEPI_HEAD_A32=1)
+    {1, 2, 8, 16, 2, 1, 2, 2, 12, 0, 0},     // v1 P3: Cin 32, two workgroups per CU (LITEPI_HEAD_2WG=1)
+    {1, 2, 16, 16, 3, 2, 2, 6, 24, 0, 0},    // v1 P3: Cin 32
+    {1, 4, 10, 20, 3, 2, 4, 4, 12, 1, 0},    // v1 P4: Cin 64, TWO workgroups per CU (MID over the input tile: 79.5 KB)
+    {1, 4, 10, 20, 3, 2, 4, 6, 24, 0, 0},    // v1 P4: Cin 64 (LITEPI_HEAD_2WG=1 / LITEPI_HEAD_1WG=1)
+    {1, 8, 10, 10, 2, 1, 4, 8, 24, 0, 0},    // v1 P5: Cin 128 (256 workgroups: the overlay shape at 76 KB changed nothing end to end)
+    {2, 3, 10, 20, 3, 2, 3, 3, 24, 0, 0},    // v2 P3: Cin 48
+    {2, 6, 10, 10, 2, 1, 3, 6, 24, 0, 0},    // v2 P4: Cin 96
+    {2, 12, 8, 8, 1, 1, 5, 6, 24, 0, 0},     // v2 P5: Cin 192
 };
 static const HeadCfg* find_cfg(int c3t, int kpt) {
   static const bool one_wg = getenv("LITEPI_HEAD_1WG") != nullptr;   // A/B switches: the 16 x 16 one-workgroup shape,
-  static const bool two_wg = getenv("LITEPI_HEAD_2WG") != nullptr;   // the two-workgroup shape of round 2
+  static const bool two_wg = getenv("LITEPI_HEAD_2WG") != nullptr;   // the two-workgroup shape of round 2,
+  static const bool a32 = getenv("LITEPI_HEAD_A32") != nullptr;      // round 3's stage A (32-pixel slots)
   for (auto& c : kHeadCfg)
-    if (c.c3t == c3t && c.kpt == kpt && !(one_wg && c.slotf <= 12) && !(c.ovl && two_wg)) return &c;
+    if (c.c3t == c3t && c.kpt == kpt && !(one_wg && c.slotf <= 12) && !(c.ovl && two_wg) && !(c.a16 && (a32 || one_wg || two_wg))) return &c;
   return nullptr;
 }
 
@@ -627,17 +762,20 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   KPT = Cin / 16;
   const HeadCfg* cfg = find_cfg(C3T, KPT);
   LP_CHECK(cfg, LP_ERR_STATE, "Detect head %s: no kernel configuration for Cin %d", name.c_str(), Cin);
-  TH = cfg->th; TW = cfg->tw; PA = cfg->pa; PB = cfg->pb; NPC = cfg->npc; KSA = cfg->ksa; SLOTF = cfg->slotf; OVL = cfg->ovl;
+  TH = cfg->th; TW = cfg->tw; PA = cfg->pa; PB = cfg->pb; NPC = cfg->npc; KSA = cfg->ksa; SLOTF = cfg->slotf; OVL = cfg->ovl; A16 = cfg->a16;
   lds_bytes = head_lds(TH, TW, KPT, C3T, SLOTF, OVL);
   const int RT = 2 + C3T, CM = 32 * C3T;
   // chunks hold at most 24 fragments (one ring slot): stage A KSA K steps x RT row tiles, stage B box 12 x 2, class 18 x 1
   // (12 x 2 for two class row tiles), projections 10 (12)
   LP_CHECK(KSA % 2 != 0 || 9 * KPT / KSA >= 2, LP_ERR_STATE, "Detect head %s: stage A needs two chunks", name.c_str());
+  if (A16)   // one tap per chunk: KSA half-steps = KPT / 2 K steps of 32 channels x two row halves; fragment 7 of an 8-fragment slot is not addressable
+    LP_CHECK(KPT % 2 == 0 && KSA == KPT && RT * KSA <= (SLOTF == 8 ? 7 : SLOTF) && (TH + 2) * (TW + 2) <= 64 * PA, LP_ERR_STATE,
+             "Detect head %s: inconsistent 16-pixel-tile configuration", name.c_str());
   LP_CHECK(lds_bytes <= (SLOTF == 8 ? 53760u : (SLOTF == 12 ? 80u * 1024 : 160u * 1024)) && ((TW + 4) * (2 * KPT + 1) + 63) / 64 == NPC &&
-               (9 * KPT) % KSA == 0 && RT * KSA <= SLOTF && TH + 4 <= (SLOTF <= 12 && !(OVL && SLOTF == 12) ? 12 : (OVL ? 16 : 20)) &&
+               (A16 || ((9 * KPT) % KSA == 0 && RT * KSA <= SLOTF)) && TH + 4 <= (SLOTF <= 12 && !(OVL && SLOTF == 12) ? 12 : (OVL ? 16 : 20)) &&
                (SLOTF == 8 || SLOTF == 12 || SLOTF == 24) &&
                (SLOTF == 8 ? C3T == 1 : 8 + 2 * C3T <= SLOTF) &&
-               (TH + 2) * (TW + 2) <= 128 * PA && TH * TW <= 128 * PB, LP_ERR_STATE, "Detect head %s: inconsistent configuration", name.c_str());
+               (A16 || (TH + 2) * (TW + 2) <= 128 * PA) && TH * TW <= 128 * PB, LP_ERR_STATE, "Detect head %s: inconsistent configuration", name.c_str());
   (void)batch_hint;
   std::vector<uint16_t> stream;
   auto frag = [&](auto&& weight_of) {  // weight_of(row rho, k element e of the K step) -> float; appends one 1 KiB fragment
@@ -656,8 +794,37 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
     stream.resize((size_t)(coff.back() + SLOTF) * 512, 0);   // every chunk is a whole slot image
   };
   const std::vector<float>& wa = *s.wa;  // [64 + c3][9][Cin]
+  // ---- stage A on 16x16x32 MFMAs: chunk = tap; K step (tap, q) covers input channels 32 q .. 32 q + 31; per K step two half-steps
+  //      of RT row tiles (16 rows each).  Fragment lane l: row l & 15 of the tile, K group kg = l >> 4 = channel slot gam(kg) =
+  //      {0, 2, 1, 3} of the step's four (the kernel's pixel fragments read the same slot order: conflict-free LDS reads).  Row r
+  //      of row tile R (= rh * RT + rt) is physical MID channel 32 (R >> 1) + 8 (r >> 2) + 4 (R & 1) + (r & 3): a lane's D
+  //      registers of tiles 2t | 2t+1 are then 8 consecutive channels of one pixel -> one 16-byte MID store.
+  auto frag16 = [&](auto&& weight_of) {  // weight_of(row r, k element e of the 32) -> float; appends one 1 KiB fragment
+    const size_t base = stream.size();
+    stream.resize(base + 512);
+    for (int lane = 0; lane < 64; ++lane)
+      for (int j = 0; j < 8; ++j) {
+        const int kg = lane >> 4, slot = (kg & 1) * 2 + (kg >> 1);
+        stream[base + lane * 8 + j] = f32_to_f16(weight_of(lane & 15, 8 * slot + j));
+      }
+  };
+  if (A16) {
+    for (int tap = 0; tap < 9; ++tap) {
+      begin_chunk();
+      for (int q = 0; q < KPT / 2; ++q)
+        for (int rh = 0; rh < 2; ++rh)
+          for (int rt = 0; rt < RT; ++rt)
+            frag16([&](int r, int e) {
+              const int R = rh * RT + rt;
+              const int c = 32 * (R >> 1) + 8 * (r >> 2) + 4 * (R & 1) + (r & 3);   // physical MID channel
+              const int src = c < 64 ? c : (c - 64 < c3 ? 64 + (c - 64) : -1);
+              return src < 0 ? 0.f : wa[((size_t)src * 9 + tap) * Cin + 32 * q + e];
+            });
+      end_chunk(KSA);
+    }
+  }
   // ---- stage A: K step (tap, cg): element e = input channel 16*cg + e
-  for (int ks = 0; ks < 9 * KPT; ++ks) {
+  for (int ks = 0; ks < (A16 ? 0 : 9 * KPT); ++ks) {
     if (ks % KSA == 0) begin_chunk();
     const int tap = ks / KPT, cg = ks % KPT;
     for (int rt = 0; rt < RT; ++rt)
@@ -766,7 +933,15 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_>), 160 * 1024); \
     LP_LAUNCH((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_>), grid, dim3(256), lds_bytes, st, a);                 \
   }
-  if (C3T == 1 && KPT == 2 && SLOTF == 8) LP_HEAD(1, 2, 1, 2, 2, 8, 3)
+#define LP_HEAD16(C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_)                                                                               \
+  {                                                                                                                                          \
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_, true>), 160 * 1024); \
+    LP_LAUNCH((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_, true>), grid, dim3(256), lds_bytes, st, a);                 \
+  }
+  if (A16 && KPT == 2) LP_HEAD16(1, 3, 1, 2, 2, 8, 3, true)
+  else if (A16 && KPT == 4) LP_HEAD16(1, 5, 2, 4, 4, 12, 4, true)
+  else if (A16 && KPT == 8) LP_HEAD16(1, 3, 1, 4, 8, 24, 5, false)
+  else if (C3T == 1 && KPT == 2 && SLOTF == 8) LP_HEAD(1, 2, 1, 2, 2, 8, 3)
   else if (C3T == 1 && KPT == 2 && SLOTF == 12) LP_HEAD(1, 2, 1, 2, 2, 12, 3)
   else if (C3T == 1 && KPT == 2) LP_HEAD(1, 3, 2, 2, 6, 24, 5)
   else if (C3T == 1 && KPT == 4 && SLOTF == 12) LP_HEAD2(1, 3, 2, 4, 4, 12, 4, true)
@@ -778,6 +953,7 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
   else throw Error(LP_ERR_STATE, "Detect head: no kernel configuration");
 #undef LP_HEAD
 #undef LP_HEAD2
+#undef LP_HEAD16
   LP_HIP(hipGetLastError());
   if (a.stamps) {  // diagnostic: dump [grid][16] stamps, one record per launch
     LP_HIP(hipStreamSynchronize(st));

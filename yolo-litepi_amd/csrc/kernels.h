@@ -85,6 +85,7 @@ struct NmsArgs {
   RoiTable tab;           // tab.total == nullptr: no ROI list
   int max_rois;
   int roi_rule;           // 0: e2e.py:465-473, 1: e2e_optimize.py:480-497 (lp_config::numerics)
+  int no_small;           // A/B + tests (LITEPI_NMS_NO_SMALL=1): every image takes the general path
 };
 // per-class greedy NMS (e2e.py:89-119,280-296) + ROI clip / area filter (e2e.py:465-473) + the batch's ROI list
 void launch_nms(const NmsArgs& a, int N, hipStream_t st);
