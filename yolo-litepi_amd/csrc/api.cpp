@@ -4,8 +4,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
 #include <mutex>
 #include <set>
+#include <thread>
 
 #include "classifier.h"
 #include "mbnet.h"
@@ -104,8 +108,79 @@ static ImgGeom make_geom(int h, int w, int S, long src_off) {
 
 using namespace lp;
 
+// Host-side upload path of the drop-in entry points (lp_run_batch / lp_detect: the caller's images are ordinary pageable
+// NumPy arrays).  A pageable hipMemcpyAsync is staged by the runtime through its own small pinned buffers, one image after
+// the other: 24 GB/s of the link's 55.  Here a few worker threads copy groups of images into a pinned staging buffer of the
+// handle while the DMA of the previous group runs (hipMemcpyAsync from pinned memory returns at once), so that the upload
+// runs at the slower of {parallel memcpy, PCIe} instead of their sum.
+class CopyPool {
+ public:
+  struct Job { const uint8_t* src; uint8_t* dst; size_t bytes; };
+  explicit CopyPool(int n) {
+    for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  // copies every job (the calling thread takes part); returns when all are done
+  void run(const Job* jobs, int n) {
+    if (n <= 0) return;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      jobs_ = jobs; njobs_ = n; next_.store(0); done_ = 0; ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> l(m_);
+    cv_done_.wait(l, [&] { return done_ == njobs_; });
+    jobs_ = nullptr; njobs_ = 0;
+  }
+
+ private:
+  void work() {
+    int mine = 0;
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= njobs_) break;
+      memcpy(jobs_[i].dst, jobs_[i].src, jobs_[i].bytes);
+      ++mine;
+    }
+    if (mine) {
+      std::lock_guard<std::mutex> l(m_);
+      done_ += mine;
+      if (done_ == njobs_) cv_done_.notify_all();
+    }
+  }
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, cv_done_;
+  const Job* jobs_ = nullptr;
+  int njobs_ = 0, done_ = 0;
+  std::atomic<int> next_{0};
+  unsigned long gen_ = 0;
+  bool stop_ = false;
+};
+
 struct lp_handle {
   lp_config cfg;
+  // pinned staging of the host entry points + the copy workers (created on first use)
+  uint8_t* h_stage = nullptr;
+  size_t h_stage_bytes = 0;
+  std::unique_ptr<CopyPool> pool;
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::unique_ptr<Detector> det;
   std::unique_ptr<ClassifierBase> cls;
@@ -264,6 +339,8 @@ void lp_destroy(lp_handle* h) {
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  h->pool.reset();
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
   delete h;
 }
 
@@ -493,8 +570,40 @@ std::vector<ImgGeom> upload_images(lp_handle* h, const uint8_t* const* imgs, con
     total = (total + 15) & ~(size_t)15;
   }
   h->ensure_src(total);
-  for (int i = 0; i < B; ++i)
-    LP_HIP(hipMemcpyAsync(h->d_src.as<uint8_t>() + g[i].src_off, imgs[i], (size_t)hs[i] * ws[i] * 3, hipMemcpyHostToDevice, h->stream));
+  // small uploads (a single frame: the batch-1 latency path) go straight from the caller's memory
+  static const int n_threads = getenv("LITEPI_UPLOAD_THREADS") ? atoi(getenv("LITEPI_UPLOAD_THREADS")) : 8;
+  if (n_threads <= 0 || B < 4 || total < ((size_t)4 << 20)) {
+    for (int i = 0; i < B; ++i)
+      LP_HIP(hipMemcpyAsync(h->d_src.as<uint8_t>() + g[i].src_off, imgs[i], (size_t)hs[i] * ws[i] * 3, hipMemcpyHostToDevice, h->stream));
+    return g;
+  }
+  if (h->h_stage_bytes < total) {
+    if (h->h_stage) { LP_HIP(hipStreamSynchronize(h->stream)); (void)hipHostFree(h->h_stage); h->h_stage = nullptr; h->h_stage_bytes = 0; }
+    LP_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), total + total / 4, hipHostMallocDefault));
+    h->h_stage_bytes = total + total / 4;
+  }
+  if (!h->pool) h->pool.reset(new CopyPool(n_threads - 1));
+  // (the previous call synchronised the stream before it returned: the staging buffer is free)
+  // groups of about 10 MB: the workers fill group k+1 while the DMA engine moves group k; an image larger than that is split
+  // into slices so that every worker has a share
+  std::vector<CopyPool::Job> jobs;
+  const size_t group_bytes = (size_t)10 << 20, slice = (size_t)1 << 20;
+  int i0 = 0;
+  while (i0 < B) {
+    int i1 = i0;
+    size_t gb = 0;
+    jobs.clear();
+    while (i1 < B && (i1 == i0 || gb + (size_t)hs[i1] * ws[i1] * 3 <= group_bytes)) {
+      const size_t nb = (size_t)hs[i1] * ws[i1] * 3;
+      for (size_t o = 0; o < nb; o += slice) jobs.push_back({imgs[i1] + o, h->h_stage + g[i1].src_off + o, std::min(slice, nb - o)});
+      gb += nb;
+      ++i1;
+    }
+    h->pool->run(jobs.data(), (int)jobs.size());
+    const size_t lo = (size_t)g[i0].src_off, hi = (size_t)g[i1 - 1].src_off + (size_t)hs[i1 - 1] * ws[i1 - 1] * 3;
+    LP_HIP(hipMemcpyAsync(h->d_src.as<uint8_t>() + lo, h->h_stage + lo, hi - lo, hipMemcpyHostToDevice, h->stream));
+    i0 = i1;
+  }
   return g;
 }
 

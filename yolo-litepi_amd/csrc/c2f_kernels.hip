@@ -961,9 +961,9 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
 // ---- stand-alone 3x3 stride-2 conv + SiLU (the downsampling convs between the modules, model.ncnn.param:41,118): one
 //      workgroup per 20 x 20 output tile, the weights staged once in LDS, the pixel operand gathered from global memory
 //      (every input pixel is touched by 2.25 taps on average; the tile's neighbours share them through L1 / L2).
-template <int CIN_, int COUT_>
+template <int CIN_, int COUT_, int TH_ = 20>
 struct S2Cfg {
-  static constexpr int KS2 = CIN_, COUT = COUT_, NW = 8, TH = 20, TW = 20, F = 0, WPS = 2, C = 32;
+  static constexpr int KS2 = CIN_, COUT = COUT_, NW = 8, TH = TH_, TW = 20, F = 0, WPS = 2, C = 32;
   static constexpr int CT = COUT / 16, NT = min_c(CT, 4), CB = CT / NT, PT = cdiv_c(cdiv_c(TH * TW, 16), NW / CB);
   static constexpr int WBYTES = CT * 9 * (KS2 / 32) * 1024;
 };
@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2conv_kernel(const C2fArgs a
   C2F_STAMP(15)
 }
 typedef S2Cfg<32, 64> S2Cfg32x64;   // model.ncnn.param:41 (conv_15: 32 -> 64 @40x40) and :118 (conv_37)
+typedef S2Cfg<32, 64, 10> S2Cfg32x64h;   // half-height tiles: twice the workgroups (A/B: LITEPI_S2C_TH10=1)
 
 // ---- instantiated configurations (YOLO-LitePi v1 widths; model.ncnn.param line of the module's cv1) ----------------------
 typedef C2fCfg<32, 1, 128, 64, true, 64, 0, 0> CfgNeck40;    // :90  up(P5) | P4 -> C2f(n=1) @40x40
@@ -1196,12 +1197,19 @@ void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st)
   a.x = out.base; a.x_pitch = out.pitch;
   a.w[C2F_W_S2] = d_w.p; a.b[C2F_W_S2] = d_b.as<float>();
   a.N = N; a.H = H; a.W = W;
-  a.tiles_x = W / 20; a.tiles_y = H / 20;
+  static const bool th10 = getenv("LITEPI_S2C_TH10") != nullptr;
+  const bool half = th10 && H % 10 == 0;
+  a.tiles_x = W / 20; a.tiles_y = half ? H / 10 : H / 20;
   typedef S2Cfg32x64 CFG;
   static const char* stamp_file = getenv("LITEPI_C2F_STAMPS");
   if (stamp_file) a.stamps = stamp_buffer((size_t)N * a.tiles_x * a.tiles_y);
-  set_max_dynamic_lds(reinterpret_cast<const void*>(&s2conv_kernel<CFG>), CFG::WBYTES);
-  LP_LAUNCH(s2conv_kernel<CFG>, dim3(N * a.tiles_x * a.tiles_y), dim3(CFG::NW * 64), CFG::WBYTES, st, a);
+  if (half) {
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&s2conv_kernel<S2Cfg32x64h>), CFG::WBYTES);
+    LP_LAUNCH(s2conv_kernel<S2Cfg32x64h>, dim3(N * a.tiles_x * a.tiles_y), dim3(CFG::NW * 64), CFG::WBYTES, st, a);
+  } else {
+    set_max_dynamic_lds(reinterpret_cast<const void*>(&s2conv_kernel<CFG>), CFG::WBYTES);
+    LP_LAUNCH(s2conv_kernel<CFG>, dim3(N * a.tiles_x * a.tiles_y), dim3(CFG::NW * 64), CFG::WBYTES, st, a);
+  }
   LP_HIP(hipGetLastError());
   if (stamp_file) dump_stamps(stamp_file, name, (size_t)N * a.tiles_x * a.tiles_y, st);
 }

@@ -28,7 +28,7 @@ struct HeadArgs {
   int KPT;                 // K steps (of 16 channels) per 3x3 tap of the first convs = Cin / 16
   int nchunks;             // weight-stream chunks
   int A, nc, anchor_off;
-  int flags;               // experiment switches (LITEPI_HEAD_FLAGS): 1 = s_setprio 1 in the K loops, 2 = s_setprio 1 in the epilogues, 4 = first-round stagger
+  int flags;               // experiment switches (LITEPI_HEAD_FLAGS): 1 = s_setprio 1 in the K loops, 2 = s_setprio 1 in the epilogues
   unsigned long long* stamps;  // diagnostic only (LITEPI_HEAD_STAMPS=<file>): 16 clock stamps per workgroup
 };
 

@@ -245,11 +245,6 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
   const char* wstream = reinterpret_cast<const char*>(a.wstream) + lane * 16;
   const int nch = a.nchunks;
   HD_STAMP(0)
-  if ((a.flags & 4) && blockIdx.x < 768u) {   // experiment: de-lockstep the workgroups that start together on a CU
-    const unsigned slot = __builtin_amdgcn_s_getreg(6148) % 3u;   // HW_ID.WAVE_ID
-    const unsigned units = slot * ((unsigned)a.flags >> 8);        // flags >> 8: delay per slot in units of 512 cycles
-    for (unsigned i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);
-  }
   HD_STAMP(1)
 
   // ---- weight ring, two 24 KiB slots, filled THROUGH REGISTERS: a wave owns pieces wave, wave + 4, .. (six 1 KiB
@@ -260,6 +255,18 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
   //      wave could not hide behind its MFMAs; a global load + ds_write pair costs ~25.)  Piece indices past a chunk's end
   //      re-read its last fragment into the slot's unused tail: no control flow around the loads (see cls_net.hip for what
   //      that does to the register allocator).
+  // A16: the first convs' biases are requested in front of the tile (they initialise the accumulators right behind the prologue;
+  // requested there, their round trip stood between the prologue and the first MFMA)
+  const float bias_c0 = a.biasC[64];   // class 0's projection bias (the only one a one-class detector needs; used in stage C)
+  floatx4 biasA16[A16 ? 2 * RT : 1];
+  if constexpr (A16) {
+    const int kgb = (lane >> 4) * 8;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      biasA16[2 * t] = *reinterpret_cast<const floatx4*>(a.biasA + 32 * t + kgb);
+      biasA16[2 * t + 1] = *reinterpret_cast<const floatx4*>(a.biasA + 32 * t + kgb + 4);
+    }
+  }
   u32x4 wreg[NPW];
   // (every chunk occupies a whole 24 KiB slot image in the stream, two zero chunks follow the last one: the source of
   //  piece j of chunk c is wstream + c * 24 KiB + (wave + 4j) KiB -- no chunk table, no clamping, no scalar loads in the K loop)
@@ -348,15 +355,14 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
     wload1(j);
   };
 
+  floatx16 biasB_box[2], biasB_cls[C3T];
   // ======================= stage A: [64 + 32*C3T] x (9 * Cin) x region-1 pixels =======================
   if constexpr (A16) {
     floatx4 accA[2 * RT][PA];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {   // row tiles 2t, 2t+1 hold channels 32t + 8 kg + {0..3}, {4..7} of this lane's pixel
-      const floatx4 b0 = *reinterpret_cast<const floatx4*>(a.biasA + 32 * t + 8 * kg16);
-      const floatx4 b1 = *reinterpret_cast<const floatx4*>(a.biasA + 32 * t + 8 * kg16 + 4);
 #pragma unroll
-      for (int p = 0; p < PA; ++p) { accA[2 * t][p] = b0; accA[2 * t + 1][p] = b1; }
+      for (int p = 0; p < PA; ++p) { accA[2 * t][p] = biasA16[2 * t]; accA[2 * t + 1][p] = biasA16[2 * t + 1]; }
     }
     {
       // K step = (tap, 32-channel block): KPT / 2 steps per tap, the byte offset kept incrementally
@@ -386,6 +392,11 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
     HD_STAMP(4)
     if (a.flags & 1) __builtin_amdgcn_s_setprio(0);
     if (a.flags & 2) __builtin_amdgcn_s_setprio(1);
+    // (stage B's biases are requested here: their round trip runs under the SiLU epilogue instead of in front of stage B's first MFMA)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) biasB_box[rt] = bias16(a.biasB + rt * 32 + h * 16);
+#pragma unroll
+    for (int rt = 0; rt < C3T; ++rt) biasB_cls[rt] = bias16(a.biasB + 64 + rt * 32 + h * 16);
     // ---- SiLU, fp16, -> MID: this lane holds channels 32t + 8 kg .. + 7 of its pixel in row tiles 2t | 2t+1: one 16-byte store each
     {
       if (OVL) lds_barrier();   // MID overlays the input tile: every wave has read its last stage-A operands
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
   floatx16 accB[2][PB];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
-    const floatx16 b = bias16(a.biasB + rt * 32 + h * 16);
+    const floatx16 b = A16 ? biasB_box[rt] : bias16(a.biasB + rt * 32 + h * 16);
 #pragma unroll
     for (int p = 0; p < PB; ++p) accB[rt][p] = b;
   }
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
   floatx16 accC[C3T][PB];
 #pragma unroll
   for (int rt = 0; rt < C3T; ++rt) {
-    const floatx16 b = bias16(a.biasB + 64 + rt * 32 + h * 16);
+    const floatx16 b = A16 ? biasB_cls[rt] : bias16(a.biasB + 64 + rt * 32 + h * 16);
 #pragma unroll
     for (int p = 0; p < PB; ++p) accC[rt][p] = b;
   }
@@ -594,12 +605,7 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
     for (int q = 0; q < 2 * C3T; ++q) wcc[q] = lds_h8(wc + q * 1024);
 #pragma unroll
     for (int j = 0; j < NPW; ++j) wstore1(c + 1, j);
-    lds_barrier();
-    const char* wb = RING + ((c + 1) & 1) * SLOTB + lane16;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) wcb[rt][q] = lds_h8(rt * 4 + q == 7 ? (((c + 1) & 1) ? f7_1 : f7_0) : wb + (rt * 4 + q) * 1024);
+    lds_barrier();   // (publishes the box projection's slot: its fragments are read only where an anchor can pass, below)
   } else {
     lds_barrier();   // the projection chunk was stored behind the class tower's steps
     const char* wb = RING + (c & 1) * SLOT + lane16;
@@ -611,7 +617,16 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
     for (int q = 0; q < 2 * C3T; ++q) wcc[q] = lds_h8(wb + (8 + q) * 1024);
   }
   HD_STAMP(8)
-  const floatx16 bC0 = bias16(a.biasC + h * 16), bC1 = bias16(a.biasC + 32 + h * 16), bCc = bias16(a.biasC + 64 + h * 16);
+  // class bias: two wave-uniform 16-float rows (scalar loads, no vector-memory round trip in front of the projection) + a select
+  floatx16 bCc;
+  if (a.nc == 1) {   // wave-uniform: only logit 0 is ever looked at; its bias was requested at the top of the kernel
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bCc[i] = 0.f;
+    bCc[0] = bias_c0;
+  } else {
+    bCc = bias16(a.biasC + 64 + h * 16);
+  }
+  bool box_w_loaded = SLOTF != 8;
 #pragma unroll
   for (int p = 0; p < PB; ++p) {
     // B operands: element j of K step (mt, s) of this lane = channel 32*mt + 16*h + 8*s + j = accumulator register 8*s + j
@@ -625,16 +640,20 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
     // arg-max of the LOGITS (selects, no branches, no transcendentals), and one sigmoid gives its score.
     float bl = -INFINITY;
     int best_c = 0;
+    if (a.nc == 1) {   // wave-uniform: the one class (the reference's detectors) needs no arg-max
+      bl = h == 0 ? oc[0] : -INFINITY;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float v = (16 * h + i < a.nc) ? oc[i] : -INFINITY;
-      const bool up = v > bl;   // strict: the first maximum in class order stays
-      bl = up ? v : bl;
-      best_c = up ? 16 * h + i : best_c;
+      for (int i = 0; i < 16; ++i) {
+        const float v = (16 * h + i < a.nc) ? oc[i] : -INFINITY;
+        const bool up = v > bl;   // strict: the first maximum in class order stays
+        bl = up ? v : bl;
+        best_c = up ? 16 * h + i : best_c;
+      }
+      const float obl = __shfl_xor(bl, 32);
+      const int oc_ = __shfl_xor(best_c, 32);
+      if (h == 0 && obl > bl) { bl = obl; best_c = oc_; }   // the upper half wins only if larger
     }
-    const float obl = __shfl_xor(bl, 32);
-    const int oc_ = __shfl_xor(best_c, 32);
-    if (h == 0 && obl > bl) { bl = obl; best_c = oc_; }   // the upper half wins only if larger
     const float best = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(bl * -1.4426950408889634f));
     // ---- box projection + DFL decode only where it can matter: emit_candidate keeps an anchor iff best > conf (the same
     //      expression, so the kept set is identical), and a typical image has a handful of such anchors among 8400 -- the box
@@ -642,8 +661,16 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
     //      stage C's cycles.  Wave-uniform branch; the parity hook (out0) needs every anchor and takes it always.
     const bool pass = pvalid[p] && h == 0 && best > a.conf;
     if (a.out0 == nullptr && !__any(pass)) continue;
+    if (SLOTF == 8 && !box_w_loaded) {   // wave-uniform; a typical wave never gets here (no anchor of its tile can pass)
+      box_w_loaded = true;
+      const char* wb = RING + ((c + 1) & 1) * SLOTB + lane16;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wcb[rt][q] = lds_h8(rt * 4 + q == 7 ? (((c + 1) & 1) ? f7_1 : f7_0) : wb + (rt * 4 + q) * 1024);
+    }
     floatx16 ob[2];
-    ob[0] = bC0; ob[1] = bC1;
+    ob[0] = bias16(a.biasC + h * 16); ob[1] = bias16(a.biasC + 32 + h * 16);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
