@@ -20,7 +20,7 @@ def family(name):
     f16 = "_f16" if "DF16_" in name or "<f16" in name else "_f32"
     ints = [int(v) for v in re.findall(r"Li(\d+)E", name)]
     if "s2conv_kernel" in name:
-        m = re.search(r"S2Cfg<(\d+), *(\d+)>", name)
+        m = re.search(r"S2Cfg<(\d+), *(\d+)[,>]", name)
         v = [int(m.group(1)), int(m.group(2))] if m else [int(x) for x in re.findall(r"Li(\d+)E", name)][:2]
         return "s2conv<%d,%d>_f16" % tuple(v)
     if "c2f_kernel" in name:   # C2fCfg<C, NB, KA, KB, UP, COUT, MODE, KS2, TH, NW>: the profiler's name is CfgName of c2f_kernels.hip
@@ -39,9 +39,12 @@ def family(name):
     if "bottleneck_mfma_kernel" in name:   # <T, NT, P1, P2, SEP, T2, SG>: the profiler's name carries <NT,P1,P2,T2,SG>
         v = (ints + [0, 0, 0, 0, 0])[:5]
         return "bottleneck3x3x2<%d,%d,%d,%d,%d>" % tuple(v) + f16
-    if "head_fused_kernel" in name:
-        t = [int(x) for x in re.findall(r"\d+", name.split("head_fused_kernel", 1)[1].split(">", 1)[0])] if "<" in name else ints
-        return "head_fused<%s>_f16" % ",".join(str(x) for x in t[:6])
+    if "head_fused_kernel" in name:   # <C3T, PA, PB, NPC, KSA, SLOTF, NRW, OV, A16, NCA>: the profiler appends "a16" for A16 = true
+        args = name.split("head_fused_kernel", 1)[1].split(">", 1)[0] if "<" in name else ""
+        t = [int(x) for x in re.findall(r"\d+", args)] if args else ints
+        toks = [x.strip() for x in args.lstrip("<").split(",")] if args else []
+        a16 = (len(toks) > 8 and toks[8] == "true") or (not args and name.count("Lb1E") >= 1 and re.search(r"Lb[01]ELb1E", name) is not None)
+        return "head_fused<%s>%s_f16" % (",".join(str(x) for x in t[:6]), "a16" if a16 else "")
     if "conv3x3s2_direct_kernel" in name:   # <T, NT, NP, T2, U>
         t2 = ints[2] if len(ints) > 2 else 0
         return ("conv3x3s2_direct+1x1<%d,%d>" % (ints[0], t2) if t2 else "conv3x3s2_direct<%d>" % ints[0]) + f16
@@ -53,7 +56,7 @@ def family(name):
         return ("conv1x1_mfma<%d,up>" % ints[0] if ups else "conv1x1_mfma<%d>" % ints[0]) + f16
     if "stem_mfma_kernel" in name or "stem_conv" in name:
         return "stem_conv_f16" if "stem_mfma" in name else "stem_conv" + f16
-    for key, fam in (("stem_block_kernel", "stem_block_f16"), ("roi_resize_kernel", "roi_resize_pil"), ("shuffle_stage_kernel", "shuffle_stage_fused_f16"),
+    for key, fam in (("letterbox", "letterbox_u8"), ("stem_block_kernel", "stem_block_f16"), ("roi_resize_kernel", "roi_resize_pil"), ("shuffle_stage_kernel", "shuffle_stage_fused_f16"),
                      ("cls_head_kernel", "cls_head_fused_f16"), ("nms_kernel", "nms"), ("roi_index_kernel", "roi_index"),
                      ("cls_front_kernel", "cls_front_f16"), ("cls_back_kernel", "cls_back_f16"),
                      ("sppf_pool", "sppf_pool_f16")):

@@ -451,7 +451,7 @@ void enqueue_detect(lp_handle* h, const uint8_t* src, const std::vector<ImgGeom>
   const uint8_t* img = src;
   if (!identity) {
     if (prof) prof->begin(h->stream);
-    launch_letterbox(src, h->d_geom.as<ImgGeom>(), h->d_lb.as<uint8_t>(), B, S, h->stream);
+    launch_letterbox(src, h->d_geom.as<ImgGeom>(), h->d_lb.as<uint8_t>(), B, S, h->stream, geoms.data());
     if (prof) {
       double bytes = (double)B * S * S * 3;
       for (int i = 0; i < B; ++i) bytes += (double)geoms[i].h * geoms[i].w * 3;
@@ -1019,7 +1019,7 @@ int lp_test_letterbox(lp_handle* h, const uint8_t* img, int H, int W, uint8_t* o
   d_geom.alloc(sizeof(g));
   LP_HIP(hipMemcpy(d_geom.p, &g, sizeof(g), hipMemcpyHostToDevice));
   d_out.alloc((size_t)S * S * 3);
-  launch_letterbox(d_src.as<uint8_t>(), d_geom.as<ImgGeom>(), d_out.as<uint8_t>(), 1, S, h->stream);
+  launch_letterbox(d_src.as<uint8_t>(), d_geom.as<ImgGeom>(), d_out.as<uint8_t>(), 1, S, h->stream, &g);
   LP_HIP(hipStreamSynchronize(h->stream));
   LP_HIP(hipMemcpy(out, d_out.p, (size_t)S * S * 3, hipMemcpyDeviceToHost));
   if (ratio) *ratio = g.ratio;

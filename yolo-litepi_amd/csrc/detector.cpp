@@ -1195,12 +1195,12 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
       if (!ok) { all = false; break; }
       trips.push_back({oa, ob, oc, cc.Cin, oproj});
     }
-    // Two class row tiles (48-channel class towers, v2): the head kernel's tile shapes for these widths are correct
-    // (tests/test_gpu_parity.py runs them) but not yet faster end to end than the three-launch plan -- the kernel owns a
-    // CU's whole LDS, which costs the overlap with the other batches in flight -- so they are opt-in: LITEPI_HEADFUSE=all
-    if (all && !trips.empty() && trips[0].c3 > 32) {
+    // Two class row tiles (48-channel class towers, v2).  Rounds 2-3: correct but slower end to end than the three-launch plan
+    // (the kernel owned a CU's whole LDS), so opt-in.  Round 4: stage A on 16-pixel tiles, P3 and P4 at two workgroups per CU and
+    // a one-round P5 shape make it the faster plan (same-box A/B 53.4 k -> 54.2 k images/s, 53 -> 43 launches): default.
+    if (all && !trips.empty() && trips[0].c3 > 32) {   // (round 4: default; LITEPI_HEADFUSE=narrow restores the three-launch plan for A/B)
       const char* hf = getenv("LITEPI_HEADFUSE");
-      if (!hf || strcmp(hf, "all") != 0) all = false;
+      if (hf && strcmp(hf, "narrow") == 0) all = false;
     }
     if (all && trips.size() == levels_.size()) {
       std::vector<char> dead(ops_.size(), 0);
@@ -1343,7 +1343,7 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         heads_[op.conv]->launch(view(op.in), B, levels_[op.in2].off, A_, d_anchors_.as<float>(), d_strides_.as<float>(), d_dfl_.as<float>(), out0,
                                 geom, cand, cand_count, conf, st);
         kname = fmt("head_fused<%d,%d,%d,%d,%d,%d>", heads_[op.conv]->C3T, heads_[op.conv]->PA, heads_[op.conv]->PB, heads_[op.conv]->NPC,
-                    heads_[op.conv]->KSA, heads_[op.conv]->SLOTF) + (heads_[op.conv]->A16 ? "a16" : "") + sfx;   // = the leading template arguments of head_fused_kernel
+                    heads_[op.conv]->KSA, heads_[op.conv]->SLOTF) + (heads_[op.conv]->A16 ? (heads_[op.conv]->C3T == 2 ? fmt("a16k%d", heads_[op.conv]->KPT) : std::string("a16")) : std::string()) + sfx;   // = the leading template arguments of head_fused_kernel
         break;
     }
     if (prof) prof->end(st, kname, op.layer, op.flops * B, op.bytes * B);

@@ -214,7 +214,8 @@ __device__ __forceinline__ void kchunkA16(const char* ring, int c, int lane16, c
 // NPC: 64-slot pieces per input-tile row, KSA: K steps per stage-A chunk (both fixed by the level's tile shape, see host)
 // SLOTF: fragments per weight-ring slot (24; 12 for the two-workgroups-per-CU shape), NRW: input-tile rows per wave = ceil((TH+4)/4)
 // A16: stage A on 16x16x32 MFMAs (kchunkA16): PA = 16-pixel tiles per wave, KSA = half-steps per chunk (one tap per chunk)
-template <int C3T, int PA, int PB, int NPC, int KSA, int SLOTF, int NRW, bool OV = (SLOTF == 8), bool A16 = false>
+// NCA: stage-A chunks of the A16 path = 9 taps x ceil(Cin / 32) K steps / (KSA / 2) K steps per chunk
+template <int C3T, int PA, int PB, int NPC, int KSA, int SLOTF, int NRW, bool OV = (SLOTF == 8), bool A16 = false, int NCA = 9>
 __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void head_fused_kernel(const HeadArgs a) {
   // SLOTF == 8: THREE workgroups per CU -- MID overlays the input tile (dead after stage A's K loops: one more barrier), 8 KiB
   // ring slots (the projections are then two chunks), <= 168 registers: 54,272 B of LDS.
@@ -329,6 +330,8 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
       if (SLOTF == 8 && j == 1 && wave == 3) dst = const_cast<char*>(f7_0);
       *reinterpret_cast<u32x4*>(dst) = w0[j];
     }
+    // A16 with an odd KPT: the slot behind the tile's last pixel is read (against zero weights) by the last K step of a tap
+    if (A16 && (KPT & 1) && tid == 0) *reinterpret_cast<u32x4*>(IN + IHin * RSin * 16) = u32x4{0u, 0u, 0u, 0u};
   }
   HD_STAMP(2)
   if (a.flags & 1) __builtin_amdgcn_s_setprio(1);
@@ -365,9 +368,12 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
       for (int p = 0; p < PA; ++p) { accA[2 * t][p] = biasA16[2 * t]; accA[2 * t + 1][p] = biasA16[2 * t + 1]; }
     }
     {
-      // K step = (tap, 32-channel block): KPT / 2 steps per tap, the byte offset kept incrementally
+      // K step = (tap, 32-channel block): ceil(KPT / 2) steps per tap, the byte offset kept incrementally.  Cin = 16 (mod 32), v2's
+      // 48-channel P3: the last step of a tap reads one pixel's padding slot and the NEXT pixel's first slot as its channels
+      // Cin .. Cin + 15 -- their weights are zero (HeadLayer::build) and what is read is finite: activations, or the zeroed guard
+      // slot behind the tile's last pixel
       int cg = 0, dx = 0, boff_run = 0;
-      const int SPT = KPT >> 1;
+      const int SPT = (KPT + 1) >> 1;
       const int d_tap = SPin * 16 - 64 * (SPT - 1), d_row = (RWin - 2) * SPin * 16 - 64 * (SPT - 1);
       auto next_boff = [&]() {
         const int boff = boff_run;
@@ -380,7 +386,6 @@ __global__ __launch_bounds__(256, (SLOTF == 8 ? 3 : (SLOTF == 12 ? 2 : 1))) void
         return boff;
       };
       half8 af[2][RT], bf[2][PA];
-      constexpr int NCA = 9;   // one tap per chunk (host-checked: KSA / 2 = KPT / 2 K steps)
       static_for<0, NCA>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         wsource(c + 2);
@@ -757,6 +762,9 @@ static const HeadCfg kHeadCfg[] = {
     {1, 2, 8, 16, 3, 1, 2, 2, 8, 1, 1},      // v1 P3: Cin 32, THREE workgroups per CU, stage A on 16-pixel tiles (12 for 180 pixels)
     {1, 4, 10, 20, 5, 2, 4, 4, 12, 1, 1},    // v1 P4: Cin 64, TWO workgroups per CU, 17 tiles of 16 for 264 pixels
     {1, 8, 10, 10, 3, 1, 4, 8, 24, 0, 1},    // v1 P5: Cin 128, 9 tiles of 16 for 144 pixels
+    {2, 3, 8, 16, 3, 1, 3, 2, 12, 1, 1},     // v2 P3: Cin 48 (K padded to 64 per tap), 48-channel class tower, TWO workgroups per CU (73.5 KB)
+    {2, 6, 10, 10, 3, 1, 3, 2, 12, 1, 1},    // v2 P4: Cin 96, 9 tiles of 16 for 144 pixels; MID over the input tile + 12-fragment slots: 64.8 KB, TWO per CU
+    {2, 12, 10, 10, 3, 1, 6, 6, 24, 1, 1},   // v2 P5: Cin 192, 10 x 10 tiles (256 workgroups = one round; MID over the input tile: 126 KB)
     {1, 2, 8, 16, 2, 1, 2, 2, 8, 1, 0},      // v1 P3, round 3's shape: stage A on 32-pixel slots (LITEPI_HEAD_A32=1)
     {1, 2, 8, 16, 2, 1, 2, 2, 12, 0, 0},     // v1 P3: Cin 32, two workgroups per CU (LITEPI_HEAD_2WG=1)
     {1, 2, 16, 16, 3, 2, 2, 6, 24, 0, 0},    // v1 P3: Cin 32
@@ -795,8 +803,10 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
   // chunks hold at most 24 fragments (one ring slot): stage A KSA K steps x RT row tiles, stage B box 12 x 2, class 18 x 1
   // (12 x 2 for two class row tiles), projections 10 (12)
   LP_CHECK(KSA % 2 != 0 || 9 * KPT / KSA >= 2, LP_ERR_STATE, "Detect head %s: stage A needs two chunks", name.c_str());
-  if (A16)   // one tap per chunk: KSA half-steps = KPT / 2 K steps of 32 channels x two row halves; fragment 7 of an 8-fragment slot is not addressable
-    LP_CHECK(KPT % 2 == 0 && KSA == KPT && RT * KSA <= (SLOTF == 8 ? 7 : SLOTF) && (TH + 2) * (TW + 2) <= 64 * PA, LP_ERR_STATE,
+  const int SPT = (KPT + 1) / 2;   // A16: K steps of 32 channels per tap (Cin = 16 mod 32: the last one half zero weights)
+  if (A16)   // a chunk is KSA half-steps = KSA / 2 K steps x two row halves; fragment 7 of an 8-fragment slot is not addressable
+    LP_CHECK(KSA % 2 == 0 && (9 * SPT) % (KSA / 2) == 0 && RT * KSA <= (SLOTF == 8 ? 7 : SLOTF) && (TH + 2) * (TW + 2) <= 64 * PA &&
+                 (KPT % 2 == 0 || (OVL && (size_t)(TH + 4) * (TW + 4) * (2 * KPT + 1) + 1 <= (size_t)(TH + 2) * (TW + 2) * (4 * RT + 1))), LP_ERR_STATE,   // (odd KPT: the zeroed guard slot behind the tile lies inside MID's span)
              "Detect head %s: inconsistent 16-pixel-tile configuration", name.c_str());
   LP_CHECK(lds_bytes <= (SLOTF == 8 ? 53760u : (SLOTF == 12 ? 80u * 1024 : 160u * 1024)) && ((TW + 4) * (2 * KPT + 1) + 63) / 64 == NPC &&
                (A16 || ((9 * KPT) % KSA == 0 && RT * KSA <= SLOTF)) && TH + 4 <= (SLOTF <= 12 && !(OVL && SLOTF == 12) ? 12 : (OVL ? 16 : 20)) &&
@@ -836,18 +846,18 @@ void HeadLayer::build(int cin_phys, int c3_, int nc_, int h, int w, int batch_hi
       }
   };
   if (A16) {
-    for (int tap = 0; tap < 9; ++tap) {
-      begin_chunk();
-      for (int q = 0; q < KPT / 2; ++q)
-        for (int rh = 0; rh < 2; ++rh)
-          for (int rt = 0; rt < RT; ++rt)
-            frag16([&](int r, int e) {
-              const int R = rh * RT + rt;
-              const int c = 32 * (R >> 1) + 8 * (r >> 2) + 4 * (R & 1) + (r & 3);   // physical MID channel
-              const int src = c < 64 ? c : (c - 64 < c3 ? 64 + (c - 64) : -1);
-              return src < 0 ? 0.f : wa[((size_t)src * 9 + tap) * Cin + 32 * q + e];
-            });
-      end_chunk(KSA);
+    for (int ks = 0; ks < 9 * SPT; ++ks) {
+      const int tap = ks / SPT, q = ks % SPT;
+      if (ks % (KSA / 2) == 0) begin_chunk();
+      for (int rh = 0; rh < 2; ++rh)
+        for (int rt = 0; rt < RT; ++rt)
+          frag16([&](int r, int e) {
+            const int R = rh * RT + rt;
+            const int c = 32 * (R >> 1) + 8 * (r >> 2) + 4 * (R & 1) + (r & 3);   // physical MID channel
+            const int src = c < 64 ? c : (c - 64 < c3 ? 64 + (c - 64) : -1);
+            return (src < 0 || 32 * q + e >= Cin) ? 0.f : wa[((size_t)src * 9 + tap) * Cin + 32 * q + e];
+          });
+      if (ks % (KSA / 2) == KSA / 2 - 1) end_chunk(KSA);
     }
   }
   // ---- stage A: K step (tap, cg): element e = input channel 16*cg + e
@@ -965,7 +975,15 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_, true>), 160 * 1024); \
     LP_LAUNCH((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_, true>), grid, dim3(256), lds_bytes, st, a);                 \
   }
-  if (A16 && KPT == 2) LP_HEAD16(1, 3, 1, 2, 2, 8, 3, true)
+#define LP_HEAD16N(C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_, NCA_)                                                                               \
+  {                                                                                                                                                \
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_, true, NCA_>), 160 * 1024); \
+    LP_LAUNCH((head_fused_kernel<C3T_, PA_, PB_, NPC_, KSA_, SLOTF_, NRW_, OV_, true, NCA_>), grid, dim3(256), lds_bytes, st, a);                 \
+  }
+  if (A16 && C3T == 2 && KPT == 3) LP_HEAD16N(2, 3, 1, 3, 2, 12, 3, true, 18)
+  else if (A16 && C3T == 2 && KPT == 6) LP_HEAD16N(2, 3, 1, 3, 2, 12, 4, true, 27)
+  else if (A16 && C3T == 2 && KPT == 12) LP_HEAD16N(2, 3, 1, 6, 6, 24, 4, true, 18)
+  else if (A16 && KPT == 2) LP_HEAD16(1, 3, 1, 2, 2, 8, 3, true)
   else if (A16 && KPT == 4) LP_HEAD16(1, 5, 2, 4, 4, 12, 4, true)
   else if (A16 && KPT == 8) LP_HEAD16(1, 3, 1, 4, 8, 24, 5, false)
   else if (C3T == 1 && KPT == 2 && SLOTF == 8) LP_HEAD(1, 2, 1, 2, 2, 8, 3)
@@ -981,6 +999,7 @@ void HeadLayer::launch(const View& in, int N, int anchor_off, int A, const float
 #undef LP_HEAD
 #undef LP_HEAD2
 #undef LP_HEAD16
+#undef LP_HEAD16N
   LP_HIP(hipGetLastError());
   if (a.stamps) {  // diagnostic: dump [grid][16] stamps, one record per launch
     LP_HIP(hipStreamSynchronize(st));

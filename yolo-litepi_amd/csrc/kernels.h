@@ -17,7 +17,7 @@ struct ImgGeom {
 
 // ---- misc_kernels.hip ------------------------------------------------------------------
 // letterbox (e2e.py:66-86): B images -> uint8 BGR [B,S,S,3], cv2.INTER_LINEAR fixed point, border 114
-void launch_letterbox(const uint8_t* src, const ImgGeom* geom, uint8_t* dst, int B, int S, hipStream_t st);
+void launch_letterbox(const uint8_t* src, const ImgGeom* geom, uint8_t* dst, int B, int S, hipStream_t st, const ImgGeom* host_geoms = nullptr);
 // Interp nearest x2 (model.ncnn.param:88,103)
 void launch_upsample2x(int prec, const View& in, const View& out, int N, hipStream_t st);
 // SPPF: three cascaded 5x5/s1/p2 max pools (model.ncnn.param:79-83) in one pass

@@ -5,6 +5,9 @@
 #include "kernels.h"
 #include "post_dev.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace lp {
 
 typedef _Float16 half_t;
@@ -59,7 +62,123 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
   }
 }
 
-void launch_letterbox(const uint8_t* src, const ImgGeom* geom, uint8_t* dst, int B, int S, hipStream_t st) {
+// Tiled form (round 4; the kernel above gathers 12 single bytes per output pixel straight from global memory: one
+// texture-path request per byte).  A workgroup owns an 8 x 128 tile of the letterboxed image: for each of its 8 output rows the
+// TWO source rows the vertical interpolation reads (cv2's non-antialiased INTER_LINEAR touches only those: at the 3.2x
+// down-scale of a 2048 x 2048 frame 5/8 of the source rows) are staged into LDS with aligned 16-byte loads over the byte
+// span the tile's columns need, then every thread resamples four adjacent output pixels from LDS -- the same fixed-point
+// arithmetic, bit for bit -- and stores them as three dwords.  HBM: every needed source byte once, in >= 1 KB runs.
+#define LB_TH 8
+#define LB_TW 128
+__global__ __launch_bounds__(256) void letterbox_tiled_kernel(const uint8_t* __restrict__ src, const ImgGeom* __restrict__ geom,
+                                                              uint8_t* __restrict__ dst, int S, int row_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t band[];   // [2 * LB_TH][row_cap]
+  __shared__ int s_shift[2 * LB_TH];                                // byte index of source byte b0 inside an LDS row
+  const int n = blockIdx.z, tid = threadIdx.x;
+  const int ox0 = blockIdx.x * LB_TW, oy0 = blockIdx.y * LB_TH;
+  const ImgGeom gm = geom[n];
+  const uint8_t* im = src + gm.src_off;
+  const bool resize = !(gm.new_w == gm.w && gm.new_h == gm.h);
+  // columns of the resized image this tile covers, and the source byte span [b0, b1) they read
+  const int dxa = max(ox0 - gm.left, 0), dxb = min(min(ox0 + LB_TW, S) - gm.left, gm.new_w);   // [dxa, dxb)
+  int b0 = 0, b1 = 0;
+  if (dxa < dxb) {
+    int sa, sb, t0, t1;
+    if (resize) { lin_coeff(dxa, gm.new_w, gm.w, sa, t0, t1); lin_coeff(dxb - 1, gm.new_w, gm.w, sb, t0, t1); }
+    else { sa = dxa; sb = dxb - 1; }
+    const int sb1 = sb + 1 < gm.w ? sb + 1 : gm.w - 1;
+    b0 = 3 * sa; b1 = 3 * (sb1 + 1);
+  }
+  const long img_bytes = (long)gm.h * gm.w * 3;
+  // ---- stage: LDS row 2j / 2j+1 = source rows sy / sy1 of output row oy0 + j
+  if (dxa < dxb) {
+    for (int r = tid >> 4; r < 2 * LB_TH; r += 16) {   // 16 threads per row
+      const int dy = oy0 + (r >> 1) - gm.top;
+      if (dy < 0 || dy >= gm.new_h) continue;
+      int sy, ay0, ay1;
+      if (resize) lin_coeff(dy, gm.new_h, gm.h, sy, ay0, ay1); else sy = dy;
+      const int syr = (r & 1) ? (sy + 1 < gm.h ? sy + 1 : gm.h - 1) : sy;
+      const long goff = (long)syr * gm.w * 3 + b0;                      // byte offset of the span inside the image
+      const long gal = ((gm.src_off + goff) & ~15L) - gm.src_off;        // 16-byte aligned start (the source buffer itself is 256-byte aligned)
+      const int shift = (int)(goff - gal);
+      if ((tid & 15) == 0) s_shift[r] = shift;
+      const int nchunk = (shift + (b1 - b0) + 15) >> 4;
+      for (int c = tid & 15; c < nchunk; c += 16) {
+        const long o = gal + 16L * c;
+        u32x4 v;
+        if (o >= -gm.src_off && o + 16 <= img_bytes) {
+          v = *reinterpret_cast<const u32x4*>(im + o);
+        } else {   // the chunk straddles the end (or start) of the buffer's image: byte by byte, nothing outside is touched
+          uint8_t t[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) t[k] = (o + k >= 0 && o + k < img_bytes) ? im[o + k] : (uint8_t)0;
+          v = *reinterpret_cast<const u32x4*>(t);
+        }
+        *reinterpret_cast<u32x4*>(band + (size_t)r * row_cap + 16 * c) = v;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- resample: thread = (row j, four adjacent columns)
+  const int j = tid >> 5, ox = ox0 + 4 * (tid & 31), oy = oy0 + j;
+  if (oy >= S || ox >= S) return;
+  const int dy = oy - gm.top;
+  const bool rowin = dy >= 0 && dy < gm.new_h;
+  int ay0 = 2048, ay1 = 0;
+  if (rowin && resize) { int sy; lin_coeff(dy, gm.new_h, gm.h, sy, ay0, ay1); }
+  const uint8_t* r0 = band + (size_t)(2 * j) * row_cap + (rowin ? s_shift[2 * j] : 0) - b0;
+  const uint8_t* r1 = band + (size_t)(2 * j + 1) * row_cap + (rowin ? s_shift[2 * j + 1] : 0) - b0;
+  uint32_t out[3] = {0u, 0u, 0u};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int dx = ox + q - gm.left;
+    uint32_t px[3] = {114u, 114u, 114u};
+    if (rowin && dx >= 0 && dx < gm.new_w) {
+      if (resize) {
+        int sx, ax0, ax1;
+        lin_coeff(dx, gm.new_w, gm.w, sx, ax0, ax1);
+        const int sx1 = sx + 1 < gm.w ? sx + 1 : gm.w - 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int h0 = r0[sx * 3 + c] * ax0 + r0[sx1 * 3 + c] * ax1;
+          const int h1 = r1[sx * 3 + c] * ax0 + r1[sx1 * 3 + c] * ax1;
+          int v = (((ay0 * (h0 >> 4)) >> 16) + ((ay1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          px[c] = (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px[c] = r0[dx * 3 + c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int b = 3 * q + c;
+      out[b >> 2] |= px[c] << (8 * (b & 3));
+    }
+  }
+  uint32_t* o = reinterpret_cast<uint32_t*>(dst + ((long)n * S * S + (long)oy * S + ox) * 3);   // 12-byte groups: 4-byte aligned (S % 4 == 0)
+  o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+}
+
+// host_geoms (optional, the B geometries): lets the launcher size the tiled kernel's LDS rows; without them, or when a source
+// row span does not fit (down-scales beyond ~10x), the per-pixel kernel runs
+void launch_letterbox(const uint8_t* src, const ImgGeom* geom, uint8_t* dst, int B, int S, hipStream_t st, const ImgGeom* host_geoms) {
+  static const bool no_tiled = getenv("LITEPI_LB_NAIVE") != nullptr;   // A/B switch
+  if (host_geoms && !no_tiled && S % 4 == 0) {
+    int cap = 0;
+    for (int i = 0; i < B; ++i) {
+      const ImgGeom& g = host_geoms[i];
+      const double scale = (double)g.w / (double)std::max(g.new_w, 1);
+      const int span = (int)(((double)LB_TW * scale + 4.0) * 3.0) + 32;   // source bytes of a tile row + alignment slack
+      cap = std::max(cap, (span + 15) & ~15);
+    }
+    if ((size_t)cap * 2 * LB_TH <= 64 * 1024) {
+      dim3 grid(ceil_div(S, LB_TW), ceil_div(S, LB_TH), B);
+      LP_LAUNCH(letterbox_tiled_kernel, grid, dim3(256), (size_t)cap * 2 * LB_TH, st, src, geom, dst, S, cap);
+      LP_HIP(hipGetLastError());
+      return;
+    }
+  }
   dim3 grid(ceil_div(S * S, 256), B);
   LP_LAUNCH(letterbox_kernel, grid, dim3(256), 0, st, src, geom, dst, S);
   LP_HIP(hipGetLastError());
