@@ -18,6 +18,7 @@
 #ifndef LITEPI_H
 #define LITEPI_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -85,7 +86,7 @@ typedef struct lp_timing {
  * contract.  300 (round 3) vs 100: lp_run_batch takes det_conf_avg, lp_test_postprocess changed, lp_config::numerics /
  * cls_arch took two reserved words, and lp_run_batch_device's dev_counts holds 3*B int32 (was 2*B: a caller that still
  * allocates 2*B is overrun).  litepi/_ffi.py refuses a library whose lp_version() differs. */
-#define LP_ABI_VERSION 300
+#define LP_ABI_VERSION 310
 
 const char* lp_last_error(void);
 int lp_version(void);
@@ -143,6 +144,25 @@ int lp_run_batch_device(lp_handle* h, const void* dev_imgs, int B, int H, int W,
  * kept - classified detections still carry cls_class = -1 (lp_run_batch turns the same condition into LP_ERR_STATE;
  * the asynchronous device path cannot).  With max_rois = 0 (default: max_batch * max_det) it cannot happen. */
 int lp_roi_overflow(lp_handle* h, int* classified, int* kept);
+
+/* ---- multi-GPU: the one collective of the path, owned by the library (ABI 310) ------ */
+/* The reference is a single process (e2e.py:1096-1134 loops over the images); sharding the images over the GPUs of a node
+ * adds exactly one exchange step: every rank's fixed-capacity payload (the lp_det records + the three count words per image
+ * that lp_run_batch_device wrote) goes to one root rank ("one ncclGather to rank 0", rccl.h:745).
+ * RCCL is loaded lazily (dlopen of librccl.so.1 at the first of these calls): a single-GPU host without RCCL still loads
+ * liblitepi_hip.so, and these four calls then fail with LP_ERR_STATE.
+ *   lp_comm_unique_id : rank 0 draws the 128-byte ncclUniqueId; the launcher hands it to every rank (any out-of-band
+ *                       channel: a file, an environment variable, a torch.distributed / MPI broadcast)
+ *   lp_comm_init      : ncclCommInitRank on the handle's device (collective over the ranks of the communicator)
+ *   lp_gather         : ncclGather of `bytes` device bytes per rank on the handle's OWN stream, i.e. ordered behind the
+ *                       lp_run_batch_device that wrote them with no event; dev_recv (root only, else may be NULL) receives
+ *                       world * bytes in rank order.  Asynchronous like lp_run_batch_device.
+ *   lp_comm_destroy   : ncclCommDestroy (also done by lp_destroy) */
+#define LP_COMM_ID_BYTES 128
+int lp_comm_unique_id(void* id_out);
+int lp_comm_init(lp_handle* h, const void* id, int rank, int world);
+int lp_gather(lp_handle* h, const void* dev_send, size_t bytes, void* dev_recv, int root);
+int lp_comm_destroy(lp_handle* h);
 
 /* ---- classifier alone ------------------------------------------------------------ */
 /* replaces PyTorchClassifier.predict_batch (e2e.py:378-396) for R host BGR crops of

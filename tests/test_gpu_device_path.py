@@ -135,3 +135,39 @@ def test_rccl_self_gather_world_size_1(tmp_path):
         eng.close()
         if created:
             dist.destroy_process_group()
+
+
+def test_lp_gather_native_collective_world_size_1(tmp_path):
+    """The library's OWN collective (include/litepi.h ABI 310: lp_comm_unique_id / lp_comm_init / lp_gather / lp_comm_destroy;
+    RCCL bound lazily with dlopen, ncclGather on the handle's stream) executes on hardware at the only world size a one-GPU box
+    allows: the per-step payload of lp_run_batch_device gathered on the handle's own stream with no event and no
+    torch.distributed -- eager, capture and replay -- equals the rank's payload byte for byte; misuse is an error."""
+    from litepi import Engine, _ffi
+    from litepi.distributed import NativeGatherer, alloc_result_buffers
+    p, b, cls_state, imgs = _models(tmp_path)
+    dev = torch.device("cuda", 0)
+    B = imgs.shape[1]
+    eng = Engine(precision="fp16", max_batch=B, max_det=300, num_classes=91)
+    try:
+        eng.load_detector(p, b)
+        eng.load_classifier(cls_state)
+        res = alloc_result_buffers(B, 300, dev)
+        with pytest.raises(_ffi.LitepiError):     # no communicator yet
+            _ffi.check(eng.lib, eng.lib.lp_gather(eng._h, res.payload.data_ptr(), res.payload.numel(), res.payload.data_ptr(), 0))
+        g = NativeGatherer(eng, res, rank=0, world=1, dst=0)
+        with pytest.raises(_ffi.LitepiError):     # a handle has one communicator
+            NativeGatherer(eng, res, rank=0, world=1, dst=0)
+        dimg = torch.from_numpy(imgs[0]).to(dev)
+        torch.cuda.synchronize()
+        for _ in range(3):   # eager, capture, replay -- the gather follows each on the handle's stream
+            eng.run_batch_device(dimg.data_ptr(), B, 640, 640, 0.25, 0.45, 50, res.dets.data_ptr(), res.counts.data_ptr())
+            gd, gc = g.gather(res)
+        eng.synchronize()
+        assert gd.shape[0] == 1 and gd.shape[1] == B and gc.shape[0] == 1
+        assert torch.equal(gc.reshape(-1).cpu(), res.counts.cpu()), "gathered counts differ from the rank's counts"
+        assert torch.equal(gd.reshape(-1).cpu(), res.dets.reshape(-1).cpu()), "gathered records differ from the rank's records"
+        assert int(res.counts[:B].sum().item()) >= 8
+        g.close()
+        g.close()   # idempotent
+    finally:
+        eng.close()

@@ -77,6 +77,9 @@ def last_step(root, p):
     ids = sorted(disp, key=lambda k: disp[k][1])
     stems = [i for i in ids if "stem" in disp[i][0] and "cls_stem" not in disp[i][0]]
     start = disp[stems[-1]][1]
+    lbs = [i for i in ids if "letterbox" in disp[i][0] and disp[i][1] < start]   # configs[4]: the step starts with the letterbox
+    if lbs and (len(stems) < 2 or disp[lbs[-1]][1] > disp[stems[-2]][1]):
+        start = disp[lbs[-1]][1]
     return [(disp[i][0], ctr[i]) for i in ids if disp[i][1] >= start and "lp" in disp[i][0]]
 
 

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <condition_variable>
+#include <dlfcn.h>
 #include <cstring>
 #include <mutex>
 #include <set>
@@ -175,8 +176,45 @@ class CopyPool {
   bool stop_ = false;
 };
 
+// RCCL, bound at run time (lp_comm_* / lp_gather): the library links nothing but the HIP runtime
+struct NcclId { char internal[128]; };
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(NcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+  int (*Gather)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+    r.GetUniqueId = reinterpret_cast<int (*)(NcclId*)>(dlsym(r.lib, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<int (*)(void**, int, NcclId, int)>(dlsym(r.lib, "ncclCommInitRank"));
+    r.Gather = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(r.lib, "ncclGather"));
+    r.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(r.lib, "ncclGetErrorString"));
+  });
+  LP_CHECK(r.lib && r.GetUniqueId && r.CommInitRank && r.Gather && r.CommDestroy, LP_ERR_STATE,
+           "RCCL is not available (dlopen librccl.so.1: %s)", r.lib ? "a symbol is missing" : dlerror());
+  return r;
+}
+#define LP_RCCL(expr)                                                                                                           \
+  do {                                                                                                                          \
+    const int rc_ = (expr);                                                                                                     \
+    if (rc_ != 0) throw Error(LP_ERR_HIP, fmt("%s: RCCL error %d (%s)", #expr, rc_, rccl().GetErrorString ? rccl().GetErrorString(rc_) : "?")); \
+  } while (0)
+
 struct lp_handle {
   lp_config cfg;
+  void* comm = nullptr;        // ncclComm_t of lp_comm_init
+  int comm_rank = 0, comm_world = 1;
   // pinned staging of the host entry points + the copy workers (created on first use)
   uint8_t* h_stage = nullptr;
   size_t h_stage_bytes = 0;
@@ -341,6 +379,7 @@ void lp_destroy(lp_handle* h) {
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   h->pool.reset();
   if (h->h_stage) (void)hipHostFree(h->h_stage);
+  if (h->comm) { try { (void)rccl().CommDestroy(h->comm); } catch (...) {} }
   delete h;
 }
 
@@ -735,6 +774,50 @@ int lp_run_batch_device(lp_handle* h, const void* dev_imgs, int B, int H, int W,
     if (classify) enqueue_classify(h, src, B, static_cast<lp_det*>(dev_dets), nullptr, nullptr, nullptr, prof);
   });
   if (prof) prof->enabled = false;  // records are collected by lp_profile_read after the caller synchronises
+  LP_API_END
+}
+
+int lp_comm_unique_id(void* id_out) {
+  LP_API_BEGIN
+  LP_CHECK(id_out, LP_ERR_ARG, "null argument");
+  NcclId id;
+  LP_RCCL(rccl().GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  LP_API_END
+}
+
+int lp_comm_init(lp_handle* h, const void* id, int rank, int world) {
+  LP_API_BEGIN
+  LP_CHECK(h && id && world >= 1 && rank >= 0 && rank < world, LP_ERR_ARG, "bad argument (rank %d of %d)", rank, world);
+  LP_CHECK(!h->comm, LP_ERR_STATE, "the handle already has a communicator");
+  LP_HIP(hipSetDevice(h->cfg.device));
+  NcclId nid;
+  memcpy(&nid, id, sizeof(nid));
+  void* comm = nullptr;
+  LP_RCCL(rccl().CommInitRank(&comm, world, nid, rank));
+  h->comm = comm; h->comm_rank = rank; h->comm_world = world;
+  LP_API_END
+}
+
+int lp_gather(lp_handle* h, const void* dev_send, size_t bytes, void* dev_recv, int root) {
+  LP_API_BEGIN
+  LP_CHECK(h && dev_send && bytes > 0, LP_ERR_ARG, "bad argument");
+  LP_CHECK(h->comm, LP_ERR_STATE, "lp_comm_init has not been called on this handle");
+  LP_CHECK(root >= 0 && root < h->comm_world && (h->comm_rank != root || dev_recv), LP_ERR_ARG, "bad root %d / receive buffer", root);
+  LP_HIP(hipSetDevice(h->cfg.device));
+  LP_RCCL(rccl().Gather(dev_send, dev_recv, bytes, 1 /* ncclUint8 */, root, h->comm, h->stream));
+  LP_API_END
+}
+
+int lp_comm_destroy(lp_handle* h) {
+  LP_API_BEGIN
+  LP_CHECK(h, LP_ERR_ARG, "null argument");
+  if (h->comm) {
+    LP_HIP(hipSetDevice(h->cfg.device));
+    LP_HIP(hipStreamSynchronize(h->stream));
+    LP_RCCL(rccl().CommDestroy(h->comm));
+    h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
+  }
   LP_API_END
 }
 

@@ -305,9 +305,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsArgs a) {
   __shared__ int s_nk, s_base;
   __shared__ double s_red[NMS_THREADS / 64];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (a.no_small == 2) return;
   int cnt = a.cand_count[n];
-  if (a.no_small == 3) { if (tid == 0) a.counts[n] = cnt; return; }
   cnt = cnt > a.A ? a.A : cnt;
   if (cnt <= 64 && cnt <= a.max_det && !a.no_small) {   // block-uniform: the other 15 waves leave before any barrier
     if (wave == 0) nms_small(a, n, cnt, (int)gridDim.x);
@@ -499,13 +497,6 @@ void launch_nms(const NmsArgs& a, int N, hipStream_t st) {
   const size_t lds = nms_lds_bytes(a.A);
   LP_CHECK(lds <= 150 * 1024, LP_ERR_STATE, "NMS: %d anchors exceed the LDS sort capacity", a.A);
   LP_CHECK(a.A <= 16384, LP_ERR_STATE, "NMS: anchor index needs more than 14 key bits");
-  if (const char* dbg = getenv("LITEPI_NMS_DEBUG")) {   // timing diagnostics only (results are garbage): 2 = return at once, 3 = return after the count load
-    NmsArgs b = a;
-    b.no_small = atoi(dbg);
-    LP_LAUNCH(nms_kernel, dim3(N), dim3(NMS_THREADS), lds, st, b);
-    LP_HIP(hipGetLastError());
-    return;
-  }
   const bool no_small = getenv("LITEPI_NMS_NO_SMALL") != nullptr;   // A/B switch + the path-equivalence test (read per enqueue: a captured graph keeps what it saw)
   NmsArgs b = a;
   b.no_small = no_small ? 1 : a.no_small;

@@ -46,8 +46,9 @@ SYMBOLS = [
     "lp_load_classifier_tensors", "lp_detect_raw", "lp_detect", "lp_run_batch", "lp_run_batch_device", "lp_classify",
     "lp_set_stream", "lp_synchronize", "lp_profile_next", "lp_profile_read", "lp_detector_info", "lp_debug_blob",
     "lp_test_conv", "lp_test_postprocess", "lp_test_nms_boxes", "lp_test_roi_resize", "lp_test_letterbox", "lp_roi_overflow",
+    "lp_comm_unique_id", "lp_comm_init", "lp_gather", "lp_comm_destroy",
 ]
-ABI_VERSION = 300   # include/litepi.h LP_ABI_VERSION: a library built from another header is refused (load_library)
+ABI_VERSION = 310   # include/litepi.h LP_ABI_VERSION: a library built from another header is refused (load_library)
 
 _lib: Optional[C.CDLL] = None
 
@@ -92,6 +93,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.lp_test_roi_resize.argtypes = [vp, u8pp, ip, ip, C.c_int, vp]
     lib.lp_test_letterbox.argtypes = [vp, vp, C.c_int, C.c_int, vp, fp, fp, fp]
     lib.lp_roi_overflow.argtypes = [vp, ip, ip]
+    lib.lp_comm_unique_id.argtypes = [vp]
+    lib.lp_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.lp_gather.argtypes = [vp, vp, C.c_size_t, vp, C.c_int]
+    lib.lp_comm_destroy.argtypes = [vp]
     for s in SYMBOLS:
         if s not in ("lp_last_error", "lp_default_config", "lp_destroy"):
             getattr(lib, s).restype = C.c_int

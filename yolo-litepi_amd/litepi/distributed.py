@@ -91,6 +91,58 @@ class Gatherer:
         return all_dets, all_counts
 
 
+class NativeGatherer:
+    """The same exchange step through the LIBRARY's own collective (include/litepi.h, ABI 310: ``lp_comm_init`` + ``lp_gather`` =
+    ``ncclGather`` from RCCL, bound lazily with dlopen): no torch.distributed on the data path, and the gather is enqueued on the
+    handle's own stream, i.e. ordered behind the ``lp_run_batch_device`` that wrote the payload without any event.
+
+    The 128-byte ``ncclUniqueId`` has to reach every rank out of band.  ``id_bytes`` may be passed explicitly (drawn on rank 0
+    with ``NativeGatherer.unique_id()`` and shipped by the launcher); if it is None and a torch.distributed process group of any
+    backend (gloo is enough) exists, rank 0's id is broadcast over it -- that group then carries 128 bytes once, nothing else."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _ffi
+        lib = _ffi.load_library()
+        buf = (C.c_char * 128)()
+        _ffi.check(lib, lib.lp_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def __init__(self, engine, like: ResultBuffers, rank: int = 0, world: int = 1, dst: int = 0, id_bytes: Optional[bytes] = None):
+        import ctypes as C
+        from . import _ffi
+        self.engine, self.rank, self.world, self.dst = engine, rank, world, dst
+        self.batch, self.max_det = like.batch, like.max_det
+        if id_bytes is None:
+            if world > 1:
+                if not (dist.is_available() and dist.is_initialized()):
+                    raise RuntimeError("NativeGatherer: pass id_bytes (NativeGatherer.unique_id() on rank 0) or initialise a process group to broadcast it")
+                box = [self.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                id_bytes = box[0]
+            else:
+                id_bytes = self.unique_id()
+        idbuf = (C.c_char * 128).from_buffer_copy(id_bytes)
+        _ffi.check(engine.lib, engine.lib.lp_comm_init(engine._h, idbuf, rank, world))
+        self.recv = torch.empty((world, like.payload.numel()), dtype=torch.uint8, device=like.payload.device) if rank == dst else None
+
+    def gather(self, buf: ResultBuffers):
+        """rank dst: ([world, batch, max_det, 32] uint8, [world, 3*batch] int32) views of the receive buffer (valid once the
+        handle's stream has reached this point: synchronise it, or keep consuming on it); other ranks: None."""
+        from . import _ffi
+        recv_ptr = self.recv.data_ptr() if self.recv is not None else None
+        _ffi.check(self.engine.lib, self.engine.lib.lp_gather(self.engine._h, buf.payload.data_ptr(), buf.payload.numel(), recv_ptr, self.dst))
+        if self.rank != self.dst:
+            return None
+        nd = self.batch * self.max_det * RECORD_BYTES
+        return self.recv[:, :nd].view(self.world, self.batch, self.max_det, RECORD_BYTES), self.recv[:, nd:].view(torch.int32)
+
+    def close(self) -> None:
+        from . import _ffi
+        _ffi.check(self.engine.lib, self.engine.lib.lp_comm_destroy(self.engine._h))
+
+
 def gather_detections(dets, counts=None, dst: int = 0, group: Optional[dist.ProcessGroup] = None):
     """Convenience form (allocates its receive slots per call; steady-state loops keep a ``Gatherer``)."""
     buf = dets if isinstance(dets, ResultBuffers) else None
