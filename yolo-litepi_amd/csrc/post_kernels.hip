@@ -225,9 +225,11 @@ __device__ __forceinline__ void nms_small(const NmsArgs& a, int n, int cnt, int 
   if (lane < cnt) c = cand[lane];
   unsigned long long key = lane < cnt ? nms_key(c) : 0ull;   // (a real key is never 0: that would take class 65535)
   int src = lane;
-#pragma unroll
+  // (rolled on purpose: one wave executes this once per image, from a cold instruction cache -- 21 unrolled stages were ~2.5 KB of
+  //  straight-line code, each 64-byte line a fetch from L2 that nothing hides)
+#pragma unroll 1
   for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
+#pragma unroll 1
     for (int j = k >> 1; j > 0; j >>= 1) {
       const unsigned lo = __shfl_xor((unsigned)key, j), hi = __shfl_xor((unsigned)(key >> 32), j);
       const unsigned long long okey = ((unsigned long long)hi << 32) | lo;
