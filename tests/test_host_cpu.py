@@ -355,3 +355,20 @@ def test_eval_row_packing_round_trips():
     assert p2 == preds and g2 == gts
     p3, g3 = unpack_eval_rows(pack_eval_rows([[]], [[]]), 1)
     assert p3 == [[]] and g3 == [[]]
+
+
+def test_copy_pool_stress_native(tmp_path):
+    """The copy workers behind the host entry points (csrc/copy_pool.h: pinned-staging uploads of lp_run_batch / lp_detect) on the
+    CPU: tests/native/copy_pool_stress.cpp pushes 1500 batches of 1..97 jobs through an 8-thread pool and verifies every byte.
+    (A first version kept the batch state in pool members and could double-count a job across two batches -- run() then waited
+    forever; the batch now lives on run()'s stack under a serial number, and the harness is clean under -fsanitize=thread.)"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "copy_pool_stress")
+    src = os.path.join(ROOT, "tests", "native", "copy_pool_stress.cpp")
+    inc = os.path.join(ROOT, "yolo-litepi_amd", "csrc")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", inc, src, "-o", exe], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

@@ -16,6 +16,7 @@
 #include "mbnet.h"
 #include "resnet.h"
 #include "common.h"
+#include "copy_pool.h"
 #include "detector.h"
 #include "kernels.h"
 
@@ -109,72 +110,7 @@ static ImgGeom make_geom(int h, int w, int S, long src_off) {
 
 using namespace lp;
 
-// Host-side upload path of the drop-in entry points (lp_run_batch / lp_detect: the caller's images are ordinary pageable
-// NumPy arrays).  A pageable hipMemcpyAsync is staged by the runtime through its own small pinned buffers, one image after
-// the other: 24 GB/s of the link's 55.  Here a few worker threads copy groups of images into a pinned staging buffer of the
-// handle while the DMA of the previous group runs (hipMemcpyAsync from pinned memory returns at once), so that the upload
-// runs at the slower of {parallel memcpy, PCIe} instead of their sum.
-class CopyPool {
- public:
-  struct Job { const uint8_t* src; uint8_t* dst; size_t bytes; };
-  explicit CopyPool(int n) {
-    for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
-  }
-  ~CopyPool() {
-    { std::lock_guard<std::mutex> l(m_); stop_ = true; ++gen_; }
-    cv_.notify_all();
-    for (auto& t : workers_) t.join();
-  }
-  // copies every job (the calling thread takes part); returns when all are done
-  void run(const Job* jobs, int n) {
-    if (n <= 0) return;
-    {
-      std::lock_guard<std::mutex> l(m_);
-      jobs_ = jobs; njobs_ = n; next_.store(0); done_ = 0; ++gen_;
-    }
-    cv_.notify_all();
-    work();
-    std::unique_lock<std::mutex> l(m_);
-    cv_done_.wait(l, [&] { return done_ == njobs_; });
-    jobs_ = nullptr; njobs_ = 0;
-  }
-
- private:
-  void work() {
-    int mine = 0;
-    for (;;) {
-      const int i = next_.fetch_add(1);
-      if (i >= njobs_) break;
-      memcpy(jobs_[i].dst, jobs_[i].src, jobs_[i].bytes);
-      ++mine;
-    }
-    if (mine) {
-      std::lock_guard<std::mutex> l(m_);
-      done_ += mine;
-      if (done_ == njobs_) cv_done_.notify_all();
-    }
-  }
-  void loop() {
-    unsigned long seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [&] { return gen_ != seen; });
-        seen = gen_;
-        if (stop_) return;
-      }
-      work();
-    }
-  }
-  std::vector<std::thread> workers_;
-  std::mutex m_;
-  std::condition_variable cv_, cv_done_;
-  const Job* jobs_ = nullptr;
-  int njobs_ = 0, done_ = 0;
-  std::atomic<int> next_{0};
-  unsigned long gen_ = 0;
-  bool stop_ = false;
-};
+using lp::CopyPool;
 
 // RCCL, bound at run time (lp_comm_* / lp_gather): the library links nothing but the HIP runtime
 struct NcclId { char internal[128]; };
