@@ -71,6 +71,7 @@ struct C2fLayer {
     const std::vector<float>*sp2 = nullptr, *sp2_b = nullptr;             // [COUT][4C]
   };
   static bool supported(const C2fShape& s, int h, int w);
+  bool cv2_from_lds() const;   // cv2 takes the last y segments from the LDS planes: they never reach the concat buffer
   void build(const C2fShape& s, int h, int w, const Src& src);
   struct IO {
     View src0, src1, cat, out;   // src0.base == nullptr when KA == 0

@@ -41,7 +41,7 @@ constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 constexpr int min_c(int a, int b) { return a < b ? a : b; }
 constexpr int max_c(int a, int b) { return a > b ? a : b; }
 
-template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_, int TH_ = 20, int NW_PERIMG = 8>
+template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_, int TH_ = 20, int NW_PERIMG = 8, bool AW_ = true>
 struct C2fCfg {
   static constexpr int C = C_, NB = NB_, KA = KA_, KB = KB_, COUT = COUT_, MODE = MODE_, KS2 = KS2_;
   static constexpr bool UP = UP_;
@@ -56,7 +56,12 @@ struct C2fCfg {
   static constexpr int TH = TH_, TW = 20;
   static constexpr int F = PERIMG ? 1 : 2 * NB;  // frame margin around the tile
   static constexpr int LW = TW + 2 * F, LH = TH + 2 * F;
-  static constexpr int PS = 2 * C + 16;          // bytes per LDS pixel of a c-channel plane
+  // general K packing of the 3x3 convs (v2's widths c = 24 / 48: a tap is not a whole number of 32-channel K steps): K group
+  // q = 4 s + gam -> (tap q / (c/8), channel group q % (c/8)), a per-lane table of LDS offsets (c3_phase)
+  static constexpr bool GK = C % 32 != 0 && C != 16;
+  // bytes per LDS pixel of a c-channel plane: an odd number of 16-byte slots.  c % 16 != 0 (c = 24: 48 B = 3 slots): no pad at
+  // all -- the lanes that own the 8 padding rows of the second channel tile skip their stores
+  static constexpr int PS = C % 16 != 0 ? 2 * C : 2 * C + 16;
   // c = 16, one bottleneck: plane 0 holds cv1's whole output y0 | y1 (2c channels per pixel), so that cv2's first K step
   // (32 channels) is one plane-0 read and the module's concat buffer is never touched: no global round trip of y0 .. y2
   static constexpr bool Y01 = C == 16 && NB == 1 && MODE_ == 0;
@@ -72,25 +77,26 @@ struct C2fCfg {
   // block shapes (NT channel tiles x PT pixel tiles per wave, CB channel blocks): one round of blocks per phase, two
   // where one would not fit the register file (cap_pt)
   static constexpr int MAXT = (MODE_ >= 1 && NW_PERIMG == 4) ? 52 : 20;   // accumulator tiles a wave can hold
-  static constexpr int cap_pt(int nt, int pt) { return nt * pt > MAXT ? cdiv_c(pt, 2) : pt; }
+  static constexpr int cap_pt(int nt, int pt) { return nt * pt > (nt == 3 ? 21 : MAXT) ? cdiv_c(pt, 2) : pt; }
   // (whole-image configurations: cv1's fragments are staged in plane 1, which nothing uses before the first bottleneck conv,
   //  and a wave holds every output channel of two pixel tiles -- as the entry conv, see WB_S2)
   static constexpr bool W1_LDS = PERIMG;
-  static constexpr int CT1 = 2 * C / 16, NT1 = W1_LDS ? CT1 : min_c(CT1, 4), CB1 = CT1 / NT1,
+  // (channel tiles in threes where the count allows it -- v2's 48 / 96 / 192 channels: NT = 3, a lane owns 12 consecutive channels)
+  static constexpr int CT1 = 2 * C / 16, NT1 = W1_LDS ? CT1 : (CT1 % 3 == 0 ? 3 : min_c(CT1, 4)), CB1 = CT1 / NT1,
                        PT1 = W1_LDS ? 2 : cap_pt(NT1, cdiv_c(npt(e_cv1), NW / CB1));
-  static constexpr int CTM = C / 16, NTM = min_c(CTM, 2), CBM = CTM / NTM;
+  static constexpr int CTM = cdiv_c(C, 16), NTM = CTM % 3 == 0 ? 3 : min_c(CTM, 2), CBM = CTM / NTM;
   static constexpr int ptm(int e) { return cdiv_c(npt(e), NW / CBM); }
-  static constexpr int CT2 = COUT / 16, NT2 = CT2 >= 2 ? CT2 / 2 : 1, CB2 = CT2 / NT2, PT2 = cap_pt(NT2, cdiv_c(npt(0), NW / CB2));
+  static constexpr int CT2 = COUT / 16, NT2 = CT2 % 3 == 0 ? 3 : (CT2 >= 2 ? CT2 / 2 : 1), CB2 = CT2 / NT2, PT2 = cap_pt(NT2, cdiv_c(npt(0), NW / CB2));
   static constexpr int PT2W = cdiv_c(npt(0), NW / CB2);   // whole-image cv2: one round of blocks (pw_sync_phase)
-  static constexpr int NTS = min_c(C / 16, 2), CBS = (C / 16) / NTS, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
+  static constexpr int NTS = NTM, CBS = CBM, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
   static constexpr int WPS = NW == 4 && MODE_ >= 1 ? 1 : 2;   // waves per SIMD the register allocation must allow
   // cv2 reads y_NB and y_{NB+1} from the LDS planes (whole K steps need c >= 32); the earlier segments from the concat buffer
-  static constexpr bool CV2_LDS = C >= 32 || Y01;
+  static constexpr bool CV2_LDS = (C >= 32 && !GK) || Y01;
   static constexpr int K2G = Y01 ? 0 : (CV2_LDS ? NB * C : (2 + NB) * C);
   // weights staged in LDS (tile configurations): fragment bytes of every phase, in execution order
-  static constexpr bool AW = !PERIMG;
-  static constexpr int c3_steps = C >= 32 ? 9 * (C / 32) : 5;
-  static constexpr int WB_CV1 = CT1 * ((KA + KB) / 32) * 1024, WB_M = CTM * c3_steps * 1024, WB_CV2 = CT2 * cdiv_c((2 + NB) * C, 32) * 1024;
+  static constexpr bool AW = !PERIMG && AW_;
+  static constexpr int c3_steps = GK ? cdiv_c(9 * (C / 8), 4) : (C >= 32 ? 9 * (C / 32) : 5);
+  static constexpr int WB_CV1 = CT1 * cdiv_c(KA + KB, 32) * 1024, WB_M = CTM * c3_steps * 1024, WB_CV2 = CT2 * cdiv_c((2 + NB) * C, 32) * 1024;
   static constexpr int WSLOT = AW ? max_c(WB_CV1, max_c(WB_M, WB_CV2)) : 0;
   // whole-image configurations: the entry conv runs before anything lives in the planes, so ALL of its fragments are staged
   // in LDS (144 KB for 64 -> 128 channels) and a wave holds every output channel of its pixels (NT = all row tiles): each
@@ -185,6 +191,14 @@ template <int NT> __device__ __forceinline__ void store_h(char* dst, const half_
 #pragma unroll
     for (int i = 0; i < 4; ++i) q[i] = h[i];
     *reinterpret_cast<half4*>(dst) = q;
+  } else if constexpr (NT % 2 == 1) {   // NT = 3: 24 bytes at a 24-byte stride -- 8-byte aligned pieces
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      half4 q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = h[4 * j + i];
+      *reinterpret_cast<half4*>(dst + 8 * j) = q;
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < NT / 2; ++j) {
@@ -200,6 +214,13 @@ template <int NT> __device__ __forceinline__ void load_h(const char* src, half_t
     const half4 q = *reinterpret_cast<const half4*>(src);
 #pragma unroll
     for (int i = 0; i < 4; ++i) h[i] = q[i];
+  } else if constexpr (NT % 2 == 1) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const half4 q = *reinterpret_cast<const half4*>(src + 8 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h[4 * j + i] = q[i];
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < NT / 2; ++j) {
@@ -432,10 +453,23 @@ __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char
   constexpr int C = CFG::C, NT = CFG::NTM, CB = CFG::CBM, LW = CFG::LW;
   constexpr int SPT = C >= 32 ? C / 32 : 1;
   constexpr int S = CFG::c3_steps;
+  constexpr bool GK = CFG::GK;
   // c = 16: taps of step s for the lanes with (g & 1) == 0 / 1
   constexpr int TA[5] = {0, 3, 6, 1, 4}, TB[5] = {2, 5, 8, 7, 4};
-  int soff[C >= 32 ? 1 : 5];
-  if constexpr (C < 32) {
+  int soff[GK ? S : (C >= 32 ? 1 : 5)];
+  if constexpr (GK) {
+    // general packing: K group q = 4 s + gam is channel group q % G of tap q / G (G = c / 8 groups per tap); the groups past
+    // the last tap carry zero weights and re-read the last real one
+    constexpr int G = C / 8;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      int q = 4 * s + cx.gam;
+      q = q < 9 * G ? q : 9 * G - 1;
+      const int tap = q / G, cg = q - tap * G;
+      const int ty = (tap * 11) >> 5;   // tap / 3 for tap < 9
+      soff[s] = (ty * LW + tap - 3 * ty) * PS + cg * 16;
+    }
+  } else if constexpr (C < 32) {
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       const int ta = ((TA[s] / 3) * LW + TA[s] % 3) * PS, tb = ((TB[s] / 3) * LW + TB[s] % 3) * PS;
@@ -458,7 +492,7 @@ __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char
       int py, px;
       pix_of(rg, p, py, px);
       const int slot = (rg.fy0 + py) * LW + rg.fx0 + px;
-      pb[i] = (slot - LW - 1) * PS + CHOFF + (C >= 32 ? cx.gam * 16 : (cx.g >> 1) * 16);
+      pb[i] = (slot - LW - 1) * PS + CHOFF + (GK ? 0 : (C >= 32 ? cx.gam * 16 : (cx.g >> 1) * 16));
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -471,7 +505,7 @@ __device__ __forceinline__ void c3_phase(const Ctx& cx, const Rg& rg, const char
     kloop<S, (LDSW ? 2 : 4), 2, NT, PT>(
         acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
         [&](int s, half8(&bf)[PT]) {
-          if constexpr (C >= 32) {
+          if constexpr (C >= 32 && !GK) {
             const int tap = s / SPT, cblk = s % SPT;
             const int off = ((tap / 3) * LW + tap % 3) * PS + cblk * 64;
 #pragma unroll
@@ -841,7 +875,8 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
         const int chb = cb * 16 * NT + 4 * NT * cx.g;
         half_t h[4 * NT];
         to_half<NT>(v, h);
-        if (ok) store_h<NT>(P1 + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + chb * 2, h);
+        // (c % 16 != 0: the last lane group owns the padding rows of the second channel tile -- nothing to store)
+        if (ok && (C % 16 == 0 || chb < C)) store_h<NT>(P1 + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + chb * 2, h);
       };
       const ASrc<AW> wa = wsrc(2 * k + 1, C2F_W_A0 + 2 * k);
       const float* ba = a.b[C2F_W_A0 + 2 * k];
@@ -855,7 +890,9 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
       const bool last = k == NB - 1;
       auto epi_b = [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NTM]) {
         constexpr int NT = CFG::NTM;
-        const int chb = cb * 16 * NT + 4 * NT * cx.g;
+        const int chb0 = cb * 16 * NT + 4 * NT * cx.g;
+        const bool real = C % 16 == 0 || chb0 < C;   // (padding rows: see epi_a)
+        const int chb = real ? chb0 : 0;
         const int fy = rg.fy0 + py, fx = rg.fx0 + px;
         char* yp = P0 + (fy * LW + fx) * PS0 + Y1OFF + chb * 2;
         half_t r[4 * NT], h[4 * NT];
@@ -865,7 +902,7 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) h[4 * t + q] = (half_t)((float)(half_t)v[t][q] + (float)r[4 * t + q]);
-        if (ok) {
+        if (ok && real) {
           if (!last) store_h<NT>(yp, h);
           else if (CFG::CV2_LDS) store_h<NT>(P1 + (fy * LW + fx) * PS + chb * 2, h);
           if (((2 + k) * C < CFG::K2G || dbg) && fy >= F && fy < F + TH && fx >= F && fx < F + TW) {
@@ -1016,6 +1053,13 @@ typedef C2fCfg<64, 1, 0, 256, false, 128, 1, 64> CfgPan20;   // :134-147 conv_42
 typedef C2fCfg<64, 1, 0, 128, false, 128, 2, 64> CfgBb20;    // :62-85 conv_22 (s2) -> C2f(n=1) -> SPPF @20x20
 typedef C2fCfg<16, 2, 0, 32, false, 32, 0, 0, 16> CfgBb80;       // :22-38 C2f(n=2) @80x80
 typedef C2fCfg<32, 2, 0, 64, false, 64, 0, 0> CfgBb40;       // :43-59 C2f(n=2) @40x40
+// YOLO-LitePi v2 widths (src/tt100k/convert/model/yolo_plus/yolo_plus_ncnn_model/model.ncnn.param, line of the module's cv1).
+// c = 48 / 96: the phases' weights do not fit beside the planes -- every wave streams its channel block's fragments from L2 (AW off)
+typedef C2fCfg<48, 1, 192, 96, true, 96, 0, 0, 20, 8, false> CfgV2Neck40;   // :101 up(P5) | P4 -> C2f(n=1) @40x40
+typedef C2fCfg<48, 1, 0, 144, false, 96, 0, 0, 20, 8, false> CfgV2Pan40;    // :132 conv_37 | F4 -> C2f(n=1) @40x40
+typedef C2fCfg<24, 1, 96, 48, true, 48, 0, 0, 16> CfgV2Neck80;              // :116 up(F4) | P3 -> C2f(n=1) @80x80
+typedef C2fCfg<96, 1, 0, 192, false, 192, 0, 0, 10, 8, false> CfgV2Bb20;    // :63 C2f(n=1) @20x20, two half-image tiles
+typedef C2fCfg<96, 1, 0, 288, false, 192, 0, 0, 10, 8, false> CfgV2Pan20;   // :145 conv_42 | P5 -> C2f(n=1) @20x20, two half-image tiles
 
 template <class CFG> struct CfgName;
 #define C2F_NAME(T, s) \
@@ -1027,6 +1071,11 @@ C2F_NAME(CfgPan20, "c2f<64,1,s2+256>")
 C2F_NAME(CfgBb20, "c2f<64,1,s2+128,sppf>")
 C2F_NAME(CfgBb80, "c2f<16,2,32>")
 C2F_NAME(CfgBb40, "c2f<32,2,64>")
+C2F_NAME(CfgV2Neck40, "c2f<48,1,up192+96>")
+C2F_NAME(CfgV2Pan40, "c2f<48,1,144>")
+C2F_NAME(CfgV2Neck80, "c2f<24,1,up96+48>")
+C2F_NAME(CfgV2Bb20, "c2f<96,1,192>")
+C2F_NAME(CfgV2Pan20, "c2f<96,1,288>")
 
 template <class CFG> size_t cfg_lds() { return (size_t)CFG::LDS_BYTES; }
 
@@ -1038,21 +1087,46 @@ template <class CFG> bool try_launch(const C2fShape& s, const C2fArgs& a, hipStr
   LP_LAUNCH(c2f_kernel<CFG>, dim3(grid), dim3(CFG::NW * 64), lds, st, a);
   return true;
 }
-struct CfgInfo { size_t lds; const char* name; bool perimg; int th, tw; };
+struct CfgInfo { size_t lds; const char* name; bool perimg, gk, cv2_lds; int th, tw, nt1, ntm, nt2, nt_s2; };
 template <class CFG> bool try_info(const C2fShape& s, CfgInfo& ci) {
   if (!(s == CFG::shape())) return false;
   ci.lds = cfg_lds<CFG>();
   ci.name = CfgName<CFG>::get();
   ci.perimg = CFG::PERIMG;
+  ci.gk = CFG::GK;
+  ci.cv2_lds = CFG::CV2_LDS;
   ci.th = CFG::TH; ci.tw = CFG::TW;
+  ci.nt1 = CFG::NT1; ci.ntm = CFG::NTM; ci.nt2 = CFG::NT2; ci.nt_s2 = CFG::NT_S2;
   return true;
 }
+// every instantiated configuration, in one place: f.template operator()<CFG>() until one returns true
+template <class F> bool for_each_cfg(F&& f) {
+  return f.template operator()<CfgNeck40>() || f.template operator()<CfgNeck80>() || f.template operator()<CfgPan40>() ||
+         f.template operator()<CfgPan20>() || f.template operator()<CfgBb20>() || f.template operator()<CfgBb80>() ||
+         f.template operator()<CfgBb40>() || f.template operator()<CfgV2Neck40>() || f.template operator()<CfgV2Pan40>() ||
+         f.template operator()<CfgV2Neck80>() || f.template operator()<CfgV2Bb20>() || f.template operator()<CfgV2Pan20>();
+}
+struct InfoFn {
+  const C2fShape& s; CfgInfo& ci;
+  template <class CFG> bool operator()() const { return try_info<CFG>(s, ci); }
+};
+struct LaunchFn {
+  const C2fShape& s; const C2fArgs& a; hipStream_t st;
+  template <class CFG> bool operator()() const { return try_launch<CFG>(s, a, st); }
+};
 bool cfg_info(const C2fShape& s, CfgInfo& ci) {
   // (CfgBb80, the n = 2 module on the 80x80 map, is opt-in: its halo-4 recompute of 16-channel layers is VALU work the
   //  two-launch bottleneck plan does not have -- 65-75 us against 59; LITEPI_C2F_BB80=1 enables it for A/B runs)
   static const bool bb80 = getenv("LITEPI_C2F_BB80") != nullptr;
-  return try_info<CfgNeck40>(s, ci) || try_info<CfgNeck80>(s, ci) || try_info<CfgPan40>(s, ci) || try_info<CfgPan20>(s, ci) ||
-         try_info<CfgBb20>(s, ci) || (bb80 && try_info<CfgBb80>(s, ci)) || try_info<CfgBb40>(s, ci);
+  if (!bb80 && s == CfgBb80::shape()) return false;
+  // A/B switch: LITEPI_C2F_SKIP=<configuration names separated by ';'> keeps those modules on the layer plan
+  static const char* skip = getenv("LITEPI_C2F_SKIP");
+  if (!for_each_cfg(InfoFn{s, ci})) return false;
+  if (skip) {
+    const std::string list = std::string(";") + skip + ";", key = std::string(";") + ci.name + ";";
+    if (list.find(key) != std::string::npos) return false;
+  }
+  return true;
 }
 
 int gam_of(int g) { return ((g & 1) << 1) | (g >> 1); }
@@ -1062,8 +1136,8 @@ int gam_of(int g) { return ((g & 1) << 1) | (g >> 1); }
 // channels (vector stores).  kidx(s, g, j) -> index into the K axis of Wm ([cout][ktot]) or -1 (zero).
 template <class KIDX>
 void pack_phase(DevBuf& dst, const std::vector<float>& Wm, int cout, int ktot, int NT, int S, KIDX&& kidx) {
-  LP_CHECK((int)Wm.size() == cout * ktot && cout % (16 * NT) == 0, LP_ERR_STATE, "c2f: weight matrix %zu != %d x %d", Wm.size(), cout, ktot);
-  const int CB = cout / (16 * NT);
+  LP_CHECK((int)Wm.size() == cout * ktot, LP_ERR_STATE, "c2f: weight matrix %zu != %d x %d", Wm.size(), cout, ktot);
+  const int CB = (cout + 16 * NT - 1) / (16 * NT);   // (rows past cout: the zero padding of the last channel tile)
   std::vector<uint16_t> buf((size_t)CB * S * NT * 64 * 8, 0);
   for (int cb = 0; cb < CB; ++cb)
     for (int s = 0; s < S; ++s)
@@ -1072,6 +1146,7 @@ void pack_phase(DevBuf& dst, const std::vector<float>& Wm, int cout, int ktot, i
           const int g = lane >> 4, m = lane & 15, gm = m >> 2, r = m & 3;
           const int oc = cb * 16 * NT + gm * 4 * NT + t * 4 + r;
           const size_t f = ((((size_t)cb * S + s) * NT + t) * 64 + lane) * 8;
+          if (oc >= cout) continue;
           for (int j = 0; j < 8; ++j) {
             const int k = kidx(s, g, j);
             if (k >= 0) buf[f + j] = f32_to_f16(Wm[(size_t)oc * ktot + k]);
@@ -1127,7 +1202,6 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
   cfg_info(s, ci);
   lds_bytes = ci.lds;
   const int C = s.C;
-  auto nt_of = [](int ct, int cap) { return ct < cap ? ct : cap; };
   auto pw_k = [](int ktot) {
     return [ktot](int s_, int g, int j) {
       const int k = 32 * s_ + 8 * gam_of(g) + j;
@@ -1136,7 +1210,13 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
   };
   // 3x3: weights come as [cout][tap][cin]
   auto c3_pack = [&](DevBuf& d, const std::vector<float>& wv, int cout, int cin, int NT) {
-    if (cin >= 32) {
+    if (cin % 32 != 0 && cin != 16) {   // general packing (C2fCfg::GK): K group q = 4 s + gam -> (tap q / G, channel group q % G)
+      const int G = cin / 8, S = (9 * G + 3) / 4;
+      pack_phase(d, wv, cout, 9 * cin, NT, S, [&](int s_, int g, int j) {
+        const int q = 4 * s_ + gam_of(g);
+        return q < 9 * G ? (q / G) * cin + 8 * (q % G) + j : -1;
+      });
+    } else if (cin >= 32) {
       const int spt = cin / 32;
       pack_phase(d, wv, cout, 9 * cin, NT, 9 * spt, [&](int s_, int g, int j) { return (s_ / spt) * cin + 32 * (s_ % spt) + 8 * gam_of(g) + j; });
     } else {
@@ -1148,22 +1228,22 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
     }
   };
   const int K1 = s.KA + s.KB;
-  pack_phase(d_w[C2F_W_CV1], *src.cv1, 2 * C, K1, ci.perimg ? 2 * C / 16 : nt_of(2 * C / 16, 4), (K1 + 31) / 32, pw_k(K1));   // NT1
+  pack_phase(d_w[C2F_W_CV1], *src.cv1, 2 * C, K1, ci.nt1, (K1 + 31) / 32, pw_k(K1));
   put_bias(d_b[C2F_W_CV1], src.cv1_b, 2 * C);
-  const int ntm = nt_of(C / 16, 2);
+  const int ntm = ci.ntm;
   for (int k = 0; k < s.NB; ++k) {
     c3_pack(d_w[C2F_W_A0 + 2 * k], *src.a[k], C, C, ntm);
     put_bias(d_b[C2F_W_A0 + 2 * k], src.a_b[k], C);
     c3_pack(d_w[C2F_W_B0 + 2 * k], *src.bb[k], C, C, ntm);
     put_bias(d_b[C2F_W_B0 + 2 * k], src.bb_b[k], C);
   }
-  const int ct2 = s.COUT / 16, nt2 = ct2 >= 2 ? ct2 / 2 : 1;
+  const int nt2 = ci.nt2;
   const int K2 = (2 + s.NB) * C;
   pack_phase(d_w[C2F_W_CV2], *src.cv2, s.COUT, K2, nt2, (K2 + 31) / 32, pw_k(K2));
   put_bias(d_b[C2F_W_CV2], src.cv2_b, s.COUT);
   macs_per_image = ((double)2 * C * K1 + (double)s.NB * 2 * 9 * C * C + (double)s.COUT * K2) * h * w;
   if (s.MODE >= 1) {
-    c3_pack(d_w[C2F_W_S2], *src.s2, 2 * C, s.KS2, 2 * C / 16);   // NT_S2: every row tile in one wave
+    c3_pack(d_w[C2F_W_S2], *src.s2, 2 * C, s.KS2, ci.nt_s2);   // NT_S2: every row tile in one wave
     put_bias(d_b[C2F_W_S2], src.s2_b, 2 * C);
     macs_per_image += 9.0 * s.KS2 * 2 * C * h * w;
   }
@@ -1214,6 +1294,11 @@ void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st)
   if (stamp_file) dump_stamps(stamp_file, name, (size_t)N * a.tiles_x * a.tiles_y, st);
 }
 
+bool C2fLayer::cv2_from_lds() const {
+  CfgInfo ci;
+  return cfg_info(sh, ci) && ci.cv2_lds;
+}
+
 std::string C2fLayer::kernel_name() const {
   CfgInfo ci;
   return cfg_info(sh, ci) ? ci.name : "c2f";
@@ -1255,14 +1340,10 @@ void C2fLayer::launch(const IO& io, int N, hipStream_t st) const {
   a.debug_store = (store_all ? 1 : 0) | (dbg_flags & ~1);
   static const char* stamp_file = getenv("LITEPI_C2F_STAMPS");
   if (stamp_file) a.stamps = stamp_buffer((size_t)N * a.tiles_x * a.tiles_y);
-  const bool ok = try_launch<CfgNeck40>(sh, a, st) || try_launch<CfgNeck80>(sh, a, st) || try_launch<CfgPan40>(sh, a, st) ||
-                  try_launch<CfgPan20>(sh, a, st) || try_launch<CfgBb20>(sh, a, st) || try_launch<CfgBb80>(sh, a, st) || try_launch<CfgBb40>(sh, a, st);
+  const bool ok = for_each_cfg(LaunchFn{sh, a, st});
   LP_CHECK(ok, LP_ERR_STATE, "c2f %s: no kernel for this shape", name.c_str());
   LP_HIP(hipGetLastError());
-  if (stamp_file && getenv("LITEPI_C2F_TWICE")) {   // diagnostic: the stamps of an immediate second launch (warm instruction cache)
-    try_launch<CfgNeck40>(sh, a, st) || try_launch<CfgNeck80>(sh, a, st) || try_launch<CfgPan40>(sh, a, st) || try_launch<CfgPan20>(sh, a, st) ||
-        try_launch<CfgBb20>(sh, a, st) || try_launch<CfgBb80>(sh, a, st) || try_launch<CfgBb40>(sh, a, st);
-  }
+  if (stamp_file && getenv("LITEPI_C2F_TWICE")) for_each_cfg(LaunchFn{sh, a, st});   // diagnostic: the stamps of an immediate second launch (warm instruction cache)
   if (stamp_file) dump_stamps(stamp_file, name, (size_t)N * a.tiles_x * a.tiles_y, st);
 }
 

@@ -1604,6 +1604,141 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------
+// The same launch for v2's widths (the paper's YOLO-LitePi: stem 3 -> 16, stride-2 conv 16 -> 24, C2f.cv1 24 -> 12 | 12 =
+// 32 physical channels; yolo_plus_ncnn_model/model.ncnn.param:3-8).  The stem runs in stem_mfma16_kernel's formulation (one
+// pixel per MFMA column, the 27 window bytes in one K step); its 17 x 65 x 16 map lives in LDS as two planes of 8 channels
+// (16 B per pixel each), so that a K group of the stride-2 conv -- (tap, 8-channel half), the direct kernel's order, whose
+// packed fragments and 1x1 tail this kernel takes as they are -- is one ds_read_b128 at a static offset.
+// Replaces stem_conv + conv3x3s2_direct+1x1<2,2>: the 320x320x16 map (210 MB per 64-image step each way) never exists.
+// ------------------------------------------------------------------------------------
+#define SB16_PLANE (SB_SH * SB_LW * 16)
+__global__ __launch_bounds__(256) void stem_block16_kernel(const StemBlockArgs a) {
+  __shared__ uint32_t in_tile[SB_IR * SB_ROWW];
+  __shared__ __attribute__((aligned(16))) char st_tile[2 * SB16_PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, col = lane & 15;
+  const int n = blockIdx.x, ox0 = blockIdx.y * SB_TW, oy0 = blockIdx.z * SB_TH;
+  // ---- 1. uint8 tile (as stem_block_kernel)
+  const int row_words = a.Win * 3 / 4;
+  const int w0 = (12 * ox0 - 9) >> 2;
+  const uint32_t* im = reinterpret_cast<const uint32_t*>(a.img + (long)n * a.Hin * a.Win * 3);
+  {
+    const int c = tid & 127, r0 = tid >> 7;
+    const int wi = w0 + c;
+    const bool colok = c < SB_ROWW && wi >= 0 && wi < row_words;
+    const int wic = wi < 0 ? 0 : (wi < row_words ? wi : row_words - 1);
+    constexpr int NR = (SB_IR + 1) / 2;
+    uint32_t v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int iy = 4 * oy0 - 3 + r0 + 2 * k;
+      const int iyc = iy < 0 ? 0 : (iy < a.Hin ? iy : a.Hin - 1);
+      v[k] = im[(long)iyc * row_words + wic];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = r0 + 2 * k;
+      const int iy = 4 * oy0 - 3 + r;
+      const uint32_t m = (colok && iy >= 0 && iy < a.Hin) ? 0xffffffffu : 0u;
+      if (c < SB_ROWW && r < SB_IR) in_tile[r * SB_ROWW + c] = v[k] & m;
+    }
+  }
+  const half8 af = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.afrag)[lane]);   // StemLayer::d_afrag (16-channel form)
+  const floatx4 sb4 = *reinterpret_cast<const floatx4*>(a.sbias + 4 * g);
+  // stride-2 conv: 5 K steps x 2 channel tiles, the 1x1 tail: 2 tiles x 1 step (ConvLayer's packing for the direct kernel)
+  half8 a1[5][2];
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) a1[s][t] = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.w1)[(s * 2 + t) * 64 + lane]);
+  __syncthreads();
+  // ---- 2. stem: 17 x 65 pixels, 16 per MFMA
+  const half2v k1024 = {(half_t)1024.f, (half_t)1024.f};
+  constexpr int NPIX = SB_SH * SB_SW, NTILE = (NPIX + 15) / 16;
+  const bool sb_interior = oy0 >= 1 && ox0 >= 1 && 2 * oy0 - 1 + SB_SH <= a.H1 && 2 * ox0 - 1 + SB_SW <= a.W1;
+  const uint8_t* t8 = reinterpret_cast<const uint8_t*>(in_tile);
+  int pi = wave * 16 + col;          // < 64 < SB_SW
+  int r = 0, c = pi;
+  for (int t = wave; t < NTILE; t += 4) {
+    const bool live = pi < NPIX;
+    const int rc = live ? r : SB_SH - 1, cc = live ? c : SB_SW - 1;
+    const int bo = 3 + 6 * cc;   // first window byte of this pixel inside a staged row
+    uint32_t wa, wb;
+    if (g < 3) {
+      const int idx = (2 * rc + g) * SB_ROWW + (bo >> 2);
+      const int sh = bo & 3;
+      const uint32_t d0 = in_tile[idx], d1 = in_tile[idx + 1], d2 = in_tile[idx + 2];
+      wa = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      wb = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    } else {
+      const int b8 = 2 * rc * SB_ROWW * 4 + bo + 8;
+      wa = (uint32_t)t8[b8] | ((uint32_t)t8[b8 + SB_ROWW * 4] << 8) | ((uint32_t)t8[b8 + 2 * SB_ROWW * 4] << 16);
+      wb = 0u;
+    }
+    const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04010400u);
+    const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04030402u);
+    const uint32_t p2 = __builtin_amdgcn_perm(0x64646464u, wb, 0x04010400u);
+    const uint32_t p3 = __builtin_amdgcn_perm(0x64646464u, wb, 0x04030402u);
+    const half2v h0 = __builtin_bit_cast(half2v, p0) - k1024, h1 = __builtin_bit_cast(half2v, p1) - k1024;
+    const half2v h2 = __builtin_bit_cast(half2v, p2) - k1024, h3 = __builtin_bit_cast(half2v, p3) - k1024;
+    const half8 bf = half8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc, 0, 0, 0);
+    if (live) {
+      const int sy = 2 * oy0 - 1 + rc, sx = 2 * ox0 - 1 + cc;
+      const bool inside = sb_interior || (sy >= 0 && sy < a.H1 && sx >= 0 && sx < a.W1);
+      const floatx4 y4 = act4<half_t, ACT_SILU>(acc, sb4);
+      const half2v q01 = {(half_t)y4[0], (half_t)y4[1]}, q23 = {(half_t)y4[2], (half_t)y4[3]};
+      const uint32_t m = inside ? 0xffffffffu : 0u;
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      // channels 4g .. 4g+3: plane g >> 1, bytes 8 (g & 1) of the pixel
+      *reinterpret_cast<u32x2*>(st_tile + (g >> 1) * SB16_PLANE + (rc * SB_LW + cc) * 16 + (g & 1) * 8) =
+          u32x2{__builtin_bit_cast(uint32_t, q01) & m, __builtin_bit_cast(uint32_t, q23) & m};
+    }
+    pi += 64;
+    c += 64;
+    if (c >= SB_SW) { c -= SB_SW; r += 1; }
+  }
+  // ---- 3. stride-2 3x3 conv from the stem planes (K group q = 4 s + g = (tap q / 2, channel half q % 2)), then the 1x1 tail
+  floatx4 bias1[2], bias2[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) bias1[t] = *reinterpret_cast<const floatx4*>(a.b1 + g * 8 + t * 4);
+  half8 w2f[2][1];
+  ConvArgs a2;
+  a2.w2 = a.w2; a2.bias2 = a.b2;
+  tail_load<half_t, 2, 2>(a2, lane, g, w2f, bias2);
+  a2.out = a.out; a2.out_pitch = a.out_pitch; a2.Cout = a.C2; a2.act = a.act2; a2.res = nullptr; a2.res_pitch = 0;
+  int toff[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int q = 4 * s + g;
+    int tap = q >> 1;
+    tap = tap > 8 ? 8 : tap;   // padded K slots: zero weights, any finite data
+    const int ky = (tap * 21846) >> 16, kx = tap - 3 * ky;
+    toff[s] = (q & 1) * SB16_PLANE + (ky * SB_LW + kx) * 16;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = wave * 4 + i;
+    const int oy = t >> 1, ox = (t & 1) * 16 + col;
+    const char* base = st_tile + ((2 * oy) * SB_LW + 2 * ox) * 16;
+    floatx4 v[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const half8 bf = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4*>(base + toff[s]));
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) v[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s][tt], bf, v[tt], 0, 0, 0);
+    }
+    const int gy = oy0 + oy, gx = ox0 + ox;
+    if (gy < a.H2 && gx < a.W2) {
+      const long pix = (n * a.H2 + gy) * a.W2 + gx;
+      tail_store<half_t, 2, 2, ACT_SILU>(a2, pix, g, v, bias1, w2f, bias2);
+    }
+  }
+}
+
 // ====================================================================================
 // Host side: weight packing and launch
 // ====================================================================================
@@ -2310,21 +2445,26 @@ void StemLayer::build(int prec_, int cout_phys, int act_, const std::vector<floa
 
 
 bool StemLayer::block_supported(const ConvLayer& c1) const {
-  return prec == LP_FP16 && CO == 8 && d_afrag_blk.p && c1.prec == LP_FP16 && c1.impl == IMPL_MFMA && c1.direct && c1.k == 3 && c1.stride == 2 &&
-         c1.Cin == 8 && c1.NT == 1 && c1.nsplits == 1 && c1.T2 == 1 && c1.act == ACT_SILU && c1.steps == 3;
+  const bool common = prec == LP_FP16 && c1.prec == LP_FP16 && c1.impl == IMPL_MFMA && c1.direct && c1.k == 3 && c1.stride == 2 && c1.nsplits == 1 &&
+                      c1.act == ACT_SILU && c1.Cin == CO;
+  if (!common) return false;
+  if (CO == 8) return d_afrag_blk.p && c1.NT == 1 && c1.T2 == 1 && c1.steps == 3;                                     // v1: stem_block_kernel
+  if (CO == 16) return d_afrag.p && c1.NT == 2 && c1.T2 == 2 && c1.steps == 5 && c1.Cout <= 32 && c1.Cout2 <= 32;     // v2: stem_block16_kernel
+  return false;
 }
 
 void StemLayer::launch_block(const uint8_t* img, int N, int Hin, int Win, const ConvLayer& c1, const View& out, hipStream_t st) const {
   LP_CHECK(block_supported(c1) && Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0, LP_ERR_STATE, "stem block: unsupported configuration");
   StemBlockArgs a;
   memset(&a, 0, sizeof(a));
-  a.img = img; a.afrag = d_afrag_blk.p; a.sbias = d_bias.as<float>();
+  a.img = img; a.afrag = CO == 16 ? d_afrag.p : d_afrag_blk.p; a.sbias = d_bias.as<float>();
   a.w1 = c1.d_w.p; a.b1 = c1.d_bias.as<float>(); a.w2 = c1.d_w2.p; a.b2 = c1.d_bias2.as<float>();
   a.out = out.base; a.N = N; a.Hin = Hin; a.Win = Win; a.H1 = (Hin + 1) / 2; a.W1 = (Win + 1) / 2;
   a.H2 = out.H; a.W2 = out.W; a.out_pitch = out.pitch; a.C2 = c1.Cout2; a.act2 = c1.act2;
   LP_CHECK(a.H2 == (a.H1 + 1) / 2 && a.W2 == (a.W1 + 1) / 2 && out.C >= c1.Cout2, LP_ERR_STATE, "stem block: output view mismatch");
   dim3 grid(N, ceil_div(a.W2, SB_TW), ceil_div(a.H2, SB_TH));
-  LP_LAUNCH(stem_block_kernel, grid, dim3(256), 0, st, a);
+  if (CO == 16) LP_LAUNCH(stem_block16_kernel, grid, dim3(256), 0, st, a);
+  else LP_LAUNCH(stem_block_kernel, grid, dim3(256), 0, st, a);
   LP_HIP(hipGetLastError());
 }
 

@@ -435,7 +435,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     const Tensor& T1 = tensors_[t1];
     if (T1.segs.size() != 2 || T1.segs[0] != T1.segs[1] || T1.parent >= 0) return false;
     const int c = T1.segs[0];
-    if (c % 16 != 0 || tensors_[cinfo[i1].tin].Cp != L[i1].in_ch) return false;
+    if (c % 8 != 0 || tensors_[cinfo[i1].tin].Cp != L[i1].in_ch) return false;
     const int sl = sole_consumer(t1);
     if (sl < 0 || L[sl].type != "Slice" || L[sl].outputs.size() != 2) return false;
     const int ty0 = get(L[sl].outputs[0]), ty1 = get(L[sl].outputs[1]);
@@ -618,7 +618,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     io.out = tout;
     ensure_buffer(tout);
     // (the y segments cv2 takes from LDS are only stored in the bisect mode, LITEPI_C2F_STORE_ALL=1)
-    for (size_t q = 2; q < m.ys.size(); ++q) tensors_[m.ys[q]].materialised = getenv("LITEPI_C2F_STORE_ALL") != nullptr || (sh.C < 32 && sh.NB > 1);
+    for (size_t q = 2; q < m.ys.size(); ++q) tensors_[m.ys[q]].materialised = getenv("LITEPI_C2F_STORE_ALL") != nullptr || !cl.cv2_from_lds();
     if (mode >= 1) {
       io.s2_in = cinfo[i0].tin;
       io.x = cinfo[i0].tout;
