@@ -381,11 +381,14 @@ def main():
             dt = time.perf_counter() - t0
             dropin = {"value": B * n_calls / dt, "unit": "images/sec", "ms_per_call": dt / n_calls * 1e3, "calls": n_calls,
                       "results_per_call": n_res / n_calls,
-                      "note": "HybridPipeline.run_batch(list of 64 host uint8 images) -> per-image result dicts, synchronous, one "
-                              "handle: pageable-host upload of 78.6 MB, the pipeline, D2H of the records, Python dict building "
-                              "(the reference's t_total span, e2e.py:446-506, for a batch)"}
+                      "upload_lanes": len(pipe._lanes),
+                      "note": "HybridPipeline.run_batch(list of 64 host uint8 images) -> per-image result dicts, synchronous: "
+                              "pageable-host upload of 78.6 MB (staged through pinned memory by copy workers), the pipeline, D2H of "
+                              "the records, Python dict building (the reference's t_total span, e2e.py:446-506, for a batch); "
+                              "upload_lanes > 0: the images are dealt to that many further handles of max_batch / lanes images, "
+                              "whose uploads and kernels overlap"}
         finally:
-            pipe.engine.close()
+            pipe.close()
 
     # ---- roofline of the dominant conv kernel (one template instantiation): profiled passes of the same step ----
     roofline, families = None, {}

@@ -171,3 +171,77 @@ def test_lp_gather_native_collective_world_size_1(tmp_path):
         g.close()   # idempotent
     finally:
         eng.close()
+
+
+def test_dropin_upload_lanes_equal_single_handles(tmp_path, monkeypatch):
+    """HybridPipeline.run_batch on 32 host images with the upload lanes (round 4: four further handles of max_batch / 4
+    images, a call's images dealt to them in contiguous slices, each slice one lp_run_batch from a worker thread) against
+    plain single handles of the SAME capacity (the plan depends on the capacity) fed the same slices one after the other:
+    every result dict must be identical -- the lanes change when an image is processed, never how."""
+    from litepi import HybridPipeline
+    p, b, sd, imgs = _models(tmp_path)
+    cls_path = str(tmp_path / "cls.pth")
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, cls_path)
+    batch = [imgs[j // 16][j % 16] for j in range(32)]
+    monkeypatch.setenv("LITEPI_DROPIN_LANES", "4")   # (off by default: an experiment that measured slower, backend.py)
+    pipe = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=32, max_det=300)
+    try:
+        assert len(pipe._lanes) == 4 and pipe._lane_cap == 8
+        first = pipe.run_batch(batch, 0.25, 0.45, 50)
+        again = pipe.run_batch(batch, 0.25, 0.45, 50)   # captured / replayed graphs on every lane
+    finally:
+        pipe.close()
+    monkeypatch.setenv("LITEPI_DROPIN_LANES", "1")
+    ref = HybridPipeline(p, b, cls_path, "shufflenetv2", num_classes=91, precision="fp16", max_batch=8, max_det=300)
+    try:
+        assert not ref._lanes
+        want = []
+        for k in range(4):
+            want += ref.run_batch(batch[8 * k:8 * k + 8], 0.25, 0.45, 50)
+    finally:
+        ref.close()
+    n = 0
+    for tag, got in (("first", first), ("again", again)):
+        assert len(got) == 32
+        for i in range(32):
+            (rg, mg), (rw, mw) = got[i], want[i]
+            assert mg.num_detections == mw.num_detections and mg.det_confidence_avg == mw.det_confidence_avg, (tag, i)
+            assert len(rg) == len(rw), (tag, i)
+            for a, c in zip(rg, rw):
+                assert all(a[k] == c[k] for k in ("bbox", "det_class", "det_conf", "cls_class", "cls_conf")), (tag, i, a, c)
+                n += 1
+    assert n >= 2 * 32, f"only {n // 2} results in 32 images"
+    print(f"upload lanes: {n // 2} results in 32 images identical to the single-handle path (first call and replay)")
+
+
+def test_run_batch_chunked_equals_whole_batch(tmp_path, monkeypatch):
+    """LITEPI_RUN_CHUNK=16 (an A/B switch, off by default: no gain measured): lp_run_batch on >= 32 frames of one size walks the
+    batch in chunks of 16 (api.cpp run_batch_chunked: chunk k's upload on a copy stream under chunk k-1's kernels, every chunk a
+    complete detect -> NMS -> ROI -> classifier pass over its slice of the handle's buffers, captured per chunk).  The same
+    handle without the switch runs the batch whole: records, counts,
+    pre-filter counts and the mean-score bits must be identical, on the first (eager), second (capturing) and third (replaying)
+    call; a 40-frame batch has a ragged last chunk."""
+    from litepi import Engine
+    p, b, sd, imgs = _models(tmp_path)
+    frames = [imgs[j // 16][j % 16] for j in range(32)] + [imgs[0][j] for j in range(8)]
+    eng = Engine(precision="fp16", max_batch=40, max_det=300, num_classes=91)
+    try:
+        eng.load_detector(p, b)
+        eng.load_classifier(sd)
+        monkeypatch.delenv("LITEPI_RUN_CHUNK", raising=False)
+        want = {n: _host_reference(eng, frames[:n]) for n in (32, 40)}
+        monkeypatch.setenv("LITEPI_RUN_CHUNK", "16")
+        total = 0
+        for call in range(3):
+            for n in (32, 40):
+                dets, counts, num_det, avg = _host_reference(eng, frames[:n])
+                wd, wc, wn, wa = want[n]
+                assert np.array_equal(counts, wc) and np.array_equal(num_det, wn), (call, n)
+                assert np.array_equal(avg.view(np.uint32), wa.view(np.uint32)), (call, n)
+                for i in range(n):
+                    assert dets[i, :counts[i]].tobytes() == wd[i, :wc[i]].tobytes(), (call, n, i)
+                total += int(counts.sum())
+        assert total >= 3 * 72
+        print(f"chunked lp_run_batch: {total // 3} records in 32 + 40 frames identical to the whole-batch pass (eager, capture, replay)")
+    finally:
+        eng.close()

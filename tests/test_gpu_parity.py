@@ -348,8 +348,8 @@ def test_detector_fp16_other_sizes(tmp_path, size):
     assert err_b.mean() <= 0.5
 
 
-@pytest.mark.parametrize("size,batch", [(320, 5), (640, 7), (800, 4)])
-def test_detector_fp16_c2f_plan_other_sizes(tmp_path, monkeypatch, size, batch):
+@pytest.mark.parametrize("preset,size,batch", [("v1", 320, 5), ("v1", 640, 7), ("v1", 800, 4), ("v2", 320, 5), ("v2", 640, 7), ("v2", 416, 4)])
+def test_detector_fp16_c2f_plan_other_sizes(tmp_path, monkeypatch, preset, size, batch):
     """The whole-C2f plan (handles of >= 4 images) on maps other than 80 / 40 / 20: at 320 the 20x20 tile kernels run on a
     single tile and the 10x10 level falls back to the layer plan; at 640 every module runs fused (an odd batch of 7); at 800
     (maps 100 / 50 / 25) the tiles do not divide the maps and every module must fall back.  Mixed plans, an odd batch.
@@ -357,10 +357,13 @@ def test_detector_fp16_c2f_plan_other_sizes(tmp_path, monkeypatch, size, batch):
     LITEPI_NO_C2F=1 (every other heuristic -- tile shapes, channel splits -- depends on the capacity only, so the two handles
     differ in nothing but the whole-C2f / s2conv launches) give the fp16 error of this model at this size, and the whole-C2f
     plan must stay within 1.25 x of it (round 3 compared against a 3-image handle, whose other tile shapes forced a loose
-    bound).  The documented absolute bounds (0.02 / 0.35 cells / 0.5 px mean) are asserted for both plans at 320 and 640."""
+    bound).  The documented absolute bounds (0.02 / 0.35 cells / 0.5 px mean) are asserted for both plans at 320 and 640.
+    v2 (the paper's widths, round 4: c = 24 / 48 / 96 configurations + stem_block16): at 320 the c = 48 modules run on one
+    tile of the 20x20 map while the c = 24 (16-row tiles on a 40-row map) and c = 96 modules fall back; at 416 every module
+    falls back and the stem block runs on partial tiles (104 = 3.25 x 32 columns)."""
     from litepi import Engine, ncnn_export
     param, binf = str(tmp_path / "d.param"), str(tmp_path / "d.bin")
-    ncnn_export.export_detector(param, binf, "v1", seed=77, cls_bias=-2.0, size=size)
+    ncnn_export.export_detector(param, binf, preset, seed=77, cls_bias=-2.0, size=size)
     rng = np.random.default_rng(7)
     imgs = rng.integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
     ref, _ = _oracle_out0(param, binf, imgs)
@@ -382,7 +385,9 @@ def test_detector_fp16_c2f_plan_other_sizes(tmp_path, monkeypatch, size, batch):
     fused = [n for n in names["c2f"] if n.startswith("c2f<") or n.startswith("s2conv<")]
     print(f"fp16 {size} x{batch}: {len(names['c2f'])} launches ({len(names['layer'])} in the layer plan), whole-C2f / s2conv: {sorted(set(fused))}")
     assert not any(n.startswith("c2f<") or n.startswith("s2conv<") for n in names["layer"])
-    assert (len(fused) > 0) == (size != 800), names["c2f"]
+    assert (len(fused) > 0) == (size in (320, 640)), names["c2f"]
+    if preset == "v2":
+        assert "stem_block16_f16" in names["c2f"] and "stem_block16_f16" in names["layer"], names["c2f"]
     n8, n16, n32 = (size // 8) ** 2, (size // 16) ** 2, (size // 32) ** 2
     stride = np.concatenate([np.full(n8, 8.0), np.full(n16, 16.0), np.full(n32, 32.0)]).astype(np.float32)
     err = {}
@@ -396,21 +401,21 @@ def test_detector_fp16_c2f_plan_other_sizes(tmp_path, monkeypatch, size, batch):
         assert np.array_equal(got["c2f"], got["layer"])
     for k, (doc, floor) in enumerate(((0.02, 1e-3), (0.35, 0.01), (0.5, 0.01))):   # score, box error in grid cells of the level, mean box error (px)
         assert err["c2f"][k] <= 1.25 * err["layer"][k] + floor, f"whole-C2f plan error {err['c2f'][k]} vs layer plan {err['layer'][k]} (metric {k})"
-        if size != 800:
+        if size in (320, 640):
             assert err["c2f"][k] <= doc and err["layer"][k] <= doc, f"metric {k}: {err['c2f'][k]} / {err['layer'][k]} against the documented {doc}"
     d = np.abs(got["c2f"][:, 4] - got["layer"][:, 4]).max()
     print(f"   c2f vs layer plan on the same images: score diff max {d:.4f}")
     assert d <= max(0.02, 1.5 * err["layer"][0])
 
 
-@pytest.mark.parametrize("seed,batch", [(11, 4), (23, 6), (37, 9)])
-def test_c2f_plan_vs_layer_plan_random_models(tmp_path, seed, batch):
+@pytest.mark.parametrize("preset,seed,batch", [("v1", 11, 4), ("v1", 23, 6), ("v1", 37, 9), ("v2", 13, 4), ("v2", 29, 7)])
+def test_c2f_plan_vs_layer_plan_random_models(tmp_path, preset, seed, batch):
     """Whole-C2f plan against the layer plan (LITEPI_NO_C2F / LITEPI_NO_S2C, read when the plan is built) on further random
     models and batch sizes, no oracle in between: the two fp16 plans sum in different orders, so the same documented fp16
     bounds apply to their difference; a tile, halo or concat indexing error would show as a difference of whole activations."""
     from litepi import Engine, ncnn_export
     param, binf = str(tmp_path / "d.param"), str(tmp_path / "d.bin")
-    ncnn_export.export_detector(param, binf, "v1", seed=seed, cls_bias=-2.0)
+    ncnn_export.export_detector(param, binf, preset, seed=seed, cls_bias=-2.0)
     imgs = np.random.default_rng(seed).integers(0, 256, (batch, 640, 640, 3), dtype=np.uint8)
     out = {}
     for plan in ("c2f", "layer"):
@@ -462,8 +467,9 @@ def test_detector_fp16_out0(synth_models, preset, cap):
         names = [k["name"] for k in e.profile_read()]
     finally:
         e.close()
-    if preset == "v1":
-        assert any(n.startswith("c2f<") for n in names) == (cap >= 4), names
+    assert any(n.startswith("c2f<") for n in names) == (cap >= 4), names
+    if preset == "v2":   # the paper's widths: five whole-C2f launches (c = 24 / 48 / 96) and the 16-channel stem block
+        assert "stem_block16_f16" in names and (sum(n.startswith("c2f<") for n in names) == 5) == (cap >= 4), names
     err_s = np.abs(got[:, 4] - ref[:, 4])
     err_b = np.abs(got[:, :4] - ref[:, :4])
     print(f"{preset} fp16: score err max {err_s.max():.4f} mean {err_s.mean():.5f}; box err max {err_b.max():.3f} mean {err_b.mean():.4f}")

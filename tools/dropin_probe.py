@@ -23,7 +23,7 @@ cls = os.path.join(d, "cls.pth")
 torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in random_shufflenet_state(91, seed=0).items()}, cls)
 imgs = [np.random.default_rng(i).integers(0, 256, (640, 640, 3), dtype=np.uint8) for i in range(64)]
 for threads in (os.environ.get("THREADS", "8,16,4,0").split(",")):
-    os.environ["LITEPI_UPLOAD_THREADS"] = threads
+    os.environ["LITEPI_UPLOAD_THREADS"] = threads   # (LITEPI_DROPIN_LANES=<n> from the environment: the upload lanes of HybridPipeline)
     with contextlib.redirect_stdout(io.StringIO()):
         pipe = HybridPipeline(p, b, cls, "shufflenetv2", num_classes=91, precision="fp16", max_batch=64, max_det=300)
     try:
@@ -46,9 +46,9 @@ for threads in (os.environ.get("THREADS", "8,16,4,0").split(",")):
             pipe.engine.run_batch_device(dimg.data_ptr(), 64, 640, 640, 0.25, 0.45, 50, res.data_ptr(), res[64 * 300 * 32:].data_ptr())
             pipe.engine.synchronize()
         t_dev = (time.perf_counter() - t0) / n
-        print(f"upload threads {threads:>2s}: run_batch {t_all * 1e3:6.3f} ms ({64 / t_all:7.0f} img/s) = C-ABI call {t_eng * 1e3:6.3f} ms "
+        print(f"lanes {len(pipe._lanes)}, upload threads {threads:>2s}: run_batch {t_all * 1e3:6.3f} ms ({64 / t_all:7.0f} img/s) = C-ABI call {t_eng * 1e3:6.3f} ms "
               f"(device-resident pipeline alone {t_dev * 1e3:5.3f} ms) + Python {1e3 * (t_all - t_eng):5.3f} ms; {sum(len(r[0]) for r in out)} results", flush=True)
     finally:
-        pipe.engine.close()
+        pipe.close()
     # the static thread count is read once per process: re-exec is not allowed on the GPU box, so only the first value counts
     break

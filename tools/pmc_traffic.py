@@ -56,7 +56,7 @@ def family(name):
         return ("conv1x1_mfma<%d,up>" % ints[0] if ups else "conv1x1_mfma<%d>" % ints[0]) + f16
     if "stem_mfma_kernel" in name or "stem_conv" in name:
         return "stem_conv_f16" if "stem_mfma" in name else "stem_conv" + f16
-    for key, fam in (("letterbox", "letterbox_u8"), ("stem_block_kernel", "stem_block_f16"), ("roi_resize_kernel", "roi_resize_pil"), ("shuffle_stage_kernel", "shuffle_stage_fused_f16"),
+    for key, fam in (("letterbox", "letterbox_u8"), ("stem_block16_kernel", "stem_block16_f16"), ("stem_block_kernel", "stem_block_f16"), ("roi_resize_kernel", "roi_resize_pil"), ("shuffle_stage_kernel", "shuffle_stage_fused_f16"),
                      ("cls_head_kernel", "cls_head_fused_f16"), ("nms_kernel", "nms"), ("roi_index_kernel", "roi_index"),
                      ("cls_front_kernel", "cls_front_f16"), ("cls_back_kernel", "cls_back_f16"),
                      ("sppf_pool", "sppf_pool_f16")):

@@ -167,6 +167,10 @@ struct lp_handle {
   std::vector<ImgGeom> geom_cache;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // lp_run_batch: start, after the ROI resize, after detect + NMS, end
   int last_roi_count = 0;
+  // chunked lp_run_batch (uniform frames, >= 32 of them): uploads on copy_stream, five events per chunk, ROI totals per chunk
+  hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> chunk_ev;
+  DevBuf d_roi_hist;
   // ---- captured steps: the launch sequence of a call is a pure function of (entry point, buffers, batch, geometry,
   //      thresholds), so the second call with the same key is captured into a hipGraph and later calls replay it
   //      (one hipGraphLaunch instead of ~40 kernel launches on the host).  LITEPI_NO_GRAPH=1 keeps every call eager.
@@ -313,6 +317,9 @@ void lp_destroy(lp_handle* h) {
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  for (auto& e : h->chunk_ev)
+    if (e) (void)hipEventDestroy(e);
   h->pool.reset();
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   if (h->comm) { try { (void)rccl().CommDestroy(h->comm); } catch (...) {} }
@@ -562,11 +569,15 @@ std::vector<ImgGeom> upload_images(lp_handle* h, const uint8_t* const* imgs, con
   // groups of about 10 MB: the workers fill group k+1 while the DMA engine moves group k; an image larger than that is split
   // into slices so that every worker has a share
   std::vector<CopyPool::Job> jobs;
-  const size_t group_bytes = (size_t)10 << 20, slice = (size_t)1 << 20;
-  int i0 = 0;
+  // (the first groups are small: nothing overlaps the first group's copy, the link idles until it is staged)
+  static const size_t group_mb = getenv("LITEPI_UPLOAD_GROUP_MB") ? (size_t)atol(getenv("LITEPI_UPLOAD_GROUP_MB")) : 10;
+  const size_t slice = (size_t)1 << 20;
+  int i0 = 0, ngroup = 0;
   while (i0 < B) {
     int i1 = i0;
     size_t gb = 0;
+    const size_t group_bytes = ngroup == 0 ? (size_t)2 << 20 : (ngroup == 1 ? (size_t)5 << 20 : group_mb << 20);
+    ++ngroup;
     jobs.clear();
     while (i1 < B && (i1 == i0 || gb + (size_t)hs[i1] * ws[i1] * 3 <= group_bytes)) {
       const size_t nb = (size_t)hs[i1] * ws[i1] * 3;
@@ -580,6 +591,121 @@ std::vector<ImgGeom> upload_images(lp_handle* h, const uint8_t* const* imgs, con
     i0 = i1;
   }
   return g;
+}
+
+
+// ---- lp_run_batch on B >= 32 frames of one size, LITEPI_RUN_CHUNK=<frames> (OFF by default): the batch goes through the
+//      handle in chunks.  Chunk k's frames are staged and sent on a copy stream while chunk k-1's kernels run on the handle's
+//      stream (an event per chunk orders the two); the frames are independent, a chunk is a complete pass (detect -> NMS ->
+//      ROI resize -> classifier) over its slice of d_src with its slice of the record / count buffers, and the results are
+//      bit-identical to the whole-batch pass (tests/test_gpu_device_path.py).  Measured on a 64-frame call (tools/dropin_probe.py,
+//      one box): whole batch 2.76 ms, chunks of 32: 2.74, of 16: 3.18, of 8: 5.0 -- a pass through the 20-launch pipeline costs
+//      0.43 ms + 7 us per frame, so k chunks add (k - 1) x 0.43 ms of kernel time while hiding at most the kernels of k - 1
+//      chunks under the 1.7 ms upload: no gain at any split, hence off.
+int run_chunk_frames() {   // (read per call: tests switch it inside one process)
+  const char* e = getenv("LITEPI_RUN_CHUNK");
+  return e ? atoi(e) : 0;
+}
+bool chunked_ok(const lp_handle* h, const int* hs, const int* ws, int B) {
+  const int c = run_chunk_frames();
+  if (c <= 0 || B < 32 || B < 2 * c || h->prof_next) return false;
+  for (int i = 1; i < B; ++i)
+    if (hs[i] != hs[0] || ws[i] != ws[0]) return false;
+  return ((size_t)hs[0] * ws[0] * 3) % 16 == 0;
+}
+void run_batch_chunked(lp_handle* h, const uint8_t* const* imgs, int H, int W, int B, float conf, float iou, int min_area, lp_det* dets,
+                       int* counts, int* num_det, float* det_conf_avg, lp_timing* timing) {
+  const int CH = run_chunk_frames(), nch = (B + CH - 1) / CH;
+  const size_t img_bytes = (size_t)H * W * 3, total = img_bytes * B;
+  for (int i = 0; i < B; ++i) LP_CHECK(imgs[i], LP_ERR_ARG, "image %d is empty", i);
+  h->ensure_src(total);
+  if (h->h_stage_bytes < total) {
+    if (h->h_stage) { LP_HIP(hipStreamSynchronize(h->stream)); (void)hipHostFree(h->h_stage); h->h_stage = nullptr; h->h_stage_bytes = 0; }
+    LP_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), total + total / 4, hipHostMallocDefault));
+    h->h_stage_bytes = total + total / 4;
+  }
+  static const int n_threads = getenv("LITEPI_UPLOAD_THREADS") ? atoi(getenv("LITEPI_UPLOAD_THREADS")) : 8;
+  if (!h->pool) h->pool.reset(new CopyPool(std::max(n_threads, 1) - 1));
+  if (!h->copy_stream) LP_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  while ((int)h->chunk_ev.size() < 5 * nch) {
+    hipEvent_t e = nullptr;
+    LP_HIP(hipEventCreate(&e));
+    h->chunk_ev.push_back(e);
+  }
+  if (h->d_roi_hist.bytes < (size_t)nch * 8) h->d_roi_hist.alloc((size_t)std::max(nch, 64) * 8);
+  // every chunk sees the same geometry: frame i of the chunk at i * img_bytes behind the chunk's base
+  std::vector<ImgGeom> g(CH);
+  for (int i = 0; i < CH; ++i) g[i] = make_geom(H, W, h->cfg.det_input, (long)(i * img_bytes));
+  h->upload_geom(g);
+  std::vector<CopyPool::Job> jobs;
+  const size_t slice = (size_t)1 << 20;
+  for (int k = 0; k < nch; ++k) {
+    const int lo = k * CH, n = std::min(CH, B - lo);
+    hipEvent_t* ev = &h->chunk_ev[5 * k];
+    // stage + send: groups of 4 frames (the first one of the call: a single frame, nothing overlaps its copy)
+    int i0 = lo;
+    while (i0 < lo + n) {
+      const int i1 = std::min(lo + n, i0 + ((k == 0 && i0 == lo) ? 1 : 4));
+      jobs.clear();
+      for (int i = i0; i < i1; ++i)
+        for (size_t o = 0; o < img_bytes; o += slice) jobs.push_back({imgs[i] + o, h->h_stage + i * img_bytes + o, std::min(slice, img_bytes - o)});
+      h->pool->run(jobs.data(), (int)jobs.size());
+      LP_HIP(hipMemcpyAsync(h->d_src.as<uint8_t>() + i0 * img_bytes, h->h_stage + i0 * img_bytes, (i1 - i0) * img_bytes, hipMemcpyHostToDevice,
+                            h->copy_stream));
+      i0 = i1;
+    }
+    LP_HIP(hipEventRecord(ev[4], h->copy_stream));
+    LP_HIP(hipStreamWaitEvent(h->stream, ev[4], 0));
+    const uint8_t* src = h->d_src.as<uint8_t>() + lo * img_bytes;
+    lp_det* d = h->d_dets.as<lp_det>() + (size_t)lo * h->cfg.max_det;
+    int* c = h->d_counts.as<int>() + 3 * lo;
+    std::vector<ImgGeom> gk(g.begin(), g.begin() + n);
+    LP_HIP(hipEventRecord(ev[0], h->stream));
+    lp_handle::GraphKey k1{6, n, h->geom_ver, min_area, src, d, c, conf, iou};
+    run_or_capture(h, k1, true, [&]() {
+      enqueue_detect(h, src, gk, n, conf, nullptr, nullptr);
+      enqueue_nms(h, n, iou, min_area, d, c, true, nullptr);
+    });
+    LP_HIP(hipEventRecord(ev[1], h->stream));
+    lp_handle::GraphKey k2{7, n, h->geom_ver, min_area, src, d, c, conf, iou};
+    run_or_capture(h, k2, true, [&]() { enqueue_classify(h, src, n, d, nullptr, nullptr, nullptr, nullptr, 1); });
+    LP_HIP(hipEventRecord(ev[2], h->stream));
+    lp_handle::GraphKey k3{8, n, h->geom_ver, min_area, src, d, c, conf, iou};
+    run_or_capture(h, k3, true, [&]() { enqueue_classify(h, src, n, d, nullptr, nullptr, nullptr, nullptr, 2); });
+    LP_HIP(hipEventRecord(ev[3], h->stream));
+    LP_HIP(hipMemcpyAsync(h->d_roi_hist.as<int>() + 2 * k, h->d_roi_total.p, 8, hipMemcpyDeviceToDevice, h->stream));
+  }
+  LP_HIP(hipMemcpyAsync(dets, h->d_dets.p, (size_t)B * h->cfg.max_det * sizeof(lp_det), hipMemcpyDeviceToHost, h->stream));
+  std::vector<int> cnt(3 * B), R(2 * nch);
+  LP_HIP(hipMemcpyAsync(cnt.data(), h->d_counts.p, (size_t)3 * B * 4, hipMemcpyDeviceToHost, h->stream));
+  LP_HIP(hipMemcpyAsync(R.data(), h->d_roi_hist.p, (size_t)nch * 8, hipMemcpyDeviceToHost, h->stream));
+  LP_HIP(hipStreamSynchronize(h->stream));
+  int kept_rois = 0, want_rois = 0;
+  float t_det = 0.f, t_roi = 0.f, t_cls = 0.f, t_all = 0.f;
+  for (int k = 0; k < nch; ++k) {
+    const int lo = k * CH, n = std::min(CH, B - lo);
+    for (int i = 0; i < n; ++i) {
+      counts[lo + i] = cnt[3 * lo + i];
+      if (num_det) num_det[lo + i] = cnt[3 * lo + n + i];
+      if (det_conf_avg) memcpy(&det_conf_avg[lo + i], &cnt[3 * lo + 2 * n + i], 4);
+    }
+    kept_rois += R[2 * k];
+    want_rois = std::max(want_rois, R[2 * k + 1]);
+    if (timing) {
+      float a = 0.f, b = 0.f, c2 = 0.f;
+      (void)hipEventElapsedTime(&a, h->chunk_ev[5 * k], h->chunk_ev[5 * k + 1]);
+      (void)hipEventElapsedTime(&b, h->chunk_ev[5 * k + 1], h->chunk_ev[5 * k + 2]);
+      (void)hipEventElapsedTime(&c2, h->chunk_ev[5 * k + 2], h->chunk_ev[5 * k + 3]);
+      t_det += a; t_roi += b; t_cls += c2;
+    }
+  }
+  h->last_roi_count = kept_rois;
+  if (timing) {
+    (void)hipEventElapsedTime(&t_all, h->chunk_ev[0], h->chunk_ev[5 * (nch - 1) + 3]);
+    timing->t_detection = t_det; timing->t_roi_extract = t_roi; timing->t_classification = t_cls; timing->t_total = t_all;
+  }
+  LP_CHECK(want_rois <= h->max_rois, LP_ERR_STATE, "%d ROIs in one chunk of this batch exceed max_rois = %d: %d detections were left unclassified",
+           want_rois, h->max_rois, want_rois - h->max_rois);
 }
 
 }  // namespace
@@ -640,6 +766,10 @@ int lp_run_batch(lp_handle* h, const uint8_t* const* imgs, const int* hs, const 
   LP_CHECK(B >= 1 && B <= h->cfg.max_batch, LP_ERR_ARG, "batch %d outside 1..%d", B, h->cfg.max_batch);
   LP_CHECK(min_area >= 0, LP_ERR_ARG, "min_area must be >= 0");
   LP_HIP(hipSetDevice(h->cfg.device));
+  if (chunked_ok(h, hs, ws, B)) {
+    run_batch_chunked(h, imgs, hs[0], ws[0], B, conf, iou, min_area, dets, counts, num_det, det_conf_avg, timing);
+    return LP_OK;
+  }
   std::vector<ImgGeom> g = upload_images(h, imgs, hs, ws, B);
   h->upload_geom(g);
   Profiler* prof = begin_profile(h);

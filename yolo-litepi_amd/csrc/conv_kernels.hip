@@ -1612,13 +1612,19 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
 // packed fragments and 1x1 tail this kernel takes as they are -- is one ds_read_b128 at a static offset.
 // Replaces stem_conv + conv3x3s2_direct+1x1<2,2>: the 320x320x16 map (210 MB per 64-image step each way) never exists.
 // ------------------------------------------------------------------------------------
-#define SB16_PLANE (SB_SH * SB_LW * 16)
+template <int TH_>
+struct SB16 {
+  static constexpr int TH = TH_, TW = 32, SH = 2 * TH + 1, SW = 2 * TW + 1, LW = 65, IR = 2 * SH + 1, ROWW = 102;
+  static constexpr int PLANE = SH * LW * 16, NPIX = SH * SW, NTILE = (NPIX + 15) / 16;
+};
+template <int TH_>
 __global__ __launch_bounds__(256) void stem_block16_kernel(const StemBlockArgs a) {
-  __shared__ uint32_t in_tile[SB_IR * SB_ROWW];
-  __shared__ __attribute__((aligned(16))) char st_tile[2 * SB16_PLANE];
+  typedef SB16<TH_> K;
+  __shared__ uint32_t in_tile[K::IR * K::ROWW];
+  __shared__ __attribute__((aligned(16))) char st_tile[2 * K::PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, col = lane & 15;
-  const int n = blockIdx.x, ox0 = blockIdx.y * SB_TW, oy0 = blockIdx.z * SB_TH;
+  const int n = blockIdx.x, ox0 = blockIdx.y * K::TW, oy0 = blockIdx.z * K::TH;
   // ---- 1. uint8 tile (as stem_block_kernel)
   const int row_words = a.Win * 3 / 4;
   const int w0 = (12 * ox0 - 9) >> 2;
@@ -1626,9 +1632,9 @@ __global__ __launch_bounds__(256) void stem_block16_kernel(const StemBlockArgs a
   {
     const int c = tid & 127, r0 = tid >> 7;
     const int wi = w0 + c;
-    const bool colok = c < SB_ROWW && wi >= 0 && wi < row_words;
+    const bool colok = c < K::ROWW && wi >= 0 && wi < row_words;
     const int wic = wi < 0 ? 0 : (wi < row_words ? wi : row_words - 1);
-    constexpr int NR = (SB_IR + 1) / 2;
+    constexpr int NR = (K::IR + 1) / 2;
     uint32_t v[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -1641,7 +1647,7 @@ __global__ __launch_bounds__(256) void stem_block16_kernel(const StemBlockArgs a
       const int r = r0 + 2 * k;
       const int iy = 4 * oy0 - 3 + r;
       const uint32_t m = (colok && iy >= 0 && iy < a.Hin) ? 0xffffffffu : 0u;
-      if (c < SB_ROWW && r < SB_IR) in_tile[r * SB_ROWW + c] = v[k] & m;
+      if (c < K::ROWW && r < K::IR) in_tile[r * K::ROWW + c] = v[k] & m;
     }
   }
   const half8 af = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.afrag)[lane]);   // StemLayer::d_afrag (16-channel form)
@@ -1653,28 +1659,37 @@ __global__ __launch_bounds__(256) void stem_block16_kernel(const StemBlockArgs a
 #pragma unroll
     for (int t = 0; t < 2; ++t) a1[s][t] = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.w1)[(s * 2 + t) * 64 + lane]);
   __syncthreads();
-  // ---- 2. stem: 17 x 65 pixels, 16 per MFMA
+  // ---- 2. stem: SH x 65 pixels, 16 per MFMA, two tiles per iteration (their LDS reads are requested together: with three
+  //         workgroups per CU one tile's read -> unpack -> MFMA -> SiLU -> store chain per iteration left the SIMDs idle)
   const half2v k1024 = {(half_t)1024.f, (half_t)1024.f};
-  constexpr int NPIX = SB_SH * SB_SW, NTILE = (NPIX + 15) / 16;
-  const bool sb_interior = oy0 >= 1 && ox0 >= 1 && 2 * oy0 - 1 + SB_SH <= a.H1 && 2 * ox0 - 1 + SB_SW <= a.W1;
-  const uint8_t* t8 = reinterpret_cast<const uint8_t*>(in_tile);
-  int pi = wave * 16 + col;          // < 64 < SB_SW
-  int r = 0, c = pi;
-  for (int t = wave; t < NTILE; t += 4) {
-    const bool live = pi < NPIX;
-    const int rc = live ? r : SB_SH - 1, cc = live ? c : SB_SW - 1;
-    const int bo = 3 + 6 * cc;   // first window byte of this pixel inside a staged row
+  const bool sb_interior = oy0 >= 1 && ox0 >= 1 && 2 * oy0 - 1 + K::SH <= a.H1 && 2 * ox0 - 1 + K::SW <= a.W1;
+  // K group g < 3: bytes 0..7 of window row g (three consecutive dwords, byte-aligned); g == 3: byte 8 of the three rows (the
+  // dword two further on in each row, the same byte shift) -- one address form for all lanes: base + k * kstride
+  const int kstride = g < 3 ? 1 : K::ROWW;
+  const int gbase = g < 3 ? g * K::ROWW : 2;
+  auto stem_tile = [&](int pi, int (&d)[3], int& rc, int& cc, int& sh, bool& live) {
+    live = pi < K::NPIX;
+    const int pc = live ? pi : K::NPIX - 1;
+    rc = (pc * 1009) >> 16;              // pc / 65 for pc < 2 * 65 * 17 (1009 / 65536 = 1 / 64.95)
+    cc = pc - rc * K::SW;
+    if (cc >= K::SW) { cc -= K::SW; rc += 1; }
+    const int bo = 3 + 6 * cc;           // first window byte of this pixel inside a staged row
+    sh = bo & 3;
+    const int idx = 2 * rc * K::ROWW + (bo >> 2) + gbase;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[k] = (int)in_tile[idx + k * kstride];
+  };
+  auto stem_finish = [&](const int (&d)[3], int rc, int cc, int sh, bool live) {
     uint32_t wa, wb;
-    if (g < 3) {
-      const int idx = (2 * rc + g) * SB_ROWW + (bo >> 2);
-      const int sh = bo & 3;
-      const uint32_t d0 = in_tile[idx], d1 = in_tile[idx + 1], d2 = in_tile[idx + 2];
-      wa = __builtin_amdgcn_alignbyte(d1, d0, sh);
-      wb = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    } else {
-      const int b8 = 2 * rc * SB_ROWW * 4 + bo + 8;
-      wa = (uint32_t)t8[b8] | ((uint32_t)t8[b8 + SB_ROWW * 4] << 8) | ((uint32_t)t8[b8 + 2 * SB_ROWW * 4] << 16);
-      wb = 0u;
+    {
+      const uint32_t wa0 = __builtin_amdgcn_alignbyte((uint32_t)d[1], (uint32_t)d[0], sh);
+      const uint32_t wb0 = __builtin_amdgcn_alignbyte((uint32_t)d[2], (uint32_t)d[1], sh);
+      const uint32_t x0 = __builtin_amdgcn_alignbyte(0u, (uint32_t)d[0], sh), x1 = __builtin_amdgcn_alignbyte(0u, (uint32_t)d[1], sh),
+                     x2 = __builtin_amdgcn_alignbyte(0u, (uint32_t)d[2], sh);
+      const uint32_t y01 = __builtin_amdgcn_perm(x1, x0, 0x0c0c0400u);   // byte 0 of x0, byte 0 of x1, 0, 0
+      const uint32_t wa3 = __builtin_amdgcn_perm(x2, y01, 0x0c040100u);  // + byte 0 of x2
+      wa = g < 3 ? wa0 : wa3;
+      wb = g < 3 ? wb0 : 0u;
     }
     const uint32_t p0 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04010400u);
     const uint32_t p1 = __builtin_amdgcn_perm(0x64646464u, wa, 0x04030402u);
@@ -1693,12 +1708,17 @@ __global__ __launch_bounds__(256) void stem_block16_kernel(const StemBlockArgs a
       const uint32_t m = inside ? 0xffffffffu : 0u;
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       // channels 4g .. 4g+3: plane g >> 1, bytes 8 (g & 1) of the pixel
-      *reinterpret_cast<u32x2*>(st_tile + (g >> 1) * SB16_PLANE + (rc * SB_LW + cc) * 16 + (g & 1) * 8) =
+      *reinterpret_cast<u32x2*>(st_tile + (g >> 1) * K::PLANE + (rc * K::LW + cc) * 16 + (g & 1) * 8) =
           u32x2{__builtin_bit_cast(uint32_t, q01) & m, __builtin_bit_cast(uint32_t, q23) & m};
     }
-    pi += 64;
-    c += 64;
-    if (c >= SB_SW) { c -= SB_SW; r += 1; }
+  };
+  for (int t = wave; t < K::NTILE; t += 8) {
+    int dA[3], dB[3], rA, cA, sA, rB, cB, sB;
+    bool lA, lB;
+    stem_tile(t * 16 + col, dA, rA, cA, sA, lA);
+    stem_tile((t + 4) * 16 + col, dB, rB, cB, sB, lB);
+    stem_finish(dA, rA, cA, sA, lA);
+    stem_finish(dB, rB, cB, sB, lB);
   }
   // ---- 3. stride-2 3x3 conv from the stem planes (K group q = 4 s + g = (tap q / 2, channel half q % 2)), then the 1x1 tail
   floatx4 bias1[2], bias2[2];
@@ -1716,14 +1736,14 @@ __global__ __launch_bounds__(256) void stem_block16_kernel(const StemBlockArgs a
     int tap = q >> 1;
     tap = tap > 8 ? 8 : tap;   // padded K slots: zero weights, any finite data
     const int ky = (tap * 21846) >> 16, kx = tap - 3 * ky;
-    toff[s] = (q & 1) * SB16_PLANE + (ky * SB_LW + kx) * 16;
+    toff[s] = (q & 1) * K::PLANE + (ky * K::LW + kx) * 16;
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int t = wave * 4 + i;
+  for (int i = 0; i < K::TH / 2; ++i) {
+    const int t = wave * (K::TH / 2) + i;
     const int oy = t >> 1, ox = (t & 1) * 16 + col;
-    const char* base = st_tile + ((2 * oy) * SB_LW + 2 * ox) * 16;
+    const char* base = st_tile + ((2 * oy) * K::LW + 2 * ox) * 16;
     floatx4 v[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
@@ -2463,8 +2483,15 @@ void StemLayer::launch_block(const uint8_t* img, int N, int Hin, int Win, const 
   a.H2 = out.H; a.W2 = out.W; a.out_pitch = out.pitch; a.C2 = c1.Cout2; a.act2 = c1.act2;
   LP_CHECK(a.H2 == (a.H1 + 1) / 2 && a.W2 == (a.W1 + 1) / 2 && out.C >= c1.Cout2, LP_ERR_STATE, "stem block: output view mismatch");
   dim3 grid(N, ceil_div(a.W2, SB_TW), ceil_div(a.H2, SB_TH));
-  if (CO == 16) LP_LAUNCH(stem_block16_kernel, grid, dim3(256), 0, st, a);
-  else LP_LAUNCH(stem_block_kernel, grid, dim3(256), 0, st, a);
+  static const int th16 = getenv("LITEPI_SB16_TH") ? atoi(getenv("LITEPI_SB16_TH")) : 8;   // A/B: output rows per workgroup of the v2 kernel
+  if (CO == 16 && th16 == 4) {
+    dim3 grid4(N, ceil_div(a.W2, 32), ceil_div(a.H2, 4));
+    LP_LAUNCH(stem_block16_kernel<4>, grid4, dim3(256), 0, st, a);
+  } else if (CO == 16) {
+    LP_LAUNCH(stem_block16_kernel<8>, grid, dim3(256), 0, st, a);
+  } else {
+    LP_LAUNCH(stem_block_kernel, grid, dim3(256), 0, st, a);
+  }
   LP_HIP(hipGetLastError());
 }
 

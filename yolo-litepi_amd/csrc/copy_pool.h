@@ -8,8 +8,38 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 
 namespace lp {
+
+// Copy into the pinned staging buffer with non-temporal stores: the destination is read next by the DMA engine, never by
+// this CPU, so the lines need neither be fetched for ownership first (a plain store stream reads every destination line
+// before it overwrites it: a third of the copy's memory traffic) nor be kept in the caches.
+inline void stream_copy(uint8_t* dst, const uint8_t* src, size_t n) {
+#if defined(__x86_64__)
+  const size_t head = (64 - (reinterpret_cast<uintptr_t>(dst) & 63)) & 63;
+  if (n < 4096 || head > n) { memcpy(dst, src, n); return; }
+  memcpy(dst, src, head);
+  dst += head; src += head; n -= head;
+  const size_t body = n & ~(size_t)63;
+  for (size_t i = 0; i < body; i += 64) {
+    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i));
+    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 16));
+    const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 32));
+    const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 48));
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i), a);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 16), b);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 32), c);
+    _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 48), d);
+  }
+  _mm_sfence();
+  memcpy(dst + body, src + body, n - body);
+#else
+  memcpy(dst, src, n);
+#endif
+}
 
 // Host-side upload path of the drop-in entry points (lp_run_batch / lp_detect: the caller's images are ordinary pageable
 // NumPy arrays).  A pageable hipMemcpyAsync is staged by the runtime through its own small pinned buffers, one image after
@@ -52,7 +82,7 @@ class CopyPool {
     for (;;) {
       const int i = b.next.fetch_add(1);
       if (i >= b.n) break;
-      memcpy(b.jobs[i].dst, b.jobs[i].src, b.jobs[i].bytes);
+      stream_copy(b.jobs[i].dst, b.jobs[i].src, b.jobs[i].bytes);
       ++mine;
     }
     if (mine) b.done.fetch_add(mine);

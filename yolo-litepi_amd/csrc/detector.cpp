@@ -1260,7 +1260,7 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         break;
       case DetOp::STEMBLOCK:
         stem_.launch_block(imgs, B, S_, S_, *convs_[op.conv], view(op.out), st);
-        kname = std::string("stem_block") + sfx;
+        kname = std::string(stem_.CO == 16 ? "stem_block16" : "stem_block") + sfx;
         break;
       case DetOp::CONV: {
         const ConvLayer& c = *convs_[op.conv];

@@ -513,6 +513,7 @@ class PyTorchClassifier:
         if self.engine.cls_arch != arch:
             raise ValueError(f"the engine was created for {self.engine.cls_arch}, not {arch}")
         sd, self.weights_loaded = load_classifier_state(model_path, num_classes, arch)
+        self.state_dict = sd   # (HybridPipeline's upload lanes load the same weights)
         self.engine.load_classifier(sd)
         print(f"  Architecture: {arch}")
         print(f"  Input size: {input_size}x{input_size}")
@@ -544,14 +545,70 @@ class HybridPipeline:
         self.classifier = PyTorchClassifier(classifier_path, classifier_arch, num_classes, cls_input_size, classifier_device,
                                             _engine=self.engine)
         self.batch_size = batch_size  # kept for signature parity: all ROIs of a call are classified in one pass
+        # ---- upload lanes (an experiment kept behind LITEPI_DROPIN_LANES=<n>, off by default: measured SLOWER, 3.2-3.6 ms per
+        # 64-frame call against 2.7-2.9 for one handle -- four 16-frame passes cost 1.4 ms of kernels instead of 0.9 and four
+        # sets of copy workers fight over the cores; the overlap of upload and kernels lives inside lp_run_batch instead, which
+        # walks a large batch in chunks, api.cpp run_batch_chunked).  Lanes are further handles of max_batch / lanes images each
+        # (own stream, staging buffer, copy workers, the same models); a call's images are dealt to them in contiguous slices and
+        # every slice runs lp_run_batch on its lane from a worker thread (ctypes drops the GIL).  Results do not depend on the
+        # split (tests/test_gpu_device_path.py compares both).
+        self._lanes: List[Engine] = []
+        self._lane_pool = None
+        n_lanes = int(os.environ.get("LITEPI_DROPIN_LANES", "1"))
+        if n_lanes > 1 and max_batch >= 2 * n_lanes:
+            from concurrent.futures import ThreadPoolExecutor
+            lane_cap = -(-max_batch // n_lanes)
+            lane_rois = max_rois if max_rois <= 0 else -(-max_rois // n_lanes)
+            for _ in range(n_lanes):
+                e = Engine(precision=precision, max_batch=lane_cap, max_det=max_det, num_classes=num_classes, det_input=det_input_size,
+                           cls_input=cls_input_size, device=device, max_rois=lane_rois, numerics=numerics, cls_arch=self.engine.cls_arch)
+                e.load_detector(detector_param, detector_bin)
+                e.load_classifier(self.classifier.state_dict)
+                self._lanes.append(e)
+            self._lane_pool = ThreadPoolExecutor(max_workers=n_lanes, thread_name_prefix="litepi-lane")
+            self._lane_cap = lane_cap
         print("\nPipeline ready!")
         print("=" * 70 + "\n")
+
+    def close(self) -> None:
+        if self._lane_pool is not None:
+            self._lane_pool.shutdown(wait=True)
+            self._lane_pool = None
+        for e in self._lanes:
+            e.close()
+        self._lanes = []
+        self.engine.close()
+
+    def _run_lanes(self, images, conf, iou, min_area):
+        """run_batch's engine call over the upload lanes: contiguous slices, results concatenated in image order."""
+        B, n = len(images), len(self._lanes)
+        per = -(-B // n)
+        slices = [(k, k * per, min(B, (k + 1) * per)) for k in range(n) if k * per < B]
+
+        def one(arg):
+            k, lo, hi = arg
+            e = self._lanes[k]
+            d, c, nd, t = e.run_batch(images[lo:hi], conf, iou, min_area)
+            return d, c, nd, t, e.last_det_conf_avg
+
+        parts = list(self._lane_pool.map(one, slices))
+        dets = np.concatenate([p[0] for p in parts], 0)
+        counts = np.concatenate([p[1] for p in parts])
+        num_det = np.concatenate([p[2] for p in parts])
+        timing = LpTiming()
+        for f in ("t_detection", "t_roi_extract", "t_classification", "t_total"):   # the lanes run side by side: the longest one
+            setattr(timing, f, max(getattr(p[3], f) for p in parts))
+        self.engine.last_det_conf_avg = np.concatenate([p[4] for p in parts])
+        return dets, counts, num_det, timing
 
     def run_batch(self, images: Sequence[np.ndarray], conf_threshold: float = 0.5, iou_threshold: float = 0.45,
                   min_area: int = 100) -> List[Tuple[List[Dict], PipelineMetrics]]:
         t0 = time.perf_counter()
         try:
-            dets, counts, num_det, timing = self.engine.run_batch(images, conf_threshold, iou_threshold, min_area)
+            if self._lanes and len(images) >= 32 and len(images) <= self._lane_cap * len(self._lanes):
+                dets, counts, num_det, timing = self._run_lanes(list(images), conf_threshold, iou_threshold, min_area)
+            else:
+                dets, counts, num_det, timing = self.engine.run_batch(images, conf_threshold, iou_threshold, min_area)
         except _ffi.LitepiError as e:
             if e.code != _ffi.LP_ERR_HIP:  # misuse / capacity errors are raised, only an engine failure yields "nothing found"
                 raise
