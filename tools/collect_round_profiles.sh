@@ -14,8 +14,9 @@ grep config1 "$OUT/latency_config1.txt"
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rocprof" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 --windows 2 --no-h2d --no-dropin --inflight 1 > "$OUT/rocprof.log" 2>&1) || { echo "rocprof failed"; exit 1; }
 echo "rocprof done"
 bash tools/pmc_profile.sh "$TAG/pmc" || exit 1
-python bench.py --preset v2 --steps 30 --warmup 5 --no-cpu-baseline --no-dropin > "$OUT/bench_v2.log" 2> "$OUT/bench_v2.err" || { echo "v2 bench failed"; exit 1; }
+python bench.py --preset v2 --steps 30 --warmup 5 --no-cpu-baseline --no-dropin --dump-profile "$OUT/hipevent_per_launch_v2.json" > "$OUT/bench_v2.log" 2> "$OUT/bench_v2.err" || { echo "v2 bench failed"; exit 1; }
 tail -1 "$OUT/bench_v2.log" > "$OUT/bench_v2.json"
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rocprof_v2" -- python3 "$R/bench.py" --preset v2 --steps 20 --warmup 5 --no-cpu-baseline --profile-steps 0 --windows 2 --no-h2d --no-dropin --inflight 1 > "$OUT/rocprof_v2.log" 2>&1) || { echo "rocprof v2 failed"; exit 1; }
 echo "v2 done"
 # configs[4]: 2048 x 2048 frames, letterbox on the device: bench line, kernel trace, the two traffic passes
 python bench.py --config 4 --steps 20 --warmup 5 --windows 4 > "$OUT/bench_config4.log" 2> "$OUT/bench_config4.err" || { echo "config4 bench failed"; tail -3 "$OUT/bench_config4.err"; exit 1; }

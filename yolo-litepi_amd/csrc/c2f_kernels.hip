@@ -1060,6 +1060,8 @@ typedef C2fCfg<48, 1, 0, 144, false, 96, 0, 0, 20, 8, false> CfgV2Pan40;    // :
 typedef C2fCfg<24, 1, 96, 48, true, 48, 0, 0, 16> CfgV2Neck80;              // :116 up(F4) | P3 -> C2f(n=1) @80x80
 typedef C2fCfg<96, 1, 0, 192, false, 192, 0, 0, 10, 8, false> CfgV2Bb20;    // :63 C2f(n=1) @20x20, two half-image tiles
 typedef C2fCfg<96, 1, 0, 288, false, 192, 0, 0, 10, 8, false> CfgV2Pan20;   // :145 conv_42 | P5 -> C2f(n=1) @20x20, two half-image tiles
+typedef C2fCfg<24, 2, 0, 48, false, 48, 0, 0, 16> CfgV2Bb80;                // :13 C2f(n=2) @80x80 (halo 4)
+typedef C2fCfg<48, 2, 0, 96, false, 96, 0, 0, 10, 8, false> CfgV2Bb40;      // :30 C2f(n=2) @40x40 (halo 4, 10-row tiles)
 
 template <class CFG> struct CfgName;
 #define C2F_NAME(T, s) \
@@ -1076,6 +1078,8 @@ C2F_NAME(CfgV2Pan40, "c2f<48,1,144>")
 C2F_NAME(CfgV2Neck80, "c2f<24,1,up96+48>")
 C2F_NAME(CfgV2Bb20, "c2f<96,1,192>")
 C2F_NAME(CfgV2Pan20, "c2f<96,1,288>")
+C2F_NAME(CfgV2Bb80, "c2f<24,2,48>")
+C2F_NAME(CfgV2Bb40, "c2f<48,2,96>")
 
 template <class CFG> size_t cfg_lds() { return (size_t)CFG::LDS_BYTES; }
 
@@ -1104,7 +1108,8 @@ template <class F> bool for_each_cfg(F&& f) {
   return f.template operator()<CfgNeck40>() || f.template operator()<CfgNeck80>() || f.template operator()<CfgPan40>() ||
          f.template operator()<CfgPan20>() || f.template operator()<CfgBb20>() || f.template operator()<CfgBb80>() ||
          f.template operator()<CfgBb40>() || f.template operator()<CfgV2Neck40>() || f.template operator()<CfgV2Pan40>() ||
-         f.template operator()<CfgV2Neck80>() || f.template operator()<CfgV2Bb20>() || f.template operator()<CfgV2Pan20>();
+         f.template operator()<CfgV2Neck80>() || f.template operator()<CfgV2Bb20>() || f.template operator()<CfgV2Pan20>() ||
+         f.template operator()<CfgV2Bb80>() || f.template operator()<CfgV2Bb40>();
 }
 struct InfoFn {
   const C2fShape& s; CfgInfo& ci;
@@ -1119,6 +1124,10 @@ bool cfg_info(const C2fShape& s, CfgInfo& ci) {
   //  two-launch bottleneck plan does not have -- 65-75 us against 59; LITEPI_C2F_BB80=1 enables it for A/B runs)
   static const bool bb80 = getenv("LITEPI_C2F_BB80") != nullptr;
   if (!bb80 && s == CfgBb80::shape()) return false;
+  // (v2's n = 2 backbone module on the 80x80 map: halo-4 recompute of cv1, 145 us against 150 for its four launches and no
+  //  change of the pipelined rate -- opt-in, LITEPI_C2F_V2BB=1; the 40x40 one (10-row tiles) is on: 77 us against 118)
+  static const bool v2bb = getenv("LITEPI_C2F_V2BB") != nullptr;
+  if (!v2bb && s == CfgV2Bb80::shape()) return false;
   // A/B switch: LITEPI_C2F_SKIP=<configuration names separated by ';'> keeps those modules on the layer plan
   static const char* skip = getenv("LITEPI_C2F_SKIP");
   if (!for_each_cfg(InfoFn{s, ci})) return false;
