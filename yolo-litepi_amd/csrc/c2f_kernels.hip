@@ -40,8 +40,19 @@ namespace {
 constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 constexpr int min_c(int a, int b) { return a < b ? a : b; }
 constexpr int max_c(int a, int b) { return a > b ? a : b; }
+// how many K steps of pixel fragments from global memory a 1x1 phase keeps in flight (C2fCfg::DEEP): as many as ~180
+// registers of fragments + accumulators allow.  (Measured neutral: cv1 of the c = 24 module at depth 5 instead of 2, and of
+// v1's c = 16 FPN module at 3 instead of 2, ran in the same 82 / 46 us -- a K step's 1.3 k cycles are not one exposed round
+// trip, the fetch path is busy with the eight waves' streams whatever the depth.  Kept for v2's configurations.)
+constexpr int deep_depth(int S, int NT, int PT, bool ldsw) {
+  int d = 2;
+  for (int t = 3; t <= 6 && t <= S; ++t)
+    if ((t * (PT + (ldsw ? 0 : NT)) + (ldsw ? 2 * NT : 0) + NT * PT) * 4 <= 180) d = t;
+  return d;
+}
 
-template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_, int TH_ = 20, int NW_PERIMG = 8, bool AW_ = true>
+template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_, int TH_ = 20, int NW_PERIMG = 8, bool AW_ = true, int WPS_ = 0,
+          bool DEEP_ = false>
 struct C2fCfg {
   static constexpr int C = C_, NB = NB_, KA = KA_, KB = KB_, COUT = COUT_, MODE = MODE_, KS2 = KS2_;
   static constexpr bool UP = UP_;
@@ -59,6 +70,7 @@ struct C2fCfg {
   // general K packing of the 3x3 convs (v2's widths c = 24 / 48: a tap is not a whole number of 32-channel K steps): K group
   // q = 4 s + gam -> (tap q / (c/8), channel group q % (c/8)), a per-lane table of LDS offsets (c3_phase)
   static constexpr bool GK = C % 32 != 0 && C != 16;
+  static constexpr bool DEEP = DEEP_ || GK || C == 96;   // (v2's configurations, A/B variants of v1's: deep_depth)
   // bytes per LDS pixel of a c-channel plane: an odd number of 16-byte slots.  c % 16 != 0 (c = 24: 48 B = 3 slots): no pad at
   // all -- the lanes that own the 8 padding rows of the second channel tile skip their stores
   static constexpr int PS = C % 16 != 0 ? 2 * C : 2 * C + 16;
@@ -89,7 +101,7 @@ struct C2fCfg {
   static constexpr int CT2 = COUT / 16, NT2 = CT2 % 3 == 0 ? 3 : (CT2 >= 2 ? CT2 / 2 : 1), CB2 = CT2 / NT2, PT2 = cap_pt(NT2, cdiv_c(npt(0), NW / CB2));
   static constexpr int PT2W = cdiv_c(npt(0), NW / CB2);   // whole-image cv2: one round of blocks (pw_sync_phase)
   static constexpr int NTS = NTM, CBS = CBM, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
-  static constexpr int WPS = NW == 4 && MODE_ >= 1 ? 1 : 2;   // waves per SIMD the register allocation must allow
+  static constexpr int WPS = WPS_ > 0 ? WPS_ : (NW == 4 && MODE_ >= 1 ? 1 : 2);   // waves per SIMD the register allocation must allow
   // cv2 reads y_NB and y_{NB+1} from the LDS planes (whole K steps need c >= 32); the earlier segments from the concat buffer
   static constexpr bool CV2_LDS = (C >= 32 && !GK) || Y01;
   static constexpr int K2G = Y01 ? 0 : (CV2_LDS ? NB * C : (2 + NB) * C);
@@ -331,7 +343,8 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
     for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
     // (whole-image cv1: 8 waves on the CU and a handful of K steps -- the pixel fragments of up to 5 steps ahead are in flight,
     //  at depth 3 the K loop ran at the L2 round trip: 18 B/clk for the CU)
-    constexpr int DB = (CFG::PERIMG && LDSW) ? min_c(S, 5) : (((NT * PT <= 20 && CFG::C >= 32) || (CFG::WPS == 1 && NT * PT <= 28)) ? 3 : 2);
+    constexpr int DB = CFG::DEEP ? deep_depth(S, NT, PT, LDSW)
+                                 : ((CFG::PERIMG && LDSW) ? min_c(S, 5) : (((NT * PT <= 20 && CFG::C >= 32) || (CFG::WPS == 1 && NT * PT <= 28)) ? 3 : 2));
     constexpr int DA = LDSW ? 2 : DB;
     if (stamp0 >= 0) { C2F_ISTAMP(stamp0) }
     kloop<S, DA, DB, NT, PT>(
