@@ -425,13 +425,14 @@ def main():
                               "of profiled (eager) passes, this process"}
         # HBM bytes per launch from the PMC passes (separate rocprofv3 runs, tools/pmc_profile.sh + tools/pmc_traffic.py;
         # committed under profiles/): offline by nature, read here so that the line carries it next to `achieved`
-        tfile = os.path.join(_ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic.json")
-        if os.path.exists(tfile) and args.preset == "v1" and args.precision == "fp16" and B == 64:
+        tname = f"{PROFILE_ROUND}_pmc_traffic.json" if args.preset == "v1" else f"{PROFILE_ROUND}_pmc_traffic_{args.preset}.json"
+        tfile = os.path.join(_ROOT, "profiles", tname)
+        if os.path.exists(tfile) and args.precision == "fp16" and B == 64 and args.config == 2:
             with open(tfile) as fh:
                 fams = json.load(fh).get("families", {})
             if dom in fams:
                 roofline["traffic"] = fams[dom]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = (f"profiles/{PROFILE_ROUND}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                roofline["traffic_source"] = (f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
                                               "same workload, separate passes)")
                 if "rocprof_avg_launch_ms" in fams[dom]:
                     roofline["avg_launch_ms_rocprof"] = fams[dom]["rocprof_avg_launch_ms"]

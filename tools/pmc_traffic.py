@@ -44,7 +44,10 @@ def family(name):
         t = [int(x) for x in re.findall(r"\d+", args)] if args else ints
         toks = [x.strip() for x in args.lstrip("<").split(",")] if args else []
         a16 = (len(toks) > 8 and toks[8] == "true") or (not args and name.count("Lb1E") >= 1 and re.search(r"Lb[01]ELb1E", name) is not None)
-        return "head_fused<%s>%s_f16" % (",".join(str(x) for x in t[:6]), "a16" if a16 else "")
+        sfx = "a16" if a16 else ""
+        if a16 and t[0] == 2 and len(t) > 6:   # two class row tiles (v2): the library's name carries K steps per tap, Cin / 16
+            sfx += "k%d" % {(12, 3): 3, (12, 4): 6, (24, 4): 12}.get((t[5], t[6]), 0)
+        return "head_fused<%s>%s_f16" % (",".join(str(x) for x in t[:6]), sfx)
     if "conv3x3s2_direct_kernel" in name:   # <T, NT, NP, T2, U>
         t2 = ints[2] if len(ints) > 2 else 0
         return ("conv3x3s2_direct+1x1<%d,%d>" % (ints[0], t2) if t2 else "conv3x3s2_direct<%d>" % ints[0]) + f16
