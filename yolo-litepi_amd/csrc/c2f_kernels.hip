@@ -103,7 +103,7 @@ struct C2fCfg {
   static constexpr int NTS = NTM, CBS = CBM, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
   static constexpr int WPS = WPS_ > 0 ? WPS_ : (NW == 4 && MODE_ >= 1 ? 1 : 2);   // waves per SIMD the register allocation must allow
   // cv2 reads y_NB and y_{NB+1} from the LDS planes (whole K steps need c >= 32); the earlier segments from the concat buffer
-  static constexpr bool CV2_LDS = (C >= 32 && !GK) || Y01;
+  static constexpr bool CV2_LDS = C >= 32 || Y01 || GK;
   static constexpr int K2G = Y01 ? 0 : (CV2_LDS ? NB * C : (2 + NB) * C);
   // weights staged in LDS (tile configurations): fragment bytes of every phase, in execution order
   static constexpr bool AW = !PERIMG && AW_;
@@ -358,6 +358,87 @@ __device__ __forceinline__ void pw_phase(const Ctx& cx, const Rg& rg, const char
             else if (s < SG + SL0) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl0 + pb[SL0 + SL1 > 0 ? i : 0] * PSL0 + cx.gam * 16 + (s - SG) * 64));
             // (a 16-channel plane 1: the lanes of K groups 2, 3 re-read groups 0, 1 -- their weights are zero)
             else bf[i] = as_h8(*reinterpret_cast<const u32x4*>(pl1 + pb[SL0 + SL1 > 0 ? i : 0] * PSL1 + (KL1 % 32 ? (cx.gam & 1) : cx.gam) * 16 + (s - SG - SL0) * 64));
+          }
+        },
+        NoFix{});
+    if (stamp0 >= 0) { C2F_ISTAMP(stamp0 + 1) }
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int p0 = (pbk * PT + i) * 16 + cx.sig;
+      const bool ok = p0 < rg.R;
+      const int p = ok ? p0 : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      floatx4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
+      epi(cb, ok, py, px, v);
+    }
+    if (stamp0 >= 0) { C2F_ISTAMP(stamp0 + 2) }
+  }
+}
+
+// ---- cv2 of the general-K configurations (c = 24 / 48: the concat's segments are not whole K steps).  K group q = 4 s + gam of
+//      concat(y0 .. y_{NB+1}) comes from the concat buffer in global memory while q < K2G / 8 (y0 .. y_{NB-1}), from plane 0 for the
+//      next c / 8 groups (y_NB) and from plane 1 for the last c / 8 (y_{NB+1}): a per-lane table of source and offset per step,
+//      at most one step of a phase mixes global and LDS lanes.  The weights keep the plain channel order of pw_phase.  With every
+//      y segment read back from the concat buffer (the first version) the c = 24 module on the 80 x 80 map moved 298 MB per launch,
+//      118 MB of it these segments.
+template <class CFG, int NT, int CB, int PT, bool LDSW, class EPI>
+__device__ __forceinline__ void pw_gk_phase(const Ctx& cx, const Rg& rg, const char* __restrict__ cat, int cat_pitch, const char* pl0, const char* pl1,
+                                            const ASrc<LDSW>& wsrc, const float* __restrict__ bias, EPI&& epi, int stamp0 = -1) {
+  constexpr int G0 = CFG::K2G / 8, GC = CFG::C / 8, GT = G0 + 2 * GC, S = cdiv_c(GT, 4), PS = CFG::PS;
+  static_assert(CFG::PS0 == CFG::PS && G0 >= 1, "one pixel pitch for both planes; y0 comes from the concat buffer");
+  int goff[S];            // global lanes: byte offset of the lane's K group inside the pixel
+  const char* lbase[S];   // LDS lanes: plane base + offset of the lane's K group inside the pixel
+  bool isg[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    int q = 4 * s + cx.gam;
+    q = q < GT ? q : GT - 1;   // (the groups past the concat carry zero weights and re-read the last real one)
+    isg[s] = q < G0;
+    goff[s] = (q < G0 ? q : G0 - 1) * 16;
+    const int ql = q < G0 ? 0 : q - G0;
+    lbase[s] = ql < GC ? pl0 + ql * 16 : pl1 + (ql - GC) * 16;
+  }
+  const int npt = (rg.R + 15) >> 4;
+  const int nblk = ((npt + PT - 1) / PT) * CB;
+  for (int blk = cx.wave; blk < nblk; blk += CFG::NW) {
+    const int cb = blk % CB, pbk = blk / CB;
+    unsigned offB[PT];
+    int pb[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      int p = (pbk * PT + i) * 16 + cx.sig;
+      p = p < rg.R ? p : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      offB[i] = (unsigned)(((cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px) * cat_pitch) * 2u;
+      pb[i] = ((rg.fy0 + py) * CFG::LW + rg.fx0 + px) * PS;
+    }
+    floatx4 acc[NT][PT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    int woff = (cb * S * NT * 64 + cx.lane) * 16;
+    asm volatile("" : "+v"(woff));
+    floatx4 bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+    constexpr int DB = deep_depth(S, NT, PT, LDSW);
+    constexpr int DA = LDSW ? 2 : DB;
+    if (stamp0 >= 0) { C2F_ISTAMP(stamp0) }
+    kloop<S, DA, DB, NT, PT>(
+        acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
+        [&](int s, half8(&bf)[PT]) {
+          const bool pure_g = 4 * s + 3 < G0, pure_l = 4 * s >= G0;   // (compile-time after unrolling)
+#pragma unroll
+          for (int i = 0; i < PT; ++i) {
+            if (pure_g) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(cat + (size_t)offB[i] + goff[s]));
+            else if (pure_l) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(lbase[s] + pb[i]));
+            else if (isg[s]) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(cat + (size_t)offB[i] + goff[s]));
+            else bf[i] = as_h8(*reinterpret_cast<const u32x4*>(lbase[s] + pb[i]));
           }
         },
         NoFix{});
@@ -964,6 +1045,8 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
                 store_h<NT>((chb < C ? P0 : P1) + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + (chb < C ? chb : chb - C) * 2, h);
             }
           }, 11);
+    } else if constexpr (CFG::GK) {
+      pw_gk_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, AW>(cx, rg, cat, a.cat_pitch, P0, P1, wsrc(2 * NB + 1, C2F_W_CV2), a.b[C2F_W_CV2], epi_cv2, 11);
     } else {
       pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, CFG::K2G, (CFG::CV2_LDS ? (CFG::Y01 ? 2 * C : C) : 0), (CFG::CV2_LDS ? C : 0), false, AW,
                decltype(epi_cv2)&, PS0, PS>(cx, rg, nullptr, 0, cat, a.cat_pitch, P0, P1, wsrc(2 * NB + 1, C2F_W_CV2), a.b[C2F_W_CV2], epi_cv2, 11);
