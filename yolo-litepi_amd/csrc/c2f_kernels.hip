@@ -1220,10 +1220,8 @@ bool cfg_info(const C2fShape& s, CfgInfo& ci) {
   //  two-launch bottleneck plan does not have -- 65-75 us against 59; LITEPI_C2F_BB80=1 enables it for A/B runs)
   static const bool bb80 = getenv("LITEPI_C2F_BB80") != nullptr;
   if (!bb80 && s == CfgBb80::shape()) return false;
-  // (v2's n = 2 backbone module on the 80x80 map: halo-4 recompute of cv1, 145 us against 150 for its four launches and no
-  //  change of the pipelined rate -- opt-in, LITEPI_C2F_V2BB=1; the 40x40 one (10-row tiles) is on: 77 us against 118)
-  static const bool v2bb = getenv("LITEPI_C2F_V2BB") != nullptr;
-  if (!v2bb && s == CfgV2Bb80::shape()) return false;
+  // (v2's n = 2 backbone modules run as one launch each: 139 us against 150 for the four launches of the 80x80 one -- 145 before
+  //  cv2 took y2 / y3 from the planes --, +1.5 % of the pipelined rate; 10-row tiles on the 40x40 map: 74 against 118)
   // A/B switch: LITEPI_C2F_SKIP=<configuration names separated by ';'> keeps those modules on the layer plan
   static const char* skip = getenv("LITEPI_C2F_SKIP");
   if (!for_each_cfg(InfoFn{s, ci})) return false;
