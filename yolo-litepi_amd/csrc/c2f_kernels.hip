@@ -103,7 +103,10 @@ struct C2fCfg {
   static constexpr int NTS = NTM, CBS = CBM, PTS = cdiv_c(npt(0), NW / CBS);  // SPPF.cv1 (c outputs)
   static constexpr int WPS = WPS_ > 0 ? WPS_ : (NW == 4 && MODE_ >= 1 ? 1 : 2);   // waves per SIMD the register allocation must allow
   // cv2 reads y_NB and y_{NB+1} from the LDS planes (whole K steps need c >= 32); the earlier segments from the concat buffer
-  static constexpr bool CV2_LDS = C >= 32 || Y01 || GK;
+  // cv2's K steps straddle the concat's segments (c = 24 / 48; c = 16 with two bottlenecks: 32 channels of y0 | y1 from the concat
+  // buffer, y2 and y3 from the planes): pw_gk_phase's per-lane source table
+  static constexpr bool CV2_TAB = GK || (C == 16 && NB == 2);
+  static constexpr bool CV2_LDS = C >= 32 || Y01 || CV2_TAB;
   static constexpr int K2G = Y01 ? 0 : (CV2_LDS ? NB * C : (2 + NB) * C);
   // weights staged in LDS (tile configurations): fragment bytes of every phase, in execution order
   static constexpr bool AW = !PERIMG && AW_;
@@ -1045,7 +1048,7 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
                 store_h<NT>((chb < C ? P0 : P1) + ((rg.fy0 + py) * LW + rg.fx0 + px) * PS + (chb < C ? chb : chb - C) * 2, h);
             }
           }, 11);
-    } else if constexpr (CFG::GK) {
+    } else if constexpr (CFG::CV2_TAB) {
       pw_gk_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, AW>(cx, rg, cat, a.cat_pitch, P0, P1, wsrc(2 * NB + 1, C2F_W_CV2), a.b[C2F_W_CV2], epi_cv2, 11);
     } else {
       pw_phase<CFG, CFG::NT2, CFG::CB2, CFG::PT2, 0, CFG::K2G, (CFG::CV2_LDS ? (CFG::Y01 ? 2 * C : C) : 0), (CFG::CV2_LDS ? C : 0), false, AW,
