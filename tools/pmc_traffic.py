@@ -19,8 +19,8 @@ import sys
 def family(name):
     f16 = "_f16" if "DF16_" in name or "<f16" in name else "_f32"
     ints = [int(v) for v in re.findall(r"Li(\d+)E", name)]
-    if "s2conv_kernel" in name:
-        m = re.search(r"S2Cfg<(\d+), *(\d+)[,>]", name)
+    if "s2conv_kernel" in name or "s2lds_kernel" in name:   # both run under the library's profile name s2conv<Cin,Cout>
+        m = re.search(r"S2L?Cfg<(\d+), *(\d+)[,>]", name)
         v = [int(m.group(1)), int(m.group(2))] if m else [int(x) for x in re.findall(r"Li(\d+)E", name)][:2]
         return "s2conv<%d,%d>_f16" % tuple(v)
     if "c2f_kernel" in name:   # C2fCfg<C, NB, KA, KB, UP, COUT, MODE, KS2, TH, NW>: the profiler's name is CfgName of c2f_kernels.hip
