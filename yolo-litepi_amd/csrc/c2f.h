@@ -85,7 +85,8 @@ struct C2fLayer {
 // Stand-alone 3x3 stride-2 conv + SiLU on the c2f machinery (s2conv_kernel): weights [cout][tap][cin] over physical channels
 struct S2ConvLayer {
   int Cin = 0, Cout = 0, H = 0, W = 0;   // H, W: OUTPUT map
-  bool lds_staged = false;               // s2lds_kernel (input tile in LDS: v2's Cin 24 / 48) instead of the gather kernel
+  bool lds_staged = false;               // s2lds_kernel (input tile in LDS: v2's Cin 24 / 48 / 96) instead of the gather kernel
+  int ksplit = 1;                        // its passes over the input channels
   std::string name;
   DevBuf d_w, d_b;
   static bool supported(int cin, int cout, int hout, int wout);

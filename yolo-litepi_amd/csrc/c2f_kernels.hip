@@ -1149,23 +1149,26 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2conv_kernel(const C2fArgs a
 //      packing for Cin 24 / 48 (c3_pack's order), the weights of this workgroup's output channels in a second LDS region.
 //      OSPLIT workgroups share an output tile (each stages the input tile and computes COUT / OSPLIT channels) when the whole
 //      weight set would not fit beside the plane.
-template <int CIN_, int COUT_, int TH_, int OSPLIT_>
+template <int CIN_, int COUT_, int TH_, int OSPLIT_, int KSPLIT_ = 1>
 struct S2LCfg {
-  static constexpr int CIN = CIN_, COUT = COUT_, TH = TH_, TW = 20, NW = 8, OSPLIT = OSPLIT_;
+  static constexpr int CIN = CIN_, COUT = COUT_, TH = TH_, TW = 20, NW = 8, OSPLIT = OSPLIT_, KSPLIT = KSPLIT_;
   static constexpr int COUTW = COUT / OSPLIT;   // output channels of one workgroup
+  static constexpr int CINH = CIN / KSPLIT;     // input channels of one pass (Cin 96: two passes of 48 -- a 21 x 41 plane of 96 is 179 KB)
   static constexpr int CT = COUTW / 16, NT = CT % 3 == 0 ? 3 : min_c(CT, 4), CB = CT / NT;
-  static constexpr bool GK = CIN % 32 != 0;
-  static constexpr int G = CIN / 8, S = GK ? cdiv_c(9 * G, 4) : 9 * (CIN / 32);
+  static constexpr bool GK = CINH % 32 != 0;
+  static constexpr int G = CINH / 8, S = GK ? cdiv_c(9 * G, 4) : 9 * (CINH / 32);   // K groups per tap, K steps per pass
   static constexpr int IH = 2 * TH + 1, IW = 2 * TW + 1, LW = IW;
-  static constexpr int PS = CIN % 16 != 0 ? 2 * CIN : 2 * CIN + 16;   // an odd number of 16-byte slots (C2fCfg::PS)
+  static constexpr int PS = CINH % 16 != 0 ? 2 * CINH : 2 * CINH + 16;   // an odd number of 16-byte slots (C2fCfg::PS)
   static constexpr int PLANE = ((IH * LW * PS + 1023) / 1024) * 1024, WBYTES = CT * S * 1024, LDS_BYTES = PLANE + WBYTES;
-  static constexpr int NPT = cdiv_c(TH * TW, 16), PT = cdiv_c(NPT, NW / CB);
-  static_assert(COUT % (16 * OSPLIT) == 0 && COUTW % (16 * NT) == 0 && NW % CB == 0 && LDS_BYTES <= 160 * 1024, "s2lds: shape");
+  static constexpr int NPT = cdiv_c(TH * TW, 16), PT = cdiv_c(NPT, NW / CB), NBLK = cdiv_c(NPT, PT) * CB;
+  static_assert(COUT % (16 * OSPLIT) == 0 && COUTW % (16 * NT) == 0 && NW % CB == 0 && CIN % (8 * KSPLIT) == 0 && LDS_BYTES <= 160 * 1024 && NBLK <= NW,
+                "s2lds: shape (one block per wave: the accumulators live across the passes)");
+  static_assert(CB == 1 || KSPLIT == 1, "the packed weights are [channel block][all K steps]: a pass is contiguous only for one block");
 };
 template <class CFG>
 __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CIN = CFG::CIN, TH = CFG::TH, TW = CFG::TW, NT = CFG::NT, CB = CFG::CB, PT = CFG::PT, S = CFG::S, LW = CFG::LW, PS = CFG::PS, G = CFG::G;
+  constexpr int TH = CFG::TH, TW = CFG::TW, NT = CFG::NT, CB = CFG::CB, PT = CFG::PT, S = CFG::S, LW = CFG::LW, PS = CFG::PS, G = CFG::G;
   char* PL = smem;
   char* WS = smem + CFG::PLANE;
   Ctx cx;
@@ -1184,35 +1187,6 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a)
   cx.oy0 = ty * TH; cx.ox0 = tx * TW;
   cx.H = a.H; cx.W = a.W;
   cx.st = nullptr; cx.dbg = 0;
-  // ---- weights of this workgroup's COUTW output channels -> WS (LDS-DMA), input tile -> PL
-  stage_weights(cx, reinterpret_cast<const char*>(a.w[C2F_W_S2]) + (size_t)os * CFG::WBYTES, WS, CFG::WBYTES, CFG::NW);
-  {
-    const int H2 = 2 * a.H, W2 = 2 * a.W, iy0 = 2 * cx.oy0 - 1, ix0 = 2 * cx.ox0 - 1;
-    const char* src = reinterpret_cast<const char*>(a.s2_in);
-    // (every piece of the tile is requested before the first is stored: 6 / 11 loads per thread in flight; in rounds of four
-    //  the copy was three exposed memory round trips)
-    constexpr int NPIECE = CFG::IH * CFG::IW * G, NTHR = CFG::NW * 64, U = cdiv_c(NPIECE, NTHR);
-    for (int it0 = threadIdx.x; it0 < NPIECE; it0 += U * NTHR) {
-      u32x4 v[U];
-      int dst[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {   // all U pieces are requested before the first is stored
-        const int it = it0 + u * NTHR;
-        const int itc = it < NPIECE ? it : NPIECE - 1;
-        const int pix = itc / G, cg = itc - pix * G;
-        const int ry = pix / CFG::IW, rx = pix - ry * CFG::IW;
-        const int iy = iy0 + ry, ix = ix0 + rx;
-        const bool in = it < NPIECE && iy >= 0 && iy < H2 && ix >= 0 && ix < W2;
-        const int iyc = in ? iy : 0, ixc = in ? ix : 0;
-        const u32x4 q = *reinterpret_cast<const u32x4*>(src + (size_t)((unsigned)((cx.n * H2 + iyc) * W2 + ixc) * (unsigned)a.s2_pitch) * 2 + cg * 16);
-        v[u] = in ? q : u32x4{0u, 0u, 0u, 0u};
-        dst[u] = it < NPIECE ? (ry * LW + rx) * PS + cg * 16 : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (dst[u] >= 0) *reinterpret_cast<u32x4*>(PL + dst[u]) = v[u];
-    }
-  }
   // K step -> LDS offset of this lane's K group from the pixel's top-left tap (c3_phase's two forms)
   int soff[S];
 #pragma unroll
@@ -1224,44 +1198,81 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a)
       const int t3 = (tap * 11) >> 5;   // tap / 3 for tap < 9
       soff[s] = (t3 * LW + tap - 3 * t3) * PS + cg * 16;
     } else {
-      constexpr int SPT = CIN / 32;
+      constexpr int SPT = CFG::CINH / 32;
       const int tap = s / SPT, cblk = s - tap * SPT;
       const int t3 = (tap * 11) >> 5;
       soff[s] = (t3 * LW + tap - 3 * t3) * PS + cblk * 64 + cx.gam * 16;
     }
   }
-  wg_sync();
-  char* xo = reinterpret_cast<char*>(a.x);
-  constexpr int NBLK = cdiv_c(CFG::NPT, PT) * CB;
+  // one block per wave: channel block cb, PT pixel tiles
+  const bool has = cx.wave < CFG::NBLK;   // wave-uniform
+  const int blk = has ? cx.wave : 0;
+  const int cb = blk % CB, pbk = blk / CB;
+  int pb[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    int p = (pbk * PT + i) * 16 + cx.sig;
+    p = p < TH * TW ? p : TH * TW - 1;
+    const int py = p / TW, px = p - py * TW;
+    pb[i] = (2 * py * LW + 2 * px) * PS;   // the window's top-left tap: input pixel (2 oy - 1, 2 ox - 1) = plane (2 py, 2 px)
+  }
+  floatx4 acc[NT][PT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
   const float* bias = a.b[C2F_W_S2] + os * CFG::COUTW;
-  for (int blk = cx.wave; blk < NBLK; blk += CFG::NW) {
-    const int cb = blk % CB, pbk = blk / CB;
-    int pb[PT];
+  floatx4 bv[NT];
 #pragma unroll
-    for (int i = 0; i < PT; ++i) {
-      int p = (pbk * PT + i) * 16 + cx.sig;
-      p = p < TH * TW ? p : TH * TW - 1;
-      const int py = p / TW, px = p - py * TW;
-      pb[i] = (2 * py * LW + 2 * px) * PS;   // the window's top-left tap: input pixel (2 oy - 1, 2 ox - 1) = plane (2 py, 2 px)
+  for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+#pragma unroll 1
+  for (int h = 0; h < CFG::KSPLIT; ++h) {
+    // ---- this pass's weights (COUTW output channels, CINH input channels) -> WS by LDS-DMA; its input channels of the tile -> PL
+    stage_weights(cx, reinterpret_cast<const char*>(a.w[C2F_W_S2]) + ((size_t)os * CFG::KSPLIT + h) * CFG::WBYTES, WS, CFG::WBYTES, CFG::NW);
+    {
+      const int H2 = 2 * a.H, W2 = 2 * a.W, iy0 = 2 * cx.oy0 - 1, ix0 = 2 * cx.ox0 - 1;
+      const char* src = reinterpret_cast<const char*>(a.s2_in) + h * CFG::CINH * 2;
+      // (every piece of the tile is requested before the first is stored: 6 / 11 loads per thread in flight; in rounds of four
+      //  the copy was three exposed memory round trips)
+      constexpr int NPIECE = CFG::IH * CFG::IW * G, NTHR = CFG::NW * 64, U = cdiv_c(NPIECE, NTHR);
+      for (int it0 = threadIdx.x; it0 < NPIECE; it0 += U * NTHR) {
+        u32x4 v[U];
+        int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int it = it0 + u * NTHR;
+          const int itc = it < NPIECE ? it : NPIECE - 1;
+          const int pix = itc / G, cg = itc - pix * G;
+          const int ry = pix / CFG::IW, rx = pix - ry * CFG::IW;
+          const int iy = iy0 + ry, ix = ix0 + rx;
+          const bool in = it < NPIECE && iy >= 0 && iy < H2 && ix >= 0 && ix < W2;
+          const int iyc = in ? iy : 0, ixc = in ? ix : 0;
+          const u32x4 q = *reinterpret_cast<const u32x4*>(src + (size_t)((unsigned)((cx.n * H2 + iyc) * W2 + ixc) * (unsigned)a.s2_pitch) * 2 + cg * 16);
+          v[u] = in ? q : u32x4{0u, 0u, 0u, 0u};
+          dst[u] = it < NPIECE ? (ry * LW + rx) * PS + cg * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (dst[u] >= 0) *reinterpret_cast<u32x4*>(PL + dst[u]) = v[u];
+      }
     }
-    floatx4 acc[NT][PT];
+    wg_sync();
+    if (has) {
+      int woff = (cb * S * NT * 64 + cx.lane) * 16;
+      asm volatile("" : "+v"(woff));
+      const ASrc<true> wsrc{WS};
+      kloop<S, 2, 2, NT, PT>(
+          acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
+          [&](int s, half8(&bf)[PT]) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    int woff = (cb * S * NT * 64 + cx.lane) * 16;
-    asm volatile("" : "+v"(woff));
-    floatx4 bv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
-    const ASrc<true> wsrc{WS};
-    kloop<S, 2, 2, NT, PT>(
-        acc, [&](int s, half8(&af)[NT]) { wsrc.template load<NT>(woff, s, af); },
-        [&](int s, half8(&bf)[PT]) {
-#pragma unroll
-          for (int i = 0; i < PT; ++i) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(PL + pb[i] + soff[s]));
-        },
-        NoFix{});
+            for (int i = 0; i < PT; ++i) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(PL + pb[i] + soff[s]));
+          },
+          NoFix{});
+    }
+    if (h + 1 < CFG::KSPLIT) lds_sync();   // every wave has read the plane and the weights before the next pass overwrites them
+  }
+  if (has) {
+    char* xo = reinterpret_cast<char*>(a.x);
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int p = (pbk * PT + i) * 16 + cx.sig;
@@ -1271,17 +1282,23 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a)
       floatx4 v[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
-      half_t h[4 * NT];
-      to_half<NT>(v, h);
+      half_t hh[4 * NT];
+      to_half<NT>(v, hh);
       const int chb = os * CFG::COUTW + cb * 16 * NT + 4 * NT * cx.g;
       const int gpix = (cx.n * cx.H + cx.oy0 + py) * cx.W + cx.ox0 + px;
-      if (ok) store_h<NT>(xo + (size_t)((unsigned)gpix * (unsigned)a.x_pitch) * 2 + chb * 2, h);
+      if (ok) store_h<NT>(xo + (size_t)((unsigned)gpix * (unsigned)a.x_pitch) * 2 + chb * 2, hh);
     }
   }
 }
 typedef S2LCfg<24, 48, 10, 1> S2L24x48;   // yolo_plus model.ncnn.param:10 (conv_8: 24 -> 48 @80x80): 41 KB plane + 21 KB of weights
 typedef S2LCfg<48, 96, 10, 2> S2L48x96;   // :27 (conv_15: 48 -> 96 @40x40): 96 KB plane + 42 KB of weights, two workgroups per tile
 typedef S2LCfg<48, 48, 10, 1> S2L48x48;   // :129 (conv_37: 48 -> 48 @40x40)
+typedef S2LCfg<48, 96, 10, 2, 2> S2L48x96k2;   // the same in two passes of 24 input channels: 41 + 21 KB, two workgroups per CU
+typedef S2LCfg<48, 48, 10, 1, 2> S2L48x48k2;
+// (v1's 32 -> 64 convs as S2LCfg<32, 64, 10, 1, 2>, two passes of 16 channels: 22.9 / 16.2 us against 22.0 / 14.0 for the gather kernel
+//  above -- at Cin 32 the tile copy costs what the gathers cost; they stay on s2conv_kernel)
+typedef S2LCfg<96, 192, 10, 4, 2> S2L96x192;   // :44 (conv_22: 96 -> 192 @20x20): two passes of 48 input channels, four workgroups per tile
+typedef S2LCfg<96, 96, 10, 2, 2> S2L96x96;     // :142 (conv_42: 96 -> 96 @20x20)
 
 typedef S2Cfg<32, 64> S2Cfg32x64;   // model.ncnn.param:41 (conv_15: 32 -> 64 @40x40) and :118 (conv_37)
 typedef S2Cfg<32, 64, 10> S2Cfg32x64h;   // half-height tiles: twice the workgroups (A/B: LITEPI_S2C_TH10=1)
@@ -1507,7 +1524,9 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
 // the LDS-staged kernel's shapes (v2): s2lds_kernel<S2LCfg<..>>; LITEPI_NO_S2LDS=1 keeps them on conv3x3s2_direct (A/B)
 static bool s2lds_shape(int cin, int cout, int hout, int wout) {
   static const bool off = getenv("LITEPI_NO_S2LDS") != nullptr;
-  return !off && hout % 10 == 0 && wout % 20 == 0 && ((cin == 24 && cout == 48) || (cin == 48 && (cout == 96 || cout == 48)));
+  static const bool off96 = getenv("LITEPI_NO_S2LDS96") != nullptr;
+  return !off && hout % 10 == 0 && wout % 20 == 0 &&
+         ((cin == 24 && cout == 48) || (cin == 48 && (cout == 96 || cout == 48)) || (!off96 && cin == 96 && (cout == 192 || cout == 96)));
 }
 bool S2ConvLayer::supported(int cin, int cout, int hout, int wout) {
   return (cin == 32 && cout == 64 && hout % 20 == 0 && wout % 20 == 0) || s2lds_shape(cin, cout, hout, wout);
@@ -1517,11 +1536,15 @@ void S2ConvLayer::build(int cin, int cout, int hout, int wout, const std::vector
   LP_CHECK(supported(cin, cout, hout, wout), LP_ERR_STATE, "s2conv: unsupported shape %d -> %d @%dx%d", cin, cout, hout, wout);
   Cin = cin; Cout = cout; H = hout; W = wout;
   lds_staged = s2lds_shape(cin, cout, hout, wout);
-  if (lds_staged) {   // general K packing (tap, 8-channel group), three channel tiles per block: S2LCfg / c3_phase's order
-    const int G = cin / 8, S = (9 * G + 3) / 4;
-    pack_phase(d_w, w_taps, cout, 9 * cin, 3, S, [&](int s_, int g, int j) {
-      const int q = 4 * s_ + gam_of(g);
-      return q < 9 * G ? (q / G) * cin + 8 * (q % G) + j : -1;
+  if (lds_staged) {   // general K packing (tap, 8-channel group), three channel tiles per block: S2LCfg / c3_phase's order;
+                      // Cin 96: two passes of 48 input channels, the second pass's steps behind the first's
+    ksplit = cin == 96 || (cin == 48 && !getenv("LITEPI_S2LDS_K1")) ? 2 : 1;
+    const int cinh = cin / ksplit;
+    const int G = cinh / 8, S = (9 * G + 3) / 4;
+    const int nt = 3;   // S2LCfg::NT of every configuration launch() picks (48 output channels = 3 tiles per workgroup)
+    pack_phase(d_w, w_taps, cout, 9 * cin, nt, ksplit * S, [&](int s_, int g, int j) {
+      const int h = s_ / S, q = 4 * (s_ % S) + gam_of(g);
+      return q < 9 * G ? (q / G) * cin + h * cinh + 8 * (q % G) + j : -1;
     });
     put_bias(d_b, &bias, cout);
     return;
@@ -1551,7 +1574,11 @@ void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st)
   a.N = N; a.H = H; a.W = W;
   if (lds_staged) {
     if (Cin == 24) launch_s2lds<S2L24x48>(a, N, H, W, st);
+    else if (Cin == 96 && Cout == 192) launch_s2lds<S2L96x192>(a, N, H, W, st);
+    else if (Cin == 96) launch_s2lds<S2L96x96>(a, N, H, W, st);
+    else if (Cout == 96 && ksplit == 2) launch_s2lds<S2L48x96k2>(a, N, H, W, st);
     else if (Cout == 96) launch_s2lds<S2L48x96>(a, N, H, W, st);
+    else if (ksplit == 2) launch_s2lds<S2L48x48k2>(a, N, H, W, st);
     else launch_s2lds<S2L48x48>(a, N, H, W, st);
     LP_HIP(hipGetLastError());
     return;
