@@ -94,4 +94,18 @@ struct S2ConvLayer {
   void launch(const View& in, const View& out, int N, hipStream_t st) const;
 };
 
+// SPPF in one launch (sppf_kernel): cv1 (1x1 + SiLU) -> three cascaded 5x5 max pools -> cv2 (1x1 + SiLU) over concat(s, p1, p2, p3),
+// for the width the whole-image C2f kernel cannot take along (v2: 192 -> 96 -> 192 @20x20)
+struct SppfLayer {
+  int Cin = 0, C = 0, Cout = 0, H = 0, W = 0;
+  std::string name;
+  DevBuf d_w1, d_b1, d_w2, d_b2;
+  double macs_per_image = 0;
+  static bool supported(int cin, int c, int cout, int h, int w);
+  // w1 [c][cin], w2 [cout][4 c] over physical channels, fp32
+  void build(int cin, int c, int cout, int h, int w, const std::vector<float>& w1, const std::vector<float>& b1, const std::vector<float>& w2,
+             const std::vector<float>& b2);
+  void launch(const View& in, const View& out, int N, hipStream_t st) const;
+};
+
 }  // namespace lp

@@ -1303,6 +1303,161 @@ typedef S2LCfg<96, 96, 10, 2, 2> S2L96x96;     // :142 (conv_42: 96 -> 96 @20x20
 typedef S2Cfg<32, 64> S2Cfg32x64;   // model.ncnn.param:41 (conv_15: 32 -> 64 @40x40) and :118 (conv_37)
 typedef S2Cfg<32, 64, 10> S2Cfg32x64h;   // half-height tiles: twice the workgroups (A/B: LITEPI_S2C_TH10=1)
 
+// ---- SPPF in one launch for widths whose planes do not fit the whole-image C2f kernel (v2: c = 96 @20x20, yolo_plus
+//      model.ncnn.param:75-87): cv1 (1x1 + SiLU) -> s in ONE LDS plane over the whole image -> cv2 accumulated over s and the three
+//      cascaded 5x5 max pools as they replace each other in that plane (sppf_tail's scheme).  The pools run IN PLACE: a thread
+//      owns ten outputs of one line and channel group, loads their fourteen inputs, and stores behind a workgroup barrier
+//      (pool_phase needs a second plane; two planes of 96 channels are 166 KB).  OSPLIT workgroups share an image: each
+//      computes s and the pools itself (cheap) and COUT / OSPLIT channels of cv2.  Weights from L2.
+template <int C_, int CIN_, int COUT_, int OSPLIT_>
+struct SpCfg {
+  static constexpr int C = C_, CIN = CIN_, COUT = COUT_, OSPLIT = OSPLIT_, COUTW = COUT / OSPLIT, NW = 8, TH = 20, TW = 20, F = 0, LW = 20;
+  static constexpr int PS = 2 * C + 16;
+  static constexpr bool PERIMG = false, DEEP = true;
+  static constexpr int WPS = 2;
+  static constexpr int NT1 = 3, CB1 = C / 48, PT1 = cdiv_c(25, NW / CB1);
+  static constexpr int NT2 = 3, CB2 = COUTW / 48, PT2 = cdiv_c(25, NW / CB2);
+  static constexpr int SPT = C / 32, LDS_BYTES = TH * TW * PS;
+  static_assert(C % 96 == 0 && CIN % 32 == 0 && COUTW % 48 == 0 && NW % CB1 == 0 && NW % CB2 == 0 && CB2 * cdiv_c(25, PT2) <= NW && NT2 * PT2 <= 28,
+                "sppf: shape (one block per wave in cv2: the accumulators live across the pools)");
+};
+template <class CFG>
+__device__ __forceinline__ void pool_inplace(char* P0) {
+  constexpr int CG = CFG::C / 8, LW = CFG::LW, PS = CFG::PS;
+  static_assert(2 * 20 * CG <= CFG::NW * 64, "one thread per (line, channel group, half line)");
+  const int t = threadIdx.x;
+  const bool work = t < 2 * 20 * CG;
+  const int tc = work ? t : 0;
+  const int half = tc / (20 * CG), line = (tc % (20 * CG)) / CG, cg = tc % CG;
+  const int x0 = 10 * half;
+  auto pass = [&](char* base, int step) {   // position 0 of the line; bytes between positions
+    half8 o[10];
+    if (work) {
+      half8 v[14];
+#pragma unroll
+      for (int j = 0; j < 14; ++j) {
+        const int x = min(max(x0 - 2 + j, 0), 19);   // clamped onto the line: the border pixel is inside the window anyway
+        v[j] = *reinterpret_cast<const half8*>(base + x * step);
+      }
+      half8 pm[13];
+#pragma unroll
+      for (int j = 0; j < 13; ++j) pm[j] = __builtin_elementwise_max(v[j], v[j + 1]);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) o[i] = __builtin_elementwise_max(__builtin_elementwise_max(pm[i], pm[i + 2]), v[i + 4]);
+    }
+    lds_sync();   // every thread holds its inputs
+    if (work) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) *reinterpret_cast<half8*>(base + (x0 + i) * step) = o[i];
+    }
+    lds_sync();
+  };
+  pass(P0 + line * LW * PS + cg * 16, PS);        // along x
+  pass(P0 + line * PS + cg * 16, LW * PS);        // along y
+}
+template <class CFG>
+__global__ __launch_bounds__(CFG::NW * 64, 2) void sppf_kernel(const C2fArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int C = CFG::C, LW = CFG::LW, PS = CFG::PS, SPT = CFG::SPT;
+  char* P0 = smem;
+  Ctx cx;
+  cx.lane = threadIdx.x & 63;
+  cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  cx.g = cx.lane >> 4;
+  {
+    const int col = cx.lane & 15;
+    cx.sig = col < 4 ? 2 * col : (col < 12 ? 2 * (col - 4) + 1 : 2 * (col - 8));
+    cx.gam = ((cx.g & 1) << 1) | (cx.g >> 1);
+  }
+  cx.n = blockIdx.x % a.N;
+  const int os = blockIdx.x / a.N;
+  cx.oy0 = 0; cx.ox0 = 0;
+  cx.H = a.H; cx.W = a.W;
+  cx.st = nullptr; cx.dbg = 0;
+  const Rg rg = make_region<CFG>(cx, 0);
+  // ---- cv1: s = silu(W1 . x + b1), x from global memory (the module in front stored it), s -> P0
+  pw_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1, 0, CFG::CIN, 0, 0, false, false>(
+      cx, rg, nullptr, 0, reinterpret_cast<const char*>(a.src1), a.pitch1, nullptr, nullptr, ASrc<false>{reinterpret_cast<const char*>(a.w[C2F_W_SP1])},
+      a.b[C2F_W_SP1], [&](int cb, bool ok, int py, int px, const floatx4(&v)[CFG::NT1]) {
+        constexpr int NT = CFG::NT1;
+        const int chb = cb * 16 * NT + 4 * NT * cx.g;
+        half_t h[4 * NT];
+        to_half<NT>(v, h);
+        if (ok) store_h<NT>(P0 + (py * LW + px) * PS + chb * 2, h);
+      });
+  lds_sync();
+  // ---- cv2 over concat(s, p1, p2, p3): one block per wave, accumulators live across the pools
+  constexpr int NT = CFG::NT2, CB = CFG::CB2, PT = CFG::PT2, S = 4 * SPT;
+  const int npt = (rg.R + 15) >> 4;
+  const int nblk = ((npt + PT - 1) / PT) * CB;
+  const bool has = cx.wave < nblk;
+  const int blk = has ? cx.wave : 0;
+  const int cb = blk % CB, pbk = blk / CB;
+  int pb[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    int p = (pbk * PT + i) * 16 + cx.sig;
+    p = p < rg.R ? p : rg.R - 1;
+    int py, px;
+    pix_of(rg, p, py, px);
+    pb[i] = (py * LW + px) * PS + cx.gam * 16;
+  }
+  floatx4 acc[NT][PT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < PT; ++i) acc[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  int woff = (((os * CB + cb) * S) * NT * 64 + cx.lane) * 16;
+  asm volatile("" : "+v"(woff));
+  const char* w2 = reinterpret_cast<const char*>(a.w[C2F_W_SP2]);
+#pragma unroll 1
+  for (int seg = 0; seg < 4; ++seg) {
+    if (seg > 0) pool_inplace<CFG>(P0);
+    if (has) {
+      half8 af[SPT][NT];   // (requested here: a set live across the pool would cost the strips their registers)
+#pragma unroll
+      for (int s = 0; s < SPT; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) af[s][t] = as_h8(*reinterpret_cast<const u32x4*>(w2 + woff + ((seg * SPT + s) * NT + t) * 1024));
+#pragma unroll
+      for (int s = 0; s < SPT; ++s) {
+        half8 bf[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) bf[i] = as_h8(*reinterpret_cast<const u32x4*>(P0 + pb[i] + s * 64));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < PT; ++i) acc[t][i] = mma16(af[s][t], bf[i], acc[t][i]);
+      }
+    }
+    if (seg < 3) lds_sync();   // every wave has read the plane before the pool overwrites it
+  }
+  if (has) {
+    char* out = reinterpret_cast<char*>(a.out2);
+    const float* bias = a.b[C2F_W_SP2] + os * CFG::COUTW;
+    floatx4 bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const floatx4*>(bias + cb * 16 * NT + 4 * NT * cx.g + 4 * t);
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+      const int p0 = (pbk * PT + i) * 16 + cx.sig;
+      const bool ok = p0 < rg.R;
+      const int p = ok ? p0 : rg.R - 1;
+      int py, px;
+      pix_of(rg, p, py, px);
+      floatx4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
+      half_t h[4 * NT];
+      to_half<NT>(v, h);
+      const int chb = os * CFG::COUTW + cb * 16 * NT + 4 * NT * cx.g;
+      const int gpix = (cx.n * cx.H + py) * cx.W + px;
+      if (ok) store_h<NT>(out + (size_t)((unsigned)gpix * (unsigned)a.out2_pitch) * 2 + chb * 2, h);
+    }
+  }
+}
+typedef SpCfg<96, 192, 192, 2> SpCfgV2;   // yolo_plus model.ncnn.param:75-87 (conv_27, three pools, conv_28): 83 KB plane, two workgroups per image
+
 // ---- instantiated configurations (YOLO-LitePi v1 widths; model.ncnn.param line of the module's cv1) ----------------------
 typedef C2fCfg<32, 1, 128, 64, true, 64, 0, 0> CfgNeck40;    // :90  up(P5) | P4 -> C2f(n=1) @40x40
 typedef C2fCfg<16, 1, 64, 32, true, 32, 0, 0, 16> CfgNeck80;     // :105 up(F4) | P3 -> C2f(n=1) @80x80
@@ -1598,6 +1753,45 @@ void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st)
   }
   LP_HIP(hipGetLastError());
   if (stamp_file) dump_stamps(stamp_file, name, (size_t)N * a.tiles_x * a.tiles_y, st);
+}
+
+bool SppfLayer::supported(int cin, int c, int cout, int h, int w) {
+  static const bool off = getenv("LITEPI_NO_SPPF_FUSED") != nullptr;
+  return !off && cin == SpCfgV2::CIN && c == SpCfgV2::C && cout == SpCfgV2::COUT && h == 20 && w == 20;
+}
+
+void SppfLayer::build(int cin, int c, int cout, int h, int w, const std::vector<float>& w1, const std::vector<float>& b1,
+                      const std::vector<float>& w2, const std::vector<float>& b2) {
+  LP_CHECK(supported(cin, c, cout, h, w), LP_ERR_STATE, "sppf: unsupported shape %d -> %d -> %d @%dx%d", cin, c, cout, h, w);
+  Cin = cin; C = c; Cout = cout; H = h; W = w;
+  auto pw_k = [](int ktot) {
+    return [ktot](int s_, int g, int j) {
+      const int k = 32 * s_ + 8 * gam_of(g) + j;
+      return k < ktot ? k : -1;
+    };
+  };
+  pack_phase(d_w1, w1, c, cin, SpCfgV2::NT1, cin / 32, pw_k(cin));
+  put_bias(d_b1, &b1, c);
+  pack_phase(d_w2, w2, cout, 4 * c, SpCfgV2::NT2, 4 * c / 32, pw_k(4 * c));
+  put_bias(d_b2, &b2, cout);
+  macs_per_image = ((double)c * cin + (double)cout * 4 * c) * h * w;
+}
+
+void SppfLayer::launch(const View& in, const View& out, int N, hipStream_t st) const {
+  LP_CHECK(in.base && out.base && in.H == H && in.W == W && in.C >= Cin && out.H == H && out.W == W && out.C >= Cout, LP_ERR_STATE, "sppf %s: bad views", name.c_str());
+  LP_CHECK((double)N * H * W * in.pitch * 2.0 < 4294967296.0 && (double)N * H * W * out.pitch * 2.0 < 4294967296.0, LP_ERR_ARG,
+           "sppf: tensor too large for 32-bit byte offsets");
+  C2fArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src1 = in.base; a.pitch1 = in.pitch;
+  a.out2 = out.base; a.out2_pitch = out.pitch;
+  a.w[C2F_W_SP1] = d_w1.p; a.b[C2F_W_SP1] = d_b1.as<float>();
+  a.w[C2F_W_SP2] = d_w2.p; a.b[C2F_W_SP2] = d_b2.as<float>();
+  a.N = N; a.H = H; a.W = W; a.tiles_x = a.tiles_y = 1;
+  typedef SpCfgV2 CFG;
+  set_max_dynamic_lds(reinterpret_cast<const void*>(&sppf_kernel<CFG>), CFG::LDS_BYTES);
+  LP_LAUNCH(sppf_kernel<CFG>, dim3(N * CFG::OSPLIT), dim3(CFG::NW * 64), CFG::LDS_BYTES, st, a);
+  LP_HIP(hipGetLastError());
 }
 
 bool C2fLayer::cv2_from_lds() const {

@@ -113,7 +113,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
   const size_t es = prec_ == LP_FP16 ? 2 : 4;
 
   tensors_.clear(); blob2tensor_.clear(); buffers_.clear(); convs_.clear(); ops_.clear(); levels_.clear();
-  bnecks_.clear(); dws_.clear(); attns_.clear(); heads_.clear(); c2fs_.clear(); c2f_io_.clear(); s2cs_.clear();
+  bnecks_.clear(); dws_.clear(); attns_.clear(); heads_.clear(); c2fs_.clear(); c2f_io_.clear(); s2cs_.clear(); sppfs_.clear();
   fused_head_ = false;
   loaded_ = false;
 
@@ -671,6 +671,58 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     return true;
   };
 
+  // ---- SPPF in one launch (sppf_kernel; the widths the whole-image C2f kernel does not take along: v2's 192 -> 96 -> 192 @20x20):
+  //      cv1 (1x1 + Swish) -> three chained 5x5 pools -> zero-copy Concat(s, p1, p2, p3) -> cv2 (1x1 + Swish); s and the pooled
+  //      maps stay in LDS, the concat buffer is never written
+  auto try_sppf = [&](int i) -> bool {
+    if (!c2f_on || !is_silu_conv(i, 1, 1)) return false;
+    const int tin = cinfo[i].tin, ts = cinfo[i].tout;
+    if (tensors_[ts].segs.size() != 1 || tensors_[tin].Cp != L[i].in_ch || tensors_[ts].Cp != L[i].ipar(0)) return false;
+    int cur = ts, cc = -1, pools[3] = {-1, -1, -1};
+    std::vector<int> chain = {ts};
+    for (int q = 0; q < 3; ++q) {
+      int jp = -1;
+      for (int cq : canon_consumers[tensors_[cur].name]) {
+        if (L[cq].type == "Pooling" && jp < 0) jp = cq;
+        else if (L[cq].type == "Concat" && (cc < 0 || cc == cq)) cc = cq;
+        else return false;
+      }
+      if (jp < 0 || done[jp]) return false;
+      pools[q] = jp; cur = get(L[jp].outputs[0]); chain.push_back(cur);
+    }
+    for (int cq : canon_consumers[tensors_[cur].name])
+      if (cq != cc) return false;
+    if (cc < 0 || is_tail(cc) || !zero_copy_concat(cc) || L[cc].inputs.size() != 4) return false;
+    for (int q = 0; q < 4; ++q)
+      if (get(L[cc].inputs[q]) != chain[q]) return false;
+    const int tc2 = get(L[cc].outputs[0]);
+    const int c = L[i].ipar(0);
+    if (tensors_[tc2].parent >= 0 || tensors_[tc2].Cp != 4 * c) return false;
+    const int j2 = sole_consumer(tc2);
+    if (!is_silu_conv(j2, 1, 1)) return false;
+    const int tout = cinfo[j2].tout;
+    if (tensors_[tout].Cp != L[j2].ipar(0) || tensors_[tout].parent >= 0 || tensors_[tout].segs.size() != 1) return false;
+    for (int q : canon_consumers[tensors_[tout].name])
+      if (L[q].type == "BinaryOp") return false;
+    const int Hh = tensors_[ts].H, Ww = tensors_[ts].W;
+    if (!SppfLayer::supported(L[i].in_ch, c, L[j2].ipar(0), Hh, Ww)) return false;
+    sppfs_.emplace_back(new SppfLayer());
+    SppfLayer& sl = *sppfs_.back();
+    sl.name = L[i].name + "+pools+" + L[j2].name;
+    sl.build(L[i].in_ch, c, L[j2].ipar(0), Hh, Ww, conv_w(i), L[i].bias, conv_w(j2), L[j2].bias);
+    ensure_buffer(tout);
+    for (int q = 0; q < 4; ++q) tensors_[chain[q]].in_c2f = true;   // never written: lp_debug_blob must not hand them out
+    tensors_[tc2].in_c2f = true;
+    macs_ += sl.macs_per_image;
+    DetOp op;
+    op.kind = DetOp::SPPFUSED; op.conv = (int)sppfs_.size() - 1; op.layer = sl.name; op.in = tin; op.out = tout;
+    op.flops = 2.0 * sl.macs_per_image;
+    op.bytes = ((double)tensors_[tin].C + (double)tensors_[tout].C) * Hh * Ww * esd + (double)(L[i].weight.size() + L[j2].weight.size()) * esd;
+    ops_.push_back(op);
+    done[i] = done[j2] = done[pools[0]] = done[pools[1]] = done[pools[2]] = 1;
+    return true;
+  };
+
   for (int i = 0; i < first_tail; ++i) {
     if ((is_tail(i) && L[i].type != "Convolution") || skip[i] || done[i]) continue;
     const NcnnLayer& l = L[i];
@@ -728,6 +780,7 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
     }
     if (l.type == "Convolution") {
       if (try_c2f(i)) continue;
+      if (try_sppf(i)) continue;
       const int tin = cinfo[i].tin;
       int tout = cinfo[i].tout, res = -1;
       const int k = l.ipar(1, 1), s = l.ipar(3, 1);
@@ -1335,6 +1388,10 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         kname = cl.kernel_name() + sfx;
         break;
       }
+      case DetOp::SPPFUSED:
+        sppfs_[op.conv]->launch(view(op.in), view(op.out), B, st);
+        kname = fmt("sppf<%d,%d,%d>", sppfs_[op.conv]->Cin, sppfs_[op.conv]->C, sppfs_[op.conv]->Cout) + sfx;
+        break;
       case DetOp::S2C:
         s2cs_[op.conv]->launch(view(op.in), view(op.out), B, st);
         kname = fmt("s2conv<%d,%d>", s2cs_[op.conv]->Cin, s2cs_[op.conv]->Cout) + sfx;

@@ -41,7 +41,7 @@ struct Tensor {
 struct Buffer { int Cp = 0, H = 0, W = 0; DevBuf mem; };
 
 struct DetOp {
-  enum Kind { STEM, STEMBLOCK, CONV, BNECK, DWCONV, ATTN, UPSAMPLE, SPPF, ADD, COPY, HEAD, C2F, S2C } kind = CONV;
+  enum Kind { STEM, STEMBLOCK, CONV, BNECK, DWCONV, ATTN, UPSAMPLE, SPPF, ADD, COPY, HEAD, C2F, S2C, SPPFUSED } kind = CONV;
   int conv = -1;                 // index into convs (CONV) / bnecks (BNECK)
   int in = -1, in2 = -1, res = -1, out = -1, out2 = -1, out3 = -1;
   std::string layer;
@@ -80,6 +80,7 @@ class Detector {
   struct C2fIO { int src0 = -1, src1 = -1, up_c = 0, cat = -1, out = -1, s2_in = -1, x = -1, cat2 = -1, out2 = -1; };
   std::vector<std::unique_ptr<C2fLayer>> c2fs_;
   std::vector<std::unique_ptr<S2ConvLayer>> s2cs_;   // stand-alone stride-2 convs on the c2f machinery
+  std::vector<std::unique_ptr<SppfLayer>> sppfs_;    // SPPF modules in one launch (sppf_kernel)
   std::vector<C2fIO> c2f_io_;
   bool fused_head_ = false;                        // every level fused: the stand-alone decode launch is gone
   // YOLO11 extras: stand-alone depthwise convs and the C2PSA attention block
