@@ -52,7 +52,7 @@ constexpr int deep_depth(int S, int NT, int PT, bool ldsw) {
 }
 
 template <int C_, int NB_, int KA_, int KB_, bool UP_, int COUT_, int MODE_, int KS2_, int TH_ = 20, int NW_PERIMG = 8, bool AW_ = true, int WPS_ = 0,
-          bool DEEP_ = false>
+          bool DEEP_ = false, int NWT_ = 0>
 struct C2fCfg {
   static constexpr int C = C_, NB = NB_, KA = KA_, KB = KB_, COUT = COUT_, MODE = MODE_, KS2 = KS2_;
   static constexpr bool UP = UP_;
@@ -63,7 +63,8 @@ struct C2fCfg {
   // whole-image configurations: NW_PERIMG = 8.  (Four waves with the whole register file each -- every wave streams its
   // channel block's weights from L2 itself, so halving the waves halves that traffic -- measured slower: 112 vs 100 us for
   // the backbone kernel; one wave per SIMD exposes every LDS and L2 latency.)
-  static constexpr int NW = MODE_ >= 1 ? NW_PERIMG : (C_ >= 32 ? 8 : 4);
+  // (NWT_: a tile configuration of c < 32 whose LDS allows only ONE workgroup per CU runs eight waves like the wide ones)
+  static constexpr int NW = MODE_ >= 1 ? NW_PERIMG : (NWT_ > 0 ? NWT_ : (C_ >= 32 ? 8 : 4));
   static constexpr int TH = TH_, TW = 20;
   static constexpr int F = PERIMG ? 1 : 2 * NB;  // frame margin around the tile
   static constexpr int LW = TW + 2 * F, LH = TH + 2 * F;
@@ -1473,7 +1474,8 @@ typedef C2fCfg<48, 1, 0, 144, false, 96, 0, 0, 20, 8, false> CfgV2Pan40;    // :
 typedef C2fCfg<24, 1, 96, 48, true, 48, 0, 0, 16> CfgV2Neck80;              // :116 up(F4) | P3 -> C2f(n=1) @80x80
 typedef C2fCfg<96, 1, 0, 192, false, 192, 0, 0, 10, 8, false> CfgV2Bb20;    // :63 C2f(n=1) @20x20, two half-image tiles
 typedef C2fCfg<96, 1, 0, 288, false, 192, 0, 0, 10, 8, false> CfgV2Pan20;   // :145 conv_42 | P5 -> C2f(n=1) @20x20, two half-image tiles
-typedef C2fCfg<24, 2, 0, 48, false, 48, 0, 0, 16> CfgV2Bb80;                // :13 C2f(n=2) @80x80 (halo 4)
+typedef C2fCfg<24, 2, 0, 48, false, 48, 0, 0, 20, 8, true, 0, false, 8> CfgV2Bb80;   // :13 C2f(n=2) @80x80 (halo 4; 103 KB: ONE workgroup per CU, so eight waves
+                                                                                     // and 20-row tiles: 130 -> 123 -> 119 us; the n = 1 module on the same shape: 91 vs 80 us for two 4-wave workgroups)
 typedef C2fCfg<48, 2, 0, 96, false, 96, 0, 0, 10, 8, false> CfgV2Bb40;      // :30 C2f(n=2) @40x40 (halo 4, 10-row tiles)
 
 template <class CFG> struct CfgName;
