@@ -23,6 +23,10 @@ def family(name):
         m = re.search(r"S2L?Cfg<(\d+), *(\d+)[,>]", name)
         v = [int(m.group(1)), int(m.group(2))] if m else [int(x) for x in re.findall(r"Li(\d+)E", name)][:2]
         return "s2conv<%d,%d>_f16" % tuple(v)
+    if "sppf_kernel" in name:   # SpCfg<C, CIN, COUT, OSPLIT>: the library's profile name is sppf<Cin,C,Cout>
+        m = re.search(r"SpCfg<(\d+), *(\d+), *(\d+)", name)
+        v = [int(m.group(i)) for i in (1, 2, 3)] if m else (ints + [0, 0, 0])[:3]
+        return "sppf<%d,%d,%d>_f16" % (v[1], v[0], v[2])
     if "c2f_kernel" in name:   # C2fCfg<C, NB, KA, KB, UP, COUT, MODE, KS2, TH, NW>: the profiler's name is CfgName of c2f_kernels.hip
         m = re.search(r"C2fCfg<([^>]*)>", name)
         if m:

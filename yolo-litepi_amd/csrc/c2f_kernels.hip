@@ -1359,7 +1359,7 @@ __device__ __forceinline__ void pool_inplace(char* P0) {
 template <class CFG>
 __global__ __launch_bounds__(CFG::NW * 64, 2) void sppf_kernel(const C2fArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int C = CFG::C, LW = CFG::LW, PS = CFG::PS, SPT = CFG::SPT;
+  constexpr int LW = CFG::LW, PS = CFG::PS, SPT = CFG::SPT;
   char* P0 = smem;
   Ctx cx;
   cx.lane = threadIdx.x & 63;
