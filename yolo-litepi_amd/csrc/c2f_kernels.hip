@@ -1298,6 +1298,7 @@ typedef S2LCfg<48, 96, 10, 2, 2> S2L48x96k2;   // the same in two passes of 24 i
 typedef S2LCfg<48, 48, 10, 1, 2> S2L48x48k2;
 // (v1's 32 -> 64 convs as S2LCfg<32, 64, 10, 1, 2>, two passes of 16 channels: 22.9 / 16.2 us against 22.0 / 14.0 for the gather kernel
 //  above -- at Cin 32 the tile copy costs what the gathers cost; they stay on s2conv_kernel)
+typedef S2LCfg<64, 128, 10, 2, 2> S2L64x128;   // v1's 64 -> 128 convs @20x20 (model.ncnn.param:62, :134) when they do not ride in the whole-image kernels
 typedef S2LCfg<96, 192, 10, 4, 2> S2L96x192;   // :44 (conv_22: 96 -> 192 @20x20): two passes of 48 input channels, four workgroups per tile
 typedef S2LCfg<96, 96, 10, 2, 2> S2L96x96;     // :142 (conv_42: 96 -> 96 @20x20)
 
@@ -1474,6 +1475,8 @@ typedef C2fCfg<48, 1, 0, 144, false, 96, 0, 0, 20, 8, false> CfgV2Pan40;    // :
 typedef C2fCfg<24, 1, 96, 48, true, 48, 0, 0, 16> CfgV2Neck80;              // :116 up(F4) | P3 -> C2f(n=1) @80x80
 typedef C2fCfg<96, 1, 0, 192, false, 192, 0, 0, 10, 8, false> CfgV2Bb20;    // :63 C2f(n=1) @20x20, two half-image tiles
 typedef C2fCfg<96, 1, 0, 288, false, 192, 0, 0, 10, 8, false> CfgV2Pan20;   // :145 conv_42 | P5 -> C2f(n=1) @20x20, two half-image tiles
+typedef C2fCfg<64, 1, 0, 256, false, 128, 0, 0, 10, 8, false> CfgPan20h;    // v1's PAN 20x20 module WITHOUT its entry conv on two half-image tiles (A/B:
+typedef C2fCfg<64, 1, 0, 128, false, 128, 0, 0, 10, 8, false> CfgBb20h;     //  LITEPI_C2F_SKIP of the whole-image configurations), and the backbone's
 typedef C2fCfg<24, 2, 0, 48, false, 48, 0, 0, 20, 8, true, 0, false, 8> CfgV2Bb80;   // :13 C2f(n=2) @80x80 (halo 4; 103 KB: ONE workgroup per CU, so eight waves
                                                                                      // and 20-row tiles: 130 -> 123 -> 119 us; the n = 1 module on the same shape: 91 vs 80 us for two 4-wave workgroups)
 typedef C2fCfg<48, 2, 0, 96, false, 96, 0, 0, 10, 8, false> CfgV2Bb40;      // :30 C2f(n=2) @40x40 (halo 4, 10-row tiles)
@@ -1494,6 +1497,8 @@ C2F_NAME(CfgV2Neck80, "c2f<24,1,up96+48>")
 C2F_NAME(CfgV2Bb20, "c2f<96,1,192>")
 C2F_NAME(CfgV2Pan20, "c2f<96,1,288>")
 C2F_NAME(CfgV2Bb80, "c2f<24,2,48>")
+C2F_NAME(CfgPan20h, "c2f<64,1,256>")
+C2F_NAME(CfgBb20h, "c2f<64,1,128>")
 C2F_NAME(CfgV2Bb40, "c2f<48,2,96>")
 
 template <class CFG> size_t cfg_lds() { return (size_t)CFG::LDS_BYTES; }
@@ -1524,7 +1529,8 @@ template <class F> bool for_each_cfg(F&& f) {
          f.template operator()<CfgPan20>() || f.template operator()<CfgBb20>() || f.template operator()<CfgBb80>() ||
          f.template operator()<CfgBb40>() || f.template operator()<CfgV2Neck40>() || f.template operator()<CfgV2Pan40>() ||
          f.template operator()<CfgV2Neck80>() || f.template operator()<CfgV2Bb20>() || f.template operator()<CfgV2Pan20>() ||
-         f.template operator()<CfgV2Bb80>() || f.template operator()<CfgV2Bb40>();
+         f.template operator()<CfgV2Bb80>() || f.template operator()<CfgV2Bb40>() || f.template operator()<CfgPan20h>() ||
+         f.template operator()<CfgBb20h>();
 }
 struct InfoFn {
   const C2fShape& s; CfgInfo& ci;
@@ -1683,7 +1689,8 @@ static bool s2lds_shape(int cin, int cout, int hout, int wout) {
   static const bool off = getenv("LITEPI_NO_S2LDS") != nullptr;
   static const bool off96 = getenv("LITEPI_NO_S2LDS96") != nullptr;
   return !off && hout % 10 == 0 && wout % 20 == 0 &&
-         ((cin == 24 && cout == 48) || (cin == 48 && (cout == 96 || cout == 48)) || (!off96 && cin == 96 && (cout == 192 || cout == 96)));
+         ((cin == 24 && cout == 48) || (cin == 48 && (cout == 96 || cout == 48)) || (!off96 && cin == 96 && (cout == 192 || cout == 96)) ||
+          (cin == 64 && cout == 128));
 }
 bool S2ConvLayer::supported(int cin, int cout, int hout, int wout) {
   return (cin == 32 && cout == 64 && hout % 20 == 0 && wout % 20 == 0) || s2lds_shape(cin, cout, hout, wout);
@@ -1695,10 +1702,10 @@ void S2ConvLayer::build(int cin, int cout, int hout, int wout, const std::vector
   lds_staged = s2lds_shape(cin, cout, hout, wout);
   if (lds_staged) {   // general K packing (tap, 8-channel group), three channel tiles per block: S2LCfg / c3_phase's order;
                       // Cin 96: two passes of 48 input channels, the second pass's steps behind the first's
-    ksplit = cin == 96 || (cin == 48 && !getenv("LITEPI_S2LDS_K1")) ? 2 : 1;
+    ksplit = cin == 96 || cin == 64 || (cin == 48 && !getenv("LITEPI_S2LDS_K1")) ? 2 : 1;
     const int cinh = cin / ksplit;
     const int G = cinh / 8, S = (9 * G + 3) / 4;
-    const int nt = 3;   // S2LCfg::NT of every configuration launch() picks (48 output channels = 3 tiles per workgroup)
+    const int nt = cin == 64 ? 4 : 3;   // S2LCfg::NT of the configuration launch() picks (64 -> 128: 64 output channels = 4 tiles per workgroup; else 48 = 3)
     pack_phase(d_w, w_taps, cout, 9 * cin, nt, ksplit * S, [&](int s_, int g, int j) {
       const int h = s_ / S, q = 4 * (s_ % S) + gam_of(g);
       return q < 9 * G ? (q / G) * cin + h * cinh + 8 * (q % G) + j : -1;
@@ -1730,7 +1737,8 @@ void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st)
   a.w[C2F_W_S2] = d_w.p; a.b[C2F_W_S2] = d_b.as<float>();
   a.N = N; a.H = H; a.W = W;
   if (lds_staged) {
-    if (Cin == 24) launch_s2lds<S2L24x48>(a, N, H, W, st);
+    if (Cin == 64) launch_s2lds<S2L64x128>(a, N, H, W, st);
+    else if (Cin == 24) launch_s2lds<S2L24x48>(a, N, H, W, st);
     else if (Cin == 96 && Cout == 192) launch_s2lds<S2L96x192>(a, N, H, W, st);
     else if (Cin == 96) launch_s2lds<S2L96x96>(a, N, H, W, st);
     else if (Cout == 96 && ksplit == 2) launch_s2lds<S2L48x96k2>(a, N, H, W, st);
