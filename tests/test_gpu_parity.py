@@ -1405,3 +1405,39 @@ def test_stem_block16_equals_unfused_plan_v2(tmp_path, monkeypatch, size, batch)
     d = np.abs(got["fused"] - got["unfused"])
     print(f"v2 {size} x{batch}: stem_block16 vs stem_conv + conv3x3s2_direct+1x1: max |diff| {d.max():.3g}")
     assert np.array_equal(got["fused"], got["unfused"]), f"max |diff| {d.max()}"
+
+
+def test_v1_split_20x20_modules_vs_layer_plan(tmp_path, monkeypatch):
+    """The opt-in split of v1's two whole-image 20x20 launches (round 4, LITEPI_C2F_SKIP: the stride-2 convs on the LDS-staged
+    kernel s2lds<64,128>, the C2f modules on two half-image tiles c2f<64,1,256> / c2f<64,1,128>, the SPPF on the layer plan) against
+    the layer plan on the same images: the documented fp16 bounds on the difference of two fp16 plans."""
+    from litepi import Engine, ncnn_export
+    param, binf = str(tmp_path / "d.param"), str(tmp_path / "d.bin")
+    ncnn_export.export_detector(param, binf, "v1", seed=41, cls_bias=-2.0)
+    imgs = np.random.default_rng(41).integers(0, 256, (5, 640, 640, 3), dtype=np.uint8)
+    out, names = {}, {}
+    for plan in ("split", "layer"):
+        if plan == "layer":
+            monkeypatch.setenv("LITEPI_NO_C2F", "1")
+            monkeypatch.setenv("LITEPI_NO_S2C", "1")
+            monkeypatch.delenv("LITEPI_C2F_SKIP", raising=False)
+        else:
+            monkeypatch.setenv("LITEPI_C2F_SKIP", "c2f<64,1,s2+256>;c2f<64,1,s2+128,sppf>")
+        e = Engine(precision="fp16", max_batch=5)
+        try:
+            e.load_detector(param, binf)
+            out[plan] = e.detect_raw(imgs)
+            e.profile_next(True)
+            e.detect_raw(imgs)
+            names[plan] = [k["name"] for k in e.profile_read()]
+        finally:
+            e.close()
+    assert "c2f<64,1,256>_f16" in names["split"] and "c2f<64,1,128>_f16" in names["split"] and names["split"].count("s2conv<64,128>_f16") == 2, names["split"]
+    assert not any(n.startswith("c2f<64,1,s2") for n in names["split"]) and not any(n.startswith("c2f<") for n in names["layer"])
+    stride = np.concatenate([np.full(6400, 8.0), np.full(1600, 16.0), np.full(400, 32.0)]).astype(np.float32)
+    ds = np.abs(out["split"][:, 4] - out["layer"][:, 4])
+    db = np.abs(out["split"][:, :4] - out["layer"][:, :4])
+    print(f"v1 split 20x20 plan vs layer plan: score diff max {ds.max():.4f}, box diff max {db.max():.3f} px ({(db / stride).max():.3f} cells), mean {db.mean():.4f}")
+    assert ds.max() <= 0.02
+    assert (db <= 0.35 * stride + 0.02 * np.abs(out["layer"][:, :4])).all()
+    assert db.mean() <= 0.5

@@ -1548,7 +1548,7 @@ bool cfg_info(const C2fShape& s, CfgInfo& ci) {
   // (v2's n = 2 backbone modules run as one launch each: 139 us against 150 for the four launches of the 80x80 one -- 145 before
   //  cv2 took y2 / y3 from the planes --, +1.5 % of the pipelined rate; 10-row tiles on the 40x40 map: 74 against 118)
   // A/B switch: LITEPI_C2F_SKIP=<configuration names separated by ';'> keeps those modules on the layer plan
-  static const char* skip = getenv("LITEPI_C2F_SKIP");
+  const char* skip = getenv("LITEPI_C2F_SKIP");   // (read per call: plan time only; tests switch it inside one process)
   if (!for_each_cfg(InfoFn{s, ci})) return false;
   if (skip) {
     const std::string list = std::string(";") + skip + ";", key = std::string(";") + ci.name + ";";
