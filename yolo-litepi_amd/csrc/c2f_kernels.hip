@@ -22,6 +22,11 @@
 // {0-3, 12-15} and odd offsets for {4-11}, and K group g reads channel group gam(g) = {0, 2, 1, 3}: inside every
 // ds_read_b128 lane group ({0-3,12-15,20-27}, ..) the 16 lanes then hit 16 distinct 16-byte slots -- conflict-free
 // fragment reads without padding rows (MI355X guide, LDS).
+//
+// Round 4 (v2, the paper's widths c = 24 / 48 / 96; yolo_plus_ncnn_model/model.ncnn.param): general K packing for the 3x3 convs
+// whose taps are not whole K steps (C2fCfg::GK), channel tiles in threes, 10-row / half-image tiles and weights from L2 where two
+// planes fill the LDS, cv2 with a per-lane source table (pw_gk_phase); and, on the same machinery, s2lds_kernel (stride-2 3x3 conv
+// from an LDS-staged input tile, output-channel and input-channel splits) and sppf_kernel (SPPF in one plane, pools in place).
 #include "c2f.h"
 
 #include <cstdlib>
