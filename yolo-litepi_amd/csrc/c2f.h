@@ -87,10 +87,14 @@ struct S2ConvLayer {
   int Cin = 0, Cout = 0, H = 0, W = 0;   // H, W: OUTPUT map
   bool lds_staged = false;               // s2lds_kernel (input tile in LDS: v2's Cin 24 / 48 / 96) instead of the gather kernel
   int ksplit = 1;                        // its passes over the input channels
+  bool has_tail = false;                 // a 1x1 conv + SiLU (C2f.cv1) on the accumulators: Cout -> Cout
   std::string name;
-  DevBuf d_w, d_b;
+  DevBuf d_w, d_b, d_w2, d_b2;
   static bool supported(int cin, int cout, int hout, int wout);
-  void build(int cin, int cout, int hout, int wout, const std::vector<float>& w_taps, const std::vector<float>& bias);
+  static bool tail_supported(int cin, int cout, int cout2, int hout, int wout);
+  // w_tail [cout][cout] (1x1), b_tail: the fused tail, or null
+  void build(int cin, int cout, int hout, int wout, const std::vector<float>& w_taps, const std::vector<float>& bias,
+             const std::vector<float>* w_tail = nullptr, const std::vector<float>* b_tail = nullptr);
   void launch(const View& in, const View& out, int N, hipStream_t st) const;
 };
 

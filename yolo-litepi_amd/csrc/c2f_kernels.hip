@@ -1155,8 +1155,11 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2conv_kernel(const C2fArgs a
 //      packing for Cin 24 / 48 (c3_pack's order), the weights of this workgroup's output channels in a second LDS region.
 //      OSPLIT workgroups share an output tile (each stages the input tile and computes COUT / OSPLIT channels) when the whole
 //      weight set would not fit beside the plane.
-template <int CIN_, int COUT_, int TH_, int OSPLIT_, int KSPLIT_ = 1>
+template <int CIN_, int COUT_, int TH_, int OSPLIT_, int KSPLIT_ = 1, bool TAIL_ = false>
 struct S2LCfg {
+  // TAIL: a 1x1 conv + SiLU on the result (C2f.cv1 behind the stride-2 conv: COUT -> COUT channels) runs on the accumulators --
+  // a lane's 4 NT consecutive channels of a pixel ARE a K group of the next MFMA's pixel operand (conv_kernels.hip tail_store)
+  static constexpr bool TAIL = TAIL_;
   static constexpr int CIN = CIN_, COUT = COUT_, TH = TH_, TW = 20, NW = 8, OSPLIT = OSPLIT_, KSPLIT = KSPLIT_;
   static constexpr int COUTW = COUT / OSPLIT;   // output channels of one workgroup
   static constexpr int CINH = CIN / KSPLIT;     // input channels of one pass (Cin 96: two passes of 48 -- a 21 x 41 plane of 96 is 179 KB)
@@ -1170,6 +1173,7 @@ struct S2LCfg {
   static_assert(COUT % (16 * OSPLIT) == 0 && COUTW % (16 * NT) == 0 && NW % CB == 0 && CIN % (8 * KSPLIT) == 0 && LDS_BYTES <= 160 * 1024 && NBLK <= NW,
                 "s2lds: shape (one block per wave: the accumulators live across the passes)");
   static_assert(CB == 1 || KSPLIT == 1, "the packed weights are [channel block][all K steps]: a pass is contiguous only for one block");
+  static_assert(!TAIL || (OSPLIT == 1 && CB == 1 && NT == 2 && COUT == 32), "tail: the workgroup holds all 32 channels of a pixel, 8 per lane");
 };
 template <class CFG>
 __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a) {
@@ -1279,6 +1283,15 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a)
   }
   if (has) {
     char* xo = reinterpret_cast<char*>(a.x);
+    half8 w2f[NT];
+    floatx4 b2v[NT];
+    if constexpr (CFG::TAIL) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        w2f[t] = as_h8(reinterpret_cast<const u32x4*>(a.w[C2F_W_CV1])[t * 64 + cx.lane]);
+        b2v[t] = *reinterpret_cast<const floatx4*>(a.b[C2F_W_CV1] + 4 * NT * cx.g + 4 * t);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
       const int p = (pbk * PT + i) * 16 + cx.sig;
@@ -1290,6 +1303,14 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a)
       for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
       half_t hh[4 * NT];
       to_half<NT>(v, hh);
+      if constexpr (CFG::TAIL) {   // out2 = silu(W2 . fp16(silu(conv)) + b2): K = 32 = one step, K group g = this lane's 8 channels
+        half8 bq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bq[j] = hh[j];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = silu4(mma16(w2f[t], bq, floatx4{0.f, 0.f, 0.f, 0.f}), b2v[t]);
+        to_half<NT>(v, hh);
+      }
       const int chb = os * CFG::COUTW + cb * 16 * NT + 4 * NT * cx.g;
       const int gpix = (cx.n * cx.H + cx.oy0 + py) * cx.W + cx.ox0 + px;
       if (ok) store_h<NT>(xo + (size_t)((unsigned)gpix * (unsigned)a.x_pitch) * 2 + chb * 2, hh);
@@ -1303,6 +1324,7 @@ typedef S2LCfg<48, 96, 10, 2, 2> S2L48x96k2;   // the same in two passes of 24 i
 typedef S2LCfg<48, 48, 10, 1, 2> S2L48x48k2;
 // (v1's 32 -> 64 convs as S2LCfg<32, 64, 10, 1, 2>, two passes of 16 channels: 22.9 / 16.2 us against 22.0 / 14.0 for the gather kernel
 //  above -- at Cin 32 the tile copy costs what the gathers cost; they stay on s2conv_kernel)
+typedef S2LCfg<16, 32, 10, 1, 1, true> S2L16x32t;   // v1 model.ncnn.param:19-20 (conv_6 16 -> 32 @80x80 + conv_7 = C2f.cv1 32 -> 32 as its tail)
 typedef S2LCfg<64, 128, 10, 2, 2> S2L64x128;   // v1's 64 -> 128 convs @20x20 (model.ncnn.param:62, :134) when they do not ride in the whole-image kernels
 typedef S2LCfg<96, 192, 10, 4, 2> S2L96x192;   // :44 (conv_22: 96 -> 192 @20x20): two passes of 48 input channels, four workgroups per tile
 typedef S2LCfg<96, 96, 10, 2, 2> S2L96x96;     // :142 (conv_42: 96 -> 96 @20x20)
@@ -1697,13 +1719,32 @@ static bool s2lds_shape(int cin, int cout, int hout, int wout) {
          ((cin == 24 && cout == 48) || (cin == 48 && (cout == 96 || cout == 48)) || (!off96 && cin == 96 && (cout == 192 || cout == 96)) ||
           (cin == 64 && cout == 128));
 }
+bool S2ConvLayer::tail_supported(int cin, int cout, int cout2, int hout, int wout) {
+  static const bool off = getenv("LITEPI_NO_S2LDS") != nullptr || getenv("LITEPI_NO_S2TAIL") != nullptr;
+  return !off && cin == 16 && cout == 32 && cout2 == 32 && hout % 10 == 0 && wout % 20 == 0;
+}
 bool S2ConvLayer::supported(int cin, int cout, int hout, int wout) {
   return (cin == 32 && cout == 64 && hout % 20 == 0 && wout % 20 == 0) || s2lds_shape(cin, cout, hout, wout);
 }
 
-void S2ConvLayer::build(int cin, int cout, int hout, int wout, const std::vector<float>& w_taps, const std::vector<float>& bias) {
-  LP_CHECK(supported(cin, cout, hout, wout), LP_ERR_STATE, "s2conv: unsupported shape %d -> %d @%dx%d", cin, cout, hout, wout);
+void S2ConvLayer::build(int cin, int cout, int hout, int wout, const std::vector<float>& w_taps, const std::vector<float>& bias,
+                        const std::vector<float>* w_tail, const std::vector<float>* b_tail) {
+  LP_CHECK(w_tail ? tail_supported(cin, cout, cout, hout, wout) : supported(cin, cout, hout, wout), LP_ERR_STATE,
+           "s2conv: unsupported shape %d -> %d @%dx%d", cin, cout, hout, wout);
   Cin = cin; Cout = cout; H = hout; W = wout;
+  has_tail = w_tail != nullptr;
+  if (has_tail) {   // S2L16x32t: one pass, general K packing (2 groups per tap: 5 steps), two channel tiles; the tail's K groups in plain order
+    lds_staged = true; ksplit = 1;
+    const int G = cin / 8, S = (9 * G + 3) / 4;
+    pack_phase(d_w, w_taps, cout, 9 * cin, 2, S, [&](int s_, int g, int j) {
+      const int q = 4 * s_ + gam_of(g);
+      return q < 9 * G ? (q / G) * cin + 8 * (q % G) + j : -1;
+    });
+    put_bias(d_b, &bias, cout);
+    pack_phase(d_w2, *w_tail, cout, cout, 2, 1, [&](int, int g, int j) { return 8 * g + j; });
+    put_bias(d_b2, b_tail, cout);
+    return;
+  }
   lds_staged = s2lds_shape(cin, cout, hout, wout);
   if (lds_staged) {   // general K packing (tap, 8-channel group), three channel tiles per block: S2LCfg / c3_phase's order;
                       // Cin 96: two passes of 48 input channels, the second pass's steps behind the first's
@@ -1741,6 +1782,12 @@ void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st)
   a.x = out.base; a.x_pitch = out.pitch;
   a.w[C2F_W_S2] = d_w.p; a.b[C2F_W_S2] = d_b.as<float>();
   a.N = N; a.H = H; a.W = W;
+  if (has_tail) {
+    a.w[C2F_W_CV1] = d_w2.p; a.b[C2F_W_CV1] = d_b2.as<float>();
+    launch_s2lds<S2L16x32t>(a, N, H, W, st);
+    LP_HIP(hipGetLastError());
+    return;
+  }
   if (lds_staged) {
     if (Cin == 64) launch_s2lds<S2L64x128>(a, N, H, W, st);
     else if (Cin == 24) launch_s2lds<S2L24x48>(a, N, H, W, st);

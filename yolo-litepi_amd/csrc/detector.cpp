@@ -984,6 +984,26 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         }
       }
       ensure_buffer(tout);
+      // a stride-2 conv WITH its folded 1x1 tail on the LDS-staged kernel (v1's conv_6 + conv_7: s2lds_kernel<S2L16x32t>)
+      if (c2f_on && !getenv("LITEPI_NO_S2C") && tail >= 0 && res < 0 && k == 3 && s == 2 && fused_act[i] == ACT_SILU && fused_act[tail] == ACT_SILU &&
+          !l.bias.empty() && !L[tail].bias.empty() && tin != input_tensor && tensors_[tin].Cp == Cin && tensors_[tmid].Cp == Cout &&
+          tensors_[tout].Cp == L[tail].ipar(0) && tensors_[tout].parent < 0 &&
+          S2ConvLayer::tail_supported(Cin, Cout, L[tail].ipar(0), tensors_[tout].H, tensors_[tout].W)) {
+        s2cs_.emplace_back(new S2ConvLayer());
+        s2cs_.back()->name = l.name + "+" + L[tail].name;
+        const std::vector<float> w2 = conv_w(tail);
+        s2cs_.back()->build(Cin, Cout, tensors_[tout].H, tensors_[tout].W, conv_w(i), l.bias, &w2, &L[tail].bias);
+        const Tensor& TI2 = tensors_[tin];
+        const Tensor& TO2 = tensors_[tout];
+        const double macs2 = (9.0 * Cin * Cout + (double)Cout * L[tail].ipar(0)) * TO2.H * TO2.W;
+        macs_ += macs2;
+        DetOp op;
+        op.kind = DetOp::S2C; op.conv = (int)s2cs_.size() - 1; op.layer = s2cs_.back()->name; op.in = tin; op.out = tout;
+        op.flops = 2.0 * macs2;
+        op.bytes = ((double)TI2.C * TI2.H * TI2.W + (double)TO2.C * TO2.H * TO2.W) * esd + (double)(l.weight.size() + L[tail].weight.size()) * esd;
+        ops_.push_back(op);
+        continue;
+      }
       // a stride-2 conv without a folded tail whose shape the c2f machinery covers: s2conv_kernel (LITEPI_NO_S2C=1: off)
       if (c2f_on && !getenv("LITEPI_NO_S2C") && tail < 0 && res < 0 && k == 3 && s == 2 && fused_act[i] == ACT_SILU && !l.bias.empty() && tin != input_tensor &&
           tensors_[tin].Cp == Cin && tensors_[tout].Cp == Cout && tensors_[tout].segs.size() == 1 &&
@@ -1394,7 +1414,7 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         break;
       case DetOp::S2C:
         s2cs_[op.conv]->launch(view(op.in), view(op.out), B, st);
-        kname = fmt("s2conv<%d,%d>", s2cs_[op.conv]->Cin, s2cs_[op.conv]->Cout) + sfx;
+        kname = fmt(s2cs_[op.conv]->has_tail ? "s2conv+1x1<%d,%d>" : "s2conv<%d,%d>", s2cs_[op.conv]->Cin, s2cs_[op.conv]->Cout) + sfx;
         break;
       case DetOp::HEAD:
         heads_[op.conv]->launch(view(op.in), B, levels_[op.in2].off, A_, d_anchors_.as<float>(), d_strides_.as<float>(), d_dfl_.as<float>(), out0,
