@@ -1374,16 +1374,19 @@ def test_nms_single_wave_path_equals_general_path(eng32, monkeypatch, nc):
                 assert d["x1"] == boxes[k, 0] and d["y2"] == boxes[k, 3] and d["det_conf"] == scores[k] and d["det_class"] == classes[k]
 
 
+@pytest.mark.parametrize("preset", ["v2", "v1"])
 @pytest.mark.parametrize("size,batch", [(640, 3), (416, 2), (352, 5)])
-def test_stem_block16_equals_unfused_plan_v2(tmp_path, monkeypatch, size, batch):
+def test_stem_block16_equals_unfused_plan_v2(tmp_path, monkeypatch, size, batch, preset):
     """v2's network head in one launch (stem_block16_kernel: stem 3 -> 16, stride-2 conv 16 -> 24, C2f.cv1 from LDS; round 4)
     against the same handle capacity with LITEPI_NO_STEMBLOCK=1 (stem_mfma16 + conv3x3s2_direct+1x1 through HBM).  Both round the
     stem map to fp16 at the same point and walk K in the same order with the same packed fragments, so out0 must agree to the
     last bit -- on whole tiles (640: 160 = 5 x 32 columns) and on partial ones (416 -> 104 = 3.25 x 32, 352 -> 88 = 2.75 x 32,
-    11 x 8 rows)."""
+    11 x 8 rows).  v1's stem_block_kernel (8-channel stem, two pixels per MFMA column) walks the stem's K groups in another order
+    than stem_mfma (rows 0 and 2, then row 1: the LDS bank pairing), so it is compared at the documented fp16 bounds, not bit for bit.
+    Both block kernels choose an interior or a border form of their stem loop per workgroup (round 4)."""
     from litepi import Engine, ncnn_export
     param, binf = str(tmp_path / "d.param"), str(tmp_path / "d.bin")
-    ncnn_export.export_detector(param, binf, "v2", seed=5, cls_bias=-2.0, size=size)
+    ncnn_export.export_detector(param, binf, preset, seed=5, cls_bias=-2.0, size=size)
     imgs = np.random.default_rng(size).integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
     got, names = {}, {}
     for plan in ("fused", "unfused"):
@@ -1400,11 +1403,17 @@ def test_stem_block16_equals_unfused_plan_v2(tmp_path, monkeypatch, size, batch)
             names[plan] = [k["name"] for k in e.profile_read()]
         finally:
             e.close()
-    assert names["fused"][0] == "stem_block16_f16" and names["unfused"][0] == "stem_conv_f16", (names["fused"][:2], names["unfused"][:3])
+    assert names["fused"][0] == ("stem_block16_f16" if preset == "v2" else "stem_block_f16") and names["unfused"][0] == "stem_conv_f16", (names["fused"][:2], names["unfused"][:3])
     assert len(names["unfused"]) == len(names["fused"]) + 1
     d = np.abs(got["fused"] - got["unfused"])
-    print(f"v2 {size} x{batch}: stem_block16 vs stem_conv + conv3x3s2_direct+1x1: max |diff| {d.max():.3g}")
-    assert np.array_equal(got["fused"], got["unfused"]), f"max |diff| {d.max()}"
+    print(f"{preset} {size} x{batch}: {names['fused'][0]} vs stem_conv + conv3x3s2_direct+1x1: max |diff| {d.max():.3g}")
+    if preset == "v2":
+        assert np.array_equal(got["fused"], got["unfused"]), f"max |diff| {d.max()}"
+    else:
+        n8, n16, n32 = (size // 8) ** 2, (size // 16) ** 2, (size // 32) ** 2
+        stride = np.concatenate([np.full(n8, 8.0), np.full(n16, 16.0), np.full(n32, 32.0)]).astype(np.float32)
+        assert np.abs(got["fused"][:, 4] - got["unfused"][:, 4]).max() <= 0.02
+        assert (np.abs(got["fused"][:, :4] - got["unfused"][:, :4]) <= 0.35 * stride + 0.02 * np.abs(got["unfused"][:, :4])).all()
 
 
 def test_v1_split_20x20_modules_vs_layer_plan(tmp_path, monkeypatch):

@@ -22,7 +22,8 @@ def family(name):
     if "s2conv_kernel" in name or "s2lds_kernel" in name:   # both run under the library's profile name s2conv<Cin,Cout>
         m = re.search(r"S2L?Cfg<(\d+), *(\d+)[,>]", name)
         v = [int(m.group(1)), int(m.group(2))] if m else [int(x) for x in re.findall(r"Li(\d+)E", name)][:2]
-        return "s2conv<%d,%d>_f16" % tuple(v)
+        tail = re.search(r"S2LCfg<[^>]*true *>", name) is not None or ("S2LCfg" in name and "Lb1E" in name)   # S2LCfg<.., TAIL>
+        return ("s2conv+1x1<%d,%d>_f16" if tail else "s2conv<%d,%d>_f16") % tuple(v)
     if "sppf_kernel" in name:   # SpCfg<C, CIN, COUT, OSPLIT>: the library's profile name is sppf<Cin,C,Cout>
         m = re.search(r"SpCfg<(\d+), *(\d+), *(\d+)", name)
         v = [int(m.group(i)) for i in (1, 2, 3)] if m else (ints + [0, 0, 0])[:3]

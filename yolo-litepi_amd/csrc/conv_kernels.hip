@@ -1523,6 +1523,9 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
   // (852 -> 522 LDS cycles per workgroup in a simulation of the access pattern).
   const int ky0 = 2 * (g & 1), hh = g >> 1;
   // pair index of this lane's column in tile t, as (row r, pair pp): t advances by 4 tiles = 64 pairs = 1 row + 31 pairs
+  // (an interior and a border form of the loop, chosen per workgroup: the per-pixel map test is 8 of an iteration's ~90 instructions
+  //  and four workgroups in five lie wholly inside the stem map)
+  auto stem_loop = [&](auto interior) {
   int pi = wave * 16 + col;
   int r = pi >= SB_PAIRS ? 1 : 0, pp = pi - r * SB_PAIRS;   // wave * 16 + col < 64 < 2 * SB_PAIRS
   for (int t = wave; t < NTILE; t += 4) {
@@ -1552,12 +1555,14 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1, bf[1], acc, 0, 0, 0);
     const int c = 2 * ppc + (g >> 1);
     if (live && c < SB_SW) {
-      const int sy = 2 * oy0 - 1 + rc, sx = 2 * ox0 - 1 + c;
-      const bool inside = sb_interior || (sy >= 0 && sy < a.H1 && sx >= 0 && sx < a.W1);
       const floatx4 y4 = act4<half_t, ACT_SILU>(acc, sb4);
       // two packed converts, then the mask on the packed words (a select per half was four converts, four selects, two packs)
       const half2v q01 = {(half_t)y4[0], (half_t)y4[1]}, q23 = {(half_t)y4[2], (half_t)y4[3]};
-      const uint32_t m = inside ? 0xffffffffu : 0u;
+      uint32_t m = 0xffffffffu;
+      if constexpr (!decltype(interior)::value) {
+        const int sy = 2 * oy0 - 1 + rc, sx = 2 * ox0 - 1 + c;
+        m = (sy >= 0 && sy < a.H1 && sx >= 0 && sx < a.W1) ? 0xffffffffu : 0u;
+      }
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2*>(st_tile + (rc * SB_LW + c) * 16 + c0 * 2) = u32x2{__builtin_bit_cast(uint32_t, q01) & m, __builtin_bit_cast(uint32_t, q23) & m};
     }
@@ -1566,6 +1571,9 @@ __global__ __launch_bounds__(256) void stem_block_kernel(const StemBlockArgs a) 
     r += 1;
     if (pp >= SB_PAIRS) { pp -= SB_PAIRS; r += 1; }
   }
+  };
+  if (sb_interior) stem_loop(std::true_type{});   // (verified bit-identical to the border form on every workgroup)
+  else stem_loop(std::false_type{});
   // ---- 3. stride-2 3x3 conv from the stem tile (K group = tap: 9 of 12 slots), then the 1x1 tail
   half8 a1[3];
 #pragma unroll
