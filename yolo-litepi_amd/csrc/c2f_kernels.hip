@@ -62,6 +62,9 @@ struct C2fCfg {
   static constexpr int C = C_, NB = NB_, KA = KA_, KB = KB_, COUT = COUT_, MODE = MODE_, KS2 = KS2_;
   static constexpr bool UP = UP_;
   static constexpr bool PERIMG = MODE_ >= 1;   // the tile is the whole image: no halo recompute, a 1-pixel zero ring
+  // MODE -1: the module WITHOUT cv1 -- the launch in front (the stride-2 conv with cv1 as its 1x1 tail, s2lds_kernel) wrote y0 | y1
+  // into the concat buffer; y1 (+ halo) is copied into plane 0.  For n = 2 modules cv1 on the halo-4 region was 2x its work.
+  static constexpr bool XCV1 = MODE_ == -1;
   // waves per workgroup.  c = 16: four, so that two workgroups (LDS allows it) share a CU at one wave each per SIMD with
   // the whole register file -- two independent workgroups drift out of phase and cover each other's epilogues and waits;
   // eight waves under a 128-register cap spilled in every epilogue
@@ -893,7 +896,7 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   auto wslot = [&](int q) { return WS + (q & 1) * CFG::WSLOT; };
   auto stage = [&](int q) {
     if constexpr (AW) {
-      if (q == 0) stage_weights(cx, a.w[C2F_W_CV1], wslot(0), CFG::WB_CV1, CFG::NW);
+      if (q == 0) { if constexpr (!CFG::XCV1) stage_weights(cx, a.w[C2F_W_CV1], wslot(0), CFG::WB_CV1, CFG::NW); }
       else if (q == 2 * NB + 1) stage_weights(cx, a.w[C2F_W_CV2], wslot(q), CFG::WB_CV2, CFG::NW);
       else if (q <= 2 * NB) stage_weights(cx, a.w[C2F_W_A0 + q - 1], wslot(q), CFG::WB_M, CFG::NW);
     }
@@ -938,7 +941,26 @@ __global__ __launch_bounds__(CFG::NW * 64, CFG::WPS) void c2f_kernel(const C2fAr
   C2F_STAMP(2)
 
   // ---- cv1 -> y0 | y1: y1 into plane 0 (whole region); into the concat buffer (tile pixels) whatever cv2 reads from there
-  {
+  if constexpr (CFG::XCV1) {   // (cv1 ran in the launch in front: copy y1 of the region out of the concat buffer, every load in flight)
+    const Rg rg = make_region<CFG>(cx, CFG::e_cv1);
+    constexpr int CG = C / 8, NTHR = CFG::NW * 64, NPC = cdiv_c(LW * CFG::LH * CG, NTHR);
+    u32x4 v[NPC];
+    int dst[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int it = threadIdx.x + j * NTHR;
+      const int pix = it / CG, cg = it - pix * CG;
+      const bool valid = pix < rg.R;
+      int py, px;
+      pix_of(rg, valid ? pix : rg.R - 1, py, px);
+      const int gpix = (cx.n * cx.H + rg.gy0 + py) * cx.W + rg.gx0 + px;
+      v[j] = *reinterpret_cast<const u32x4*>(cat + (size_t)((unsigned)gpix * (unsigned)a.cat_pitch) * 2 + C * 2 + cg * 16);
+      dst[j] = valid ? ((rg.fy0 + py) * LW + rg.fx0 + px) * PS0 + Y1OFF + cg * 16 : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NPC; ++j)
+      if (dst[j] >= 0) *reinterpret_cast<u32x4*>(P0 + dst[j]) = v[j];
+  } else {
     const Rg rg = make_region<CFG>(cx, CFG::e_cv1);
     pw_phase<CFG, CFG::NT1, CFG::CB1, CFG::PT1, CFG::KA, CFG::KB, 0, 0, CFG::UP, AW || CFG::W1_LDS>(
         cx, rg, reinterpret_cast<const char*>(a.src0), a.pitch0, src1, a.pitch1, nullptr, nullptr,
@@ -1502,6 +1524,7 @@ typedef C2fCfg<48, 1, 0, 144, false, 96, 0, 0, 20, 8, false> CfgV2Pan40;    // :
 typedef C2fCfg<24, 1, 96, 48, true, 48, 0, 0, 16> CfgV2Neck80;              // :116 up(F4) | P3 -> C2f(n=1) @80x80
 typedef C2fCfg<96, 1, 0, 192, false, 192, 0, 0, 10, 8, false> CfgV2Bb20;    // :63 C2f(n=1) @20x20, two half-image tiles
 typedef C2fCfg<96, 1, 0, 288, false, 192, 0, 0, 10, 8, false> CfgV2Pan20;   // :145 conv_42 | P5 -> C2f(n=1) @20x20, two half-image tiles
+typedef C2fCfg<16, 2, 0, 32, false, 32, -1, 0, 16> CfgBb80x;     // v1 :22-38 C2f(n=2) @80x80 WITHOUT cv1 (MODE -1: cv1 is the tail of the stride-2 conv in front)
 typedef C2fCfg<64, 1, 0, 256, false, 128, 0, 0, 10, 8, false> CfgPan20h;    // v1's PAN 20x20 module WITHOUT its entry conv on two half-image tiles (A/B:
 typedef C2fCfg<64, 1, 0, 128, false, 128, 0, 0, 10, 8, false> CfgBb20h;     //  LITEPI_C2F_SKIP of the whole-image configurations), and the backbone's
 typedef C2fCfg<24, 2, 0, 48, false, 48, 0, 0, 20, 8, true, 0, false, 8> CfgV2Bb80;   // :13 C2f(n=2) @80x80 (halo 4; 103 KB: ONE workgroup per CU, so eight waves
@@ -1524,6 +1547,7 @@ C2F_NAME(CfgV2Neck80, "c2f<24,1,up96+48>")
 C2F_NAME(CfgV2Bb20, "c2f<96,1,192>")
 C2F_NAME(CfgV2Pan20, "c2f<96,1,288>")
 C2F_NAME(CfgV2Bb80, "c2f<24,2,48>")
+C2F_NAME(CfgBb80x, "c2f<16,2,y0y1>")
 C2F_NAME(CfgPan20h, "c2f<64,1,256>")
 C2F_NAME(CfgBb20h, "c2f<64,1,128>")
 C2F_NAME(CfgV2Bb40, "c2f<48,2,96>")
@@ -1557,7 +1581,7 @@ template <class F> bool for_each_cfg(F&& f) {
          f.template operator()<CfgBb40>() || f.template operator()<CfgV2Neck40>() || f.template operator()<CfgV2Pan40>() ||
          f.template operator()<CfgV2Neck80>() || f.template operator()<CfgV2Bb20>() || f.template operator()<CfgV2Pan20>() ||
          f.template operator()<CfgV2Bb80>() || f.template operator()<CfgV2Bb40>() || f.template operator()<CfgPan20h>() ||
-         f.template operator()<CfgBb20h>();
+         f.template operator()<CfgBb20h>() || f.template operator()<CfgBb80x>();
 }
 struct InfoFn {
   const C2fShape& s; CfgInfo& ci;
@@ -1683,8 +1707,10 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
     }
   };
   const int K1 = s.KA + s.KB;
-  pack_phase(d_w[C2F_W_CV1], *src.cv1, 2 * C, K1, ci.nt1, (K1 + 31) / 32, pw_k(K1));
-  put_bias(d_b[C2F_W_CV1], src.cv1_b, 2 * C);
+  if (s.MODE != -1) {   // (MODE -1: cv1 belongs to the launch in front)
+    pack_phase(d_w[C2F_W_CV1], *src.cv1, 2 * C, K1, ci.nt1, (K1 + 31) / 32, pw_k(K1));
+    put_bias(d_b[C2F_W_CV1], src.cv1_b, 2 * C);
+  }
   const int ntm = ci.ntm;
   for (int k = 0; k < s.NB; ++k) {
     c3_pack(d_w[C2F_W_A0 + 2 * k], *src.a[k], C, C, ntm);
@@ -1696,7 +1722,7 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
   const int K2 = (2 + s.NB) * C;
   pack_phase(d_w[C2F_W_CV2], *src.cv2, s.COUT, K2, nt2, (K2 + 31) / 32, pw_k(K2));
   put_bias(d_b[C2F_W_CV2], src.cv2_b, s.COUT);
-  macs_per_image = ((double)2 * C * K1 + (double)s.NB * 2 * 9 * C * C + (double)s.COUT * K2) * h * w;
+  macs_per_image = ((s.MODE != -1 ? (double)2 * C * K1 : 0.0) + (double)s.NB * 2 * 9 * C * C + (double)s.COUT * K2) * h * w;
   if (s.MODE >= 1) {
     c3_pack(d_w[C2F_W_S2], *src.s2, 2 * C, s.KS2, ci.nt_s2);   // NT_S2: every row tile in one wave
     put_bias(d_b[C2F_W_S2], src.s2_b, 2 * C);

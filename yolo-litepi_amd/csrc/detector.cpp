@@ -1002,6 +1002,58 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         op.flops = 2.0 * macs2;
         op.bytes = ((double)TI2.C * TI2.H * TI2.W + (double)TO2.C * TO2.H * TO2.W) * esd + (double)(l.weight.size() + L[tail].weight.size()) * esd;
         ops_.push_back(op);
+        // ---- A/B (LITEPI_C2F_XCV1=1): the C2f module this cv1 belongs to, WITHOUT its cv1 (C2fShape::MODE -1: y0 | y1 come from the
+        //      concat buffer the launch above fills; for n = 2 modules cv1 on the halo-4 region was twice its work): both bottlenecks +
+        //      cv2 in one launch.  v1's 80x80 backbone module: 56.0 us against 25.0 + 33.1 for the two bottleneck launches, 19 launches,
+        //      +0.1 to +0.5 % end to end: inside the noise, so the two-launch plan stays the default.
+        {
+          C2fMatch m;
+          done[tail] = 0;   // (match_c2f wants its cv1 unclaimed)
+          const bool ok = getenv("LITEPI_C2F_XCV1") && match_c2f(tail, m);
+          done[tail] = 1;
+          if (ok) {
+            C2fShape sh = c2f_shape(m, -1, 0);
+            const int t2 = cinfo[m.cv2].tout;
+            const int Hh = tensors_[t2].H, Ww = tensors_[t2].W;
+            if (C2fLayer::supported(sh, Hh, Ww)) {
+              std::vector<float> w_cv2 = conv_w(m.cv2), w_a[2], w_b[2];
+              C2fLayer::Src src;
+              src.cv2 = &w_cv2; src.cv2_b = &L[m.cv2].bias;
+              for (int q = 0; q < m.nb; ++q) {
+                w_a[q] = conv_w(m.a[q]); w_b[q] = conv_w(m.b[q]);
+                src.a[q] = &w_a[q]; src.a_b[q] = &L[m.a[q]].bias;
+                src.bb[q] = &w_b[q]; src.bb_b[q] = &L[m.b[q]].bias;
+              }
+              c2fs_.emplace_back(new C2fLayer());
+              C2fLayer& cl = *c2fs_.back();
+              cl.name = L[m.a[0]].name + ".." + L[m.cv2].name;
+              cl.build(sh, Hh, Ww, src);
+              C2fIO io;
+              io.src1 = m.t_cat;   // (unused by MODE -1: the module reads the concat buffer)
+              io.cat = m.t_cat;
+              io.out = t2;
+              ensure_buffer(t2);
+              for (size_t q = 2; q < m.ys.size(); ++q) tensors_[m.ys[q]].materialised = getenv("LITEPI_C2F_STORE_ALL") != nullptr || !cl.cv2_from_lds();
+              if (!getenv("LITEPI_C2F_STORE_ALL")) {
+                for (size_t q = 2; q < m.ys.size(); ++q) tensors_[m.ys[q]].in_c2f = true;
+                for (int q = 0; q < m.nb; ++q) {
+                  tensors_[cinfo[m.a[q]].tout].in_c2f = true; tensors_[cinfo[m.b[q]].tout].in_c2f = true;
+                  for (auto& o : L[m.add[q]].outputs) tensors_[get(o)].in_c2f = true;
+                }
+              }
+              c2f_io_.push_back(io);
+              macs_ += cl.macs_per_image;
+              DetOp op2;
+              op2.kind = DetOp::C2F; op2.conv = (int)c2fs_.size() - 1; op2.layer = cl.name;
+              op2.in = m.t_cat; op2.out = t2;
+              op2.flops = 2.0 * cl.macs_per_image;
+              op2.bytes = ((double)tensors_[m.t_cat].C * 0.5 + (double)tensors_[t2].C) * Hh * Ww * esd;
+              ops_.push_back(op2);
+              done[m.cv2] = 1;
+              for (int q = 0; q < m.nb; ++q) done[m.a[q]] = done[m.b[q]] = done[m.add[q]] = 1;
+            }
+          }
+        }
         continue;
       }
       // a stride-2 conv without a folded tail whose shape the c2f machinery covers: s2conv_kernel (LITEPI_NO_S2C=1: off)
