@@ -1195,7 +1195,10 @@ struct S2LCfg {
   static_assert(COUT % (16 * OSPLIT) == 0 && COUTW % (16 * NT) == 0 && NW % CB == 0 && CIN % (8 * KSPLIT) == 0 && LDS_BYTES <= 160 * 1024 && NBLK <= NW,
                 "s2lds: shape (one block per wave: the accumulators live across the passes)");
   static_assert(CB == 1 || KSPLIT == 1, "the packed weights are [channel block][all K steps]: a pass is contiguous only for one block");
-  static_assert(!TAIL || (OSPLIT == 1 && CB == 1 && NT == 2 && COUT == 32), "tail: the workgroup holds all 32 channels of a pixel, 8 per lane");
+  // (NT = 2: a lane's 8 channels are one K group, one K step; NT = 3: its 12 channels are K group g of step 0 and the first half of
+  //  K group g of step 1, whose second half is zero -- the tail's weights are packed to that order, S2ConvLayer::build)
+  static constexpr int TSTEPS = NT == 3 ? 2 : 1;
+  static_assert(!TAIL || (OSPLIT == 1 && CB == 1 && ((NT == 2 && COUT == 32) || (NT == 3 && COUT == 48))), "tail: the workgroup holds every channel of a pixel");
 };
 template <class CFG>
 __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a) {
@@ -1305,12 +1308,13 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a)
   }
   if (has) {
     char* xo = reinterpret_cast<char*>(a.x);
-    half8 w2f[NT];
+    half8 w2f[CFG::TSTEPS][NT];
     floatx4 b2v[NT];
     if constexpr (CFG::TAIL) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        w2f[t] = as_h8(reinterpret_cast<const u32x4*>(a.w[C2F_W_CV1])[t * 64 + cx.lane]);
+#pragma unroll
+        for (int ts = 0; ts < CFG::TSTEPS; ++ts) w2f[ts][t] = as_h8(reinterpret_cast<const u32x4*>(a.w[C2F_W_CV1])[(ts * NT + t) * 64 + cx.lane]);
         b2v[t] = *reinterpret_cast<const floatx4*>(a.b[C2F_W_CV1] + 4 * NT * cx.g + 4 * t);
       }
     }
@@ -1325,12 +1329,21 @@ __global__ __launch_bounds__(CFG::NW * 64, 2) void s2lds_kernel(const C2fArgs a)
       for (int t = 0; t < NT; ++t) v[t] = silu4(acc[t][i], bv[t]);
       half_t hh[4 * NT];
       to_half<NT>(v, hh);
-      if constexpr (CFG::TAIL) {   // out2 = silu(W2 . fp16(silu(conv)) + b2): K = 32 = one step, K group g = this lane's 8 channels
-        half8 bq;
+      if constexpr (CFG::TAIL) {   // out2 = silu(W2 . fp16(silu(conv)) + b2): K group g of step 0 = this lane's first 8 channels, of step 1 its last 4
+        half8 bq[CFG::TSTEPS];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bq[j] = hh[j];
+        for (int j = 0; j < 8; ++j) bq[0][j] = hh[j];
+        if constexpr (CFG::TSTEPS == 2) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) v[t] = silu4(mma16(w2f[t], bq, floatx4{0.f, 0.f, 0.f, 0.f}), b2v[t]);
+          for (int j = 0; j < 8; ++j) bq[1][j] = j < 4 ? hh[8 + j] : (half_t)0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          floatx4 o = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ts = 0; ts < CFG::TSTEPS; ++ts) o = mma16(w2f[ts][t], bq[ts], o);
+          v[t] = silu4(o, b2v[t]);
+        }
         to_half<NT>(v, hh);
       }
       const int chb = os * CFG::COUTW + cb * 16 * NT + 4 * NT * cx.g;
@@ -1347,6 +1360,7 @@ typedef S2LCfg<48, 48, 10, 1, 2> S2L48x48k2;
 // (v1's 32 -> 64 convs as S2LCfg<32, 64, 10, 1, 2>, two passes of 16 channels: 22.9 / 16.2 us against 22.0 / 14.0 for the gather kernel
 //  above -- at Cin 32 the tile copy costs what the gathers cost; they stay on s2conv_kernel)
 typedef S2LCfg<16, 32, 10, 1, 1, true> S2L16x32t;   // v1 model.ncnn.param:19-20 (conv_6 16 -> 32 @80x80 + conv_7 = C2f.cv1 32 -> 32 as its tail)
+typedef S2LCfg<24, 48, 10, 1, 1, true> S2L24x48t;   // v2 :10-11 (conv_8 24 -> 48 @80x80 + conv_9 = C2f.cv1 48 -> 48 as its tail)
 typedef S2LCfg<64, 128, 10, 2, 2> S2L64x128;   // v1's 64 -> 128 convs @20x20 (model.ncnn.param:62, :134) when they do not ride in the whole-image kernels
 typedef S2LCfg<96, 192, 10, 4, 2> S2L96x192;   // :44 (conv_22: 96 -> 192 @20x20): two passes of 48 input channels, four workgroups per tile
 typedef S2LCfg<96, 96, 10, 2, 2> S2L96x96;     // :142 (conv_42: 96 -> 96 @20x20)
@@ -1524,6 +1538,7 @@ typedef C2fCfg<48, 1, 0, 144, false, 96, 0, 0, 20, 8, false> CfgV2Pan40;    // :
 typedef C2fCfg<24, 1, 96, 48, true, 48, 0, 0, 16> CfgV2Neck80;              // :116 up(F4) | P3 -> C2f(n=1) @80x80
 typedef C2fCfg<96, 1, 0, 192, false, 192, 0, 0, 10, 8, false> CfgV2Bb20;    // :63 C2f(n=1) @20x20, two half-image tiles
 typedef C2fCfg<96, 1, 0, 288, false, 192, 0, 0, 10, 8, false> CfgV2Pan20;   // :145 conv_42 | P5 -> C2f(n=1) @20x20, two half-image tiles
+typedef C2fCfg<24, 2, 0, 48, false, 48, -1, 0, 20, 8, true, 0, false, 8> CfgV2Bb80x;   // v2 :13-26 C2f(n=2) @80x80 without cv1 (as CfgBb80x)
 typedef C2fCfg<16, 2, 0, 32, false, 32, -1, 0, 16> CfgBb80x;     // v1 :22-38 C2f(n=2) @80x80 WITHOUT cv1 (MODE -1: cv1 is the tail of the stride-2 conv in front)
 typedef C2fCfg<64, 1, 0, 256, false, 128, 0, 0, 10, 8, false> CfgPan20h;    // v1's PAN 20x20 module WITHOUT its entry conv on two half-image tiles (A/B:
 typedef C2fCfg<64, 1, 0, 128, false, 128, 0, 0, 10, 8, false> CfgBb20h;     //  LITEPI_C2F_SKIP of the whole-image configurations), and the backbone's
@@ -1548,6 +1563,7 @@ C2F_NAME(CfgV2Bb20, "c2f<96,1,192>")
 C2F_NAME(CfgV2Pan20, "c2f<96,1,288>")
 C2F_NAME(CfgV2Bb80, "c2f<24,2,48>")
 C2F_NAME(CfgBb80x, "c2f<16,2,y0y1>")
+C2F_NAME(CfgV2Bb80x, "c2f<24,2,y0y1>")
 C2F_NAME(CfgPan20h, "c2f<64,1,256>")
 C2F_NAME(CfgBb20h, "c2f<64,1,128>")
 C2F_NAME(CfgV2Bb40, "c2f<48,2,96>")
@@ -1581,7 +1597,7 @@ template <class F> bool for_each_cfg(F&& f) {
          f.template operator()<CfgBb40>() || f.template operator()<CfgV2Neck40>() || f.template operator()<CfgV2Pan40>() ||
          f.template operator()<CfgV2Neck80>() || f.template operator()<CfgV2Bb20>() || f.template operator()<CfgV2Pan20>() ||
          f.template operator()<CfgV2Bb80>() || f.template operator()<CfgV2Bb40>() || f.template operator()<CfgPan20h>() ||
-         f.template operator()<CfgBb20h>() || f.template operator()<CfgBb80x>();
+         f.template operator()<CfgBb20h>() || f.template operator()<CfgBb80x>() || f.template operator()<CfgV2Bb80x>();
 }
 struct InfoFn {
   const C2fShape& s; CfgInfo& ci;
@@ -1747,7 +1763,7 @@ static bool s2lds_shape(int cin, int cout, int hout, int wout) {
 }
 bool S2ConvLayer::tail_supported(int cin, int cout, int cout2, int hout, int wout) {
   static const bool off = getenv("LITEPI_NO_S2LDS") != nullptr || getenv("LITEPI_NO_S2TAIL") != nullptr;
-  return !off && cin == 16 && cout == 32 && cout2 == 32 && hout % 10 == 0 && wout % 20 == 0;
+  return !off && ((cin == 16 && cout == 32 && cout2 == 32) || (cin == 24 && cout == 48 && cout2 == 48)) && hout % 10 == 0 && wout % 20 == 0;
 }
 bool S2ConvLayer::supported(int cin, int cout, int hout, int wout) {
   return (cin == 32 && cout == 64 && hout % 20 == 0 && wout % 20 == 0) || s2lds_shape(cin, cout, hout, wout);
@@ -1759,15 +1775,17 @@ void S2ConvLayer::build(int cin, int cout, int hout, int wout, const std::vector
            "s2conv: unsupported shape %d -> %d @%dx%d", cin, cout, hout, wout);
   Cin = cin; Cout = cout; H = hout; W = wout;
   has_tail = w_tail != nullptr;
-  if (has_tail) {   // S2L16x32t: one pass, general K packing (2 groups per tap: 5 steps), two channel tiles; the tail's K groups in plain order
+  if (has_tail) {   // S2L16x32t / S2L24x48t: one pass, general K packing, every channel tile in one block; the tail's K groups follow
+                    // the lanes' channel ownership: 4 NT consecutive channels per lane group g
     lds_staged = true; ksplit = 1;
-    const int G = cin / 8, S = (9 * G + 3) / 4;
-    pack_phase(d_w, w_taps, cout, 9 * cin, 2, S, [&](int s_, int g, int j) {
+    const int G = cin / 8, S = (9 * G + 3) / 4, nt = cout / 16;
+    pack_phase(d_w, w_taps, cout, 9 * cin, nt, S, [&](int s_, int g, int j) {
       const int q = 4 * s_ + gam_of(g);
       return q < 9 * G ? (q / G) * cin + 8 * (q % G) + j : -1;
     });
     put_bias(d_b, &bias, cout);
-    pack_phase(d_w2, *w_tail, cout, cout, 2, 1, [&](int, int g, int j) { return 8 * g + j; });
+    if (nt == 2) pack_phase(d_w2, *w_tail, cout, cout, 2, 1, [&](int, int g, int j) { return 8 * g + j; });
+    else pack_phase(d_w2, *w_tail, cout, cout, 3, 2, [&](int s_, int g, int j) { return s_ == 0 ? 12 * g + j : (j < 4 ? 12 * g + 8 + j : -1); });
     put_bias(d_b2, b_tail, cout);
     return;
   }
@@ -1810,7 +1828,8 @@ void S2ConvLayer::launch(const View& in, const View& out, int N, hipStream_t st)
   a.N = N; a.H = H; a.W = W;
   if (has_tail) {
     a.w[C2F_W_CV1] = d_w2.p; a.b[C2F_W_CV1] = d_b2.as<float>();
-    launch_s2lds<S2L16x32t>(a, N, H, W, st);
+    if (Cin == 16) launch_s2lds<S2L16x32t>(a, N, H, W, st);
+    else launch_s2lds<S2L24x48t>(a, N, H, W, st);
     LP_HIP(hipGetLastError());
     return;
   }

@@ -975,7 +975,15 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
           bool b_feeds_add = false;
           for (int c : canon_consumers[tensors_[tb].name]) b_feeds_add = b_feeds_add || L[c].type == "BinaryOp";
           // (a C2f.cv1 that the whole-C2f launch computes itself is not folded into this conv)
-          if (plain1x1 && !b_feeds_add && !c2f_plain_ok(cs2[0]) && ConvLayer::tail_supported(k, s, tensors_[tout].Cp, tensors_[tb].Cp)) {
+          // (round 4: a stride-2 conv whose 1x1 consumer is the cv1 of a C2f module that can run WITHOUT its cv1 -- C2fShape::MODE -1 --
+          //  keeps that cv1 as its tail on the LDS-staged kernel even though a whole-module launch exists: v2's 80x80 backbone module)
+          bool s2tail = false;
+          if (c2f_on && plain1x1 && s == 2 && !getenv("LITEPI_NO_C2F_XCV1") && tensors_[tout].Cp == 48 &&
+              S2ConvLayer::tail_supported(Cin, tensors_[tout].Cp, tensors_[tb].Cp, tensors_[tb].H, tensors_[tb].W)) {
+            C2fMatch mx;
+            s2tail = match_c2f(cs2[0], mx) && C2fLayer::supported(c2f_shape(mx, -1, 0), tensors_[tb].H, tensors_[tb].W);
+          }
+          if (plain1x1 && !b_feeds_add && (s2tail || (!c2f_plain_ok(cs2[0]) && ConvLayer::tail_supported(k, s, tensors_[tout].Cp, tensors_[tb].Cp)))) {
             tail = cs2[0];
             tmid = tout;
             tout = tb;
@@ -1009,7 +1017,8 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
         {
           C2fMatch m;
           done[tail] = 0;   // (match_c2f wants its cv1 unclaimed)
-          const bool ok = getenv("LITEPI_C2F_XCV1") && match_c2f(tail, m);
+          // (on for v2's module, whose alternative is the whole-module launch with cv1 recomputed on the halo-4 region; opt-in for v1's)
+          const bool ok = (getenv("LITEPI_C2F_XCV1") || (Cout == 48 && !getenv("LITEPI_NO_C2F_XCV1"))) && match_c2f(tail, m);
           done[tail] = 1;
           if (ok) {
             C2fShape sh = c2f_shape(m, -1, 0);
