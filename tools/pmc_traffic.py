@@ -36,7 +36,9 @@ def family(name):
         else:
             v = [int(x) for x in re.findall(r"L[ib](\d+)E", name)]
         C, NB, KA, KB, UP, COUT, MODE, KS2 = (v + [0] * 8)[:8]
-        if MODE >= 1:
+        if MODE == -1:   # the module without its cv1 (C2fShape::MODE -1)
+            src = "y0y1"
+        elif MODE >= 1:
             src = "s2+%d" % KB + (",sppf" if MODE == 2 else "")
         else:
             src = ("up%d+%d" % (KA, KB)) if UP else str(KA + KB)
