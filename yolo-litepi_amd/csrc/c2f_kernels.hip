@@ -1607,17 +1607,18 @@ struct LaunchFn {
   const C2fShape& s; const C2fArgs& a; hipStream_t st;
   template <class CFG> bool operator()() const { return try_launch<CFG>(s, a, st); }
 };
-bool cfg_info(const C2fShape& s, CfgInfo& ci) {
+// the configuration of a shape (build / launch / names: no switches -- a layer that was planned keeps its kernel)
+bool cfg_info(const C2fShape& s, CfgInfo& ci) { return for_each_cfg(InfoFn{s, ci}); }
+// .. and whether the PLANNER may use it (C2fLayer::supported): the A/B switches live here, read at plan time
+bool cfg_enabled(const C2fShape& s, CfgInfo& ci) {
   // (CfgBb80, the n = 2 module on the 80x80 map, is opt-in: its halo-4 recompute of 16-channel layers is VALU work the
   //  two-launch bottleneck plan does not have -- 65-75 us against 59; LITEPI_C2F_BB80=1 enables it for A/B runs)
-  static const bool bb80 = getenv("LITEPI_C2F_BB80") != nullptr;
-  if (!bb80 && s == CfgBb80::shape()) return false;
+  if (!getenv("LITEPI_C2F_BB80") && s == CfgBb80::shape()) return false;
   // (v2's n = 2 backbone modules run as one launch each: 139 us against 150 for the four launches of the 80x80 one -- 145 before
   //  cv2 took y2 / y3 from the planes --, +1.5 % of the pipelined rate; 10-row tiles on the 40x40 map: 74 against 118)
+  if (!cfg_info(s, ci)) return false;
   // A/B switch: LITEPI_C2F_SKIP=<configuration names separated by ';'> keeps those modules on the layer plan
-  const char* skip = getenv("LITEPI_C2F_SKIP");   // (read per call: plan time only; tests switch it inside one process)
-  if (!for_each_cfg(InfoFn{s, ci})) return false;
-  if (skip) {
+  if (const char* skip = getenv("LITEPI_C2F_SKIP")) {
     const std::string list = std::string(";") + skip + ";", key = std::string(";") + ci.name + ";";
     if (list.find(key) != std::string::npos) return false;
   }
@@ -1683,7 +1684,7 @@ static void dump_stamps(const char* file, const std::string& name, size_t nwg, h
 
 bool C2fLayer::supported(const C2fShape& s, int h, int w) {
   CfgInfo ci;
-  if (!cfg_info(s, ci)) return false;
+  if (!cfg_enabled(s, ci)) return false;
   if (h % ci.th != 0 || w % ci.tw != 0) return false;
   if (ci.perimg && (h != ci.th || w != ci.tw)) return false;
   if (s.UP && (h % 2 || w % 2)) return false;
@@ -1694,7 +1695,7 @@ void C2fLayer::build(const C2fShape& s, int h, int w, const Src& src) {
   LP_CHECK(supported(s, h, w), LP_ERR_STATE, "c2f: unsupported shape");
   sh = s; H = h; W = w;
   CfgInfo ci;
-  cfg_info(s, ci);
+  LP_CHECK(cfg_info(s, ci), LP_ERR_STATE, "c2f: no configuration for this shape");
   lds_bytes = ci.lds;
   const int C = s.C;
   auto pw_k = [](int ktot) {
@@ -1940,7 +1941,7 @@ void C2fLayer::launch(const IO& io, int N, hipStream_t st) const {
   }
   a.N = N; a.H = H; a.W = W;
   CfgInfo ci;
-  cfg_info(sh, ci);
+  LP_CHECK(cfg_info(sh, ci), LP_ERR_STATE, "c2f %s: no configuration for this shape", name.c_str());
   a.tiles_x = W / ci.tw; a.tiles_y = H / ci.th;
   static const bool store_all = getenv("LITEPI_C2F_STORE_ALL") != nullptr;   // bisect aid: every y segment goes to the concat buffer
   static const int dbg_flags = getenv("LITEPI_C2F_DEBUG") ? atoi(getenv("LITEPI_C2F_DEBUG")) : 0;   // see Ctx::dbg
