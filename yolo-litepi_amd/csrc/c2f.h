@@ -45,7 +45,8 @@ struct C2fShape {
   int KB = 0;     // cv1 input channels taken from src1
   int UP = 0;     // src0 is half resolution (fused Interp nearest x2)
   int COUT = 0;   // cv2 output channels
-  int MODE = 0;   // 0: C2f; 1: stride-2 3x3 entry conv + C2f (whole image per workgroup); 2: entry conv + C2f + SPPF
+  int MODE = 0;   // 0: C2f; 1: stride-2 3x3 entry conv + C2f (whole image per workgroup); 2: entry conv + C2f + SPPF;
+                  // -1: C2f without its cv1 (y0 | y1 already in the concat buffer: the stride-2 conv in front ran cv1 as its tail)
   int KS2 = 0;    // input channels of the entry conv
   bool operator==(const C2fShape& o) const {
     return C == o.C && NB == o.NB && KA == o.KA && KB == o.KB && UP == o.UP && COUT == o.COUT && MODE == o.MODE && KS2 == o.KS2;
