@@ -1425,6 +1425,42 @@ def test_stem_block16_equals_unfused_plan_v2(tmp_path, monkeypatch, size, batch,
         assert (np.abs(got["fused"][:, :4] - got["unfused"][:, :4]) <= 0.35 * stride + 0.02 * np.abs(got["unfused"][:, :4])).all()
 
 
+@pytest.mark.parametrize("preset", ["v1", "v2"])
+@pytest.mark.parametrize("size,batch", [(640, 3), (416, 2), (352, 5)])
+def test_bottleneck_concat_from_lds_equals_gather_plan(tmp_path, monkeypatch, size, batch, preset):
+    """The 160x160 module's bottleneck + cv2 launch stages the WHOLE stored concat pixel (y0 | y1) with its halo and lets cv2 gather
+    from the tile (the kernel's CL variant, round 4; opt-in with LITEPI_BNECK_CL=1: fewer HBM bytes, but slower -- DESIGN.md section 7)
+    instead of staging y1 and gathering y0 | y1 from global memory again.  Same values into the same MFMAs in the same order: out0
+    must equal the default plan to the last bit, on whole tiles (640:
+    160 = 4 x 40 columns, 10 x 16 or 20 x 8 rows) and partial ones (416 -> 104, 352 -> 88 columns and rows).  The handles are
+    planned for 16 images: the variant is taken where its 16x40 / 8x40 tiles still give the chip a workgroup per CU."""
+    from litepi import Engine, ncnn_export
+    param, binf = str(tmp_path / "d.param"), str(tmp_path / "d.bin")
+    ncnn_export.export_detector(param, binf, preset, seed=9, cls_bias=-2.0, size=size)
+    imgs = np.random.default_rng(size + 1).integers(0, 256, (batch, size, size, 3), dtype=np.uint8)
+    got, names = {}, {}
+    for plan in ("cl", "gather"):
+        if plan == "cl":
+            monkeypatch.setenv("LITEPI_BNECK_CL", "1")
+        else:
+            monkeypatch.delenv("LITEPI_BNECK_CL", raising=False)
+        e = Engine(precision="fp16", max_batch=16, det_input=size)
+        try:
+            e.load_detector(param, binf)
+            got[plan] = e.detect_raw(imgs)
+            e.profile_next(True)
+            e.detect_raw(imgs)
+            names[plan] = [k["name"] for k in e.profile_read()]
+        finally:
+            e.close()
+    cl = [n for n in names["cl"] if n.startswith("bottleneck3x3x2") and ",cl>" in n]
+    assert len(cl) == 1 and names["cl"].index(cl[0]) == 1, names["cl"][:4]
+    assert not any(",cl>" in n for n in names["gather"]) and len(names["gather"]) == len(names["cl"])
+    d = np.abs(got["cl"] - got["gather"])
+    print(f"{preset} {size} x{batch}: {cl[0]} vs {names['gather'][1]}: max |diff| {d.max():.3g}")
+    assert np.array_equal(got["cl"], got["gather"]), f"max |diff| {d.max()}"
+
+
 def test_v1_split_20x20_modules_vs_layer_plan(tmp_path, monkeypatch):
     """The opt-in split of v1's two whole-image 20x20 launches (round 4, LITEPI_C2F_SKIP: the stride-2 convs on the LDS-staged
     kernel s2lds<64,128>, the C2f modules on two half-image tiles c2f<64,1,256> / c2f<64,1,128>, the SPPF on the layer plan) against

@@ -45,7 +45,9 @@ def family(name):
         return "c2f<%d,%d,%s>_f16" % (C, NB, src)
     if "bottleneck_mfma_kernel" in name:   # <T, NT, P1, P2, SEP, T2, SG>: the profiler's name carries <NT,P1,P2,T2,SG>
         v = (ints + [0, 0, 0, 0, 0])[:5]
-        return "bottleneck3x3x2<%d,%d,%d,%d,%d>" % tuple(v) + f16
+        # the trailing template argument CL (the "concat from LDS" variant): Lb1E mangled, `true>` demangled
+        cl = re.search(r"Lb1EEEv", name) is not None or re.search(r", true>\(", name) is not None
+        return "bottleneck3x3x2<%d,%d,%d,%d,%d%s>" % (tuple(v) + (",cl" if cl else "",)) + f16
     if "head_fused_kernel" in name:   # <C3T, PA, PB, NPC, KSA, SLOTF, NRW, OV, A16, NCA>: the profiler appends "a16" for A16 = true
         args = name.split("head_fused_kernel", 1)[1].split(">", 1)[0] if "<" in name else ""
         t = [int(x) for x in re.findall(r"\d+", args)] if args else ints

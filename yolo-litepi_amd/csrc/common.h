@@ -173,6 +173,7 @@ struct BneckArgs {
   void* out3;
   int cat_pitch, out3_pitch, C3, act3;
   int kg, sg;       // global K groups and their K steps (sr = register steps, fixed by NT)
+  int PSA;          // CL variant: bytes per staged pixel (all kg stored groups, padded to an odd number of 16-byte slots)
   unsigned long long* stamps;  // diagnostic only (LITEPI_BNECK_STAMPS=<file>): 16 clock stamps per workgroup
 };
 

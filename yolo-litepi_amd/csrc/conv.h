@@ -63,8 +63,11 @@ struct BottleneckPair {
     int c3 = 0, act = ACT_NONE;  // cv2 output channels (physical), activation
     const std::vector<float>* w = nullptr;  // fp32 [c3][cat_global + C] over physical concat channels
     const std::vector<float>* bias = nullptr;
+    bool in_is_last_stored = false;  // the bottleneck's input is the concat's last stored segment, same buffer and pitch (C2f: y_n)
   };
   int T2 = 0, C3 = 0, act3 = ACT_NONE, kg = 0, sg = 0;
+  bool cl = false;   // "concat from LDS": the tile is staged with every stored segment, cv2 gathers from it (see the kernel)
+  int PSA = 0;       // its pixel pitch in LDS
   // pixel tiles (of 16) per wave in conv_a / conv_b = the kernel's P1 / P2 template arguments
   int p1() const { return (((TH + 2) * (TW + 2) + 15) / 16 + 3) / 4; }
   int p2() const { return ((TH * TW + 15) / 16 + 3) / 4; }
@@ -78,7 +81,9 @@ struct BottleneckPair {
   // out = cv2's output view; the bottleneck output itself is not stored.
   void launch(const View& in, const View& out, int N, hipStream_t st, const View* cat = nullptr) const;
  private:
-  static bool plan(int prec, int c_phys, int h, int w, int batch_hint, size_t extra_lds, bool tail, int& th, int& tw, int& lw, size_t& lds);
+  // kg_cl > 0: try the CL variant with kg_cl staged K groups per pixel first (cl_out says whether it was taken)
+  static bool plan(int prec, int c_phys, int h, int w, int batch_hint, size_t extra_lds, bool tail, int& th, int& tw, int& lw, size_t& lds,
+                   int kg_cl = 0, bool* cl_out = nullptr, int* psa_out = nullptr);
   static bool cv2_shape(int prec, int c_phys, const Cv2& cv2, int& t2, int& kg, int& sg);
 };
 

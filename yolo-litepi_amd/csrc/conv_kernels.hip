@@ -573,11 +573,17 @@ __global__ __launch_bounds__(320, (NT <= 2 ? 4 : ((NT == 4 && (T2 > 0 || sizeof(
 // T2 > 0: the C2f's closing 1x1 conv (cv2 over concat[y0, y1, .., y_last]) runs here as well, T2 = its 16-channel
 // output tiles.  y_last never leaves the registers (the accumulator tile is already a B operand, as in tail_store);
 // the other concat segments are gathered from the concat buffer, 16 B per lane per K step.
+// CL ("concat from LDS", round 4): the input x is the last stored segment of that concat buffer, and a pixel's stored
+// segments are one contiguous piece of a.kg K groups.  The tile is then staged with ALL of them (pitch a.PSA), conv_a reads
+// x at its offset inside the pixel, and cv2 takes its gathered K groups from the tile instead of from global memory.  The
+// halo read of x alone already pulled whole 64 / 128-byte lines, i.e. the neighbouring segments, through L2 (160x160 maps:
+// 2.7 reads of the concat buffer per output pixel); now it is read once, with the halo.
 #define BN_STAMP(k)                                                                                                   \
   if (a.stamps && threadIdx.x == 0)                                                                                 \
     a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = ((k) == 0 || (k) == 15) ? wall_clock64() : clock64();
-template <typename T, int NT, int P1, int P2, bool SEP, int T2 = 0, int SG = 0>
+template <typename T, int NT, int P1, int P2, bool SEP, int T2 = 0, int SG = 0, bool CL = false>
 __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5)) ? 2 : 3)) void bottleneck_mfma_kernel(const BneckArgs a) {
+  static_assert(!CL || (SEP && T2 > 0 && SG > 0), "CL: the staged tile must survive conv_a, and cv2's gather must be the straight-line form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int G = Tr<T>::G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -588,6 +594,9 @@ __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5))
   BN_STAMP(0)
   BN_STAMP(1)
   const int TH = a.TH, TW = a.TW, LW = a.LW, PS = a.PS, S = a.steps, CG = a.CG;
+  const int PSA = CL ? a.PSA : PS;             // bytes per staged pixel
+  const int CGA = CL ? a.kg : CG;              // K groups staged per pixel
+  const int c1off = CL ? (a.kg - CG) * 16 : 0; // x inside the staged pixel
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int IH = TH + 4, IW = TW + 4, H1 = TH + 2, W1 = TW + 2;
   const int R1 = H1 * W1, R2 = TH * TW;
@@ -602,18 +611,21 @@ __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5))
   const int w3frags = T2 > 0 ? T2 * (a.sg + SR) : 0;
   const u32x4* lds_w3 = reinterpret_cast<const u32x4*>(smem + 512 + 2 * wbytes);
   char* tile = smem + 512 + 2 * wbytes + w3frags * 1024;
-  char* tile2 = SEP ? tile + (TH + 4) * LW * PS : tile;  // where the intermediate goes
+  char* tile2 = SEP ? tile + (TH + 4) * LW * PSA : tile;  // where the intermediate goes (pitch PS)
   for (int q = tid; q < S * 4; q += 256) {
     int tap = (int)(((unsigned)q * a.rcp_cg) >> 16);
     const int cg = q - tap * CG;
     tap = tap > 8 ? 8 : tap;
     const int ky = (tap * 21846) >> 16, kx = tap - 3 * ky;
-    lds_toff[q] = (ky * LW + kx) * PS + cg * 16;
+    lds_toff[q] = (ky * LW + kx) * PSA + c1off + cg * 16;
+    if (CL) lds_toff[64 + q] = (ky * LW + kx) * PS + cg * 16;   // conv_b walks the intermediate (S <= 16)
   }
 
   // ---- stage: both weight sets and the halo-2 input tile (see conv3x3_mfma_kernel for the slot map)
-  const int RS = LW * (PS >> 4), PSs = PS >> 4;
+  const int RS = LW * (PSA >> 4), PSs = PSA >> 4;
   const int pcs = (RS + 63) >> 6;
+  constexpr int NPC = CL ? 4 : 3;
+  const int st_pitch = CL ? a.cat_pitch : a.in_pitch;
   const int iy0 = oy0 - 2, ix0 = ox0 - 2;
   const char* zeros = reinterpret_cast<const char*>(a.zeros);
   {
@@ -625,29 +637,29 @@ __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5))
       LP_GLDS16(src + lane, smem + 512 + p * 1024);
     }
     for (int p = wave_s; p < w3frags; p += 4) LP_GLDS16(reinterpret_cast<const u32x4*>(a.w3) + p * 64 + lane, smem + 512 + 2 * wbytes + p * 1024);
-    const char* in_b = reinterpret_cast<const char*>(a.in);
-    if (pcs <= 3) {
+    const char* in_b = reinterpret_cast<const char*>(CL ? a.cat : a.in);
+    if (pcs <= NPC) {
       // rows to the waves, the (<= 3) 64-slot pieces of a row unrolled: what depends on the lane only -- pixel, channel group,
       // validity, byte offset inside the row -- is computed once per piece instead of once per (row, piece); an item is then a
       // scalar row pointer, one 64-bit select and the DMA (the item loop below spends ~60 instructions per item, 9-11 k issue
       // cycles per workgroup on the 80x80 maps: tools/bneck_stamps.py)
-      int voff[3];
-      bool lok[3], inrs[3];
+      int voff[NPC];
+      bool lok[NPC], inrs[NPC];
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
+      for (int pc = 0; pc < NPC; ++pc) {
         const int sl = pc * 64 + lane;
         const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
         const int gx = ix0 + ix;
         inrs[pc] = sl < RS;
-        lok[pc] = gx >= 0 && gx < a.W && ix < IW && cgs < CG;
-        voff[pc] = (ix * a.in_pitch + cgs * G) * (int)sizeof(T);
+        lok[pc] = gx >= 0 && gx < a.W && ix < IW && cgs < CGA;
+        voff[pc] = (ix * st_pitch + cgs * G) * (int)sizeof(T);
       }
       for (int iy = wave_s; iy < IH; iy += 4) {
         const int gy = iy0 + iy;
         const bool rok = gy >= 0 && gy < a.H;
-        const char* rowp = in_b + ((long)(n * a.H + (rok ? gy : 0)) * a.W + ix0) * a.in_pitch * (long)sizeof(T);
+        const char* rowp = in_b + ((long)(n * a.H + (rok ? gy : 0)) * a.W + ix0) * st_pitch * (long)sizeof(T);
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
+        for (int pc = 0; pc < NPC; ++pc) {
           if (pc < pcs) {   // wave-uniform
             const char* src = (rok && lok[pc]) ? rowp + voff[pc] : zeros;
             if (inrs[pc]) LP_GLDS16(src, tile + (iy * RS + pc * 64) * 16);
@@ -659,12 +671,12 @@ __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5))
       for (int it = wave_s; it < nitems; it += 4) {
         const int iy = (int)(((unsigned)it * a.rcp_pcs) >> 16), pc = it - iy * pcs;
         const int gy = iy0 + iy;
-        const char* rowp = in_b + ((long)(n * a.H + gy) * a.W + ix0) * a.in_pitch * (long)sizeof(T);
+        const char* rowp = in_b + ((long)(n * a.H + gy) * a.W + ix0) * st_pitch * (long)sizeof(T);
         const int sl = pc * 64 + lane;
         const int ix = (int)(((unsigned)sl * a.rcp_ps) >> 16), cgs = sl - ix * PSs;
         const int gx = ix0 + ix;
-        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ix < IW && cgs < CG;
-        const char* src = ok ? rowp + (ix * a.in_pitch + cgs * G) * (int)sizeof(T) : zeros;
+        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ix < IW && cgs < CGA;
+        const char* src = ok ? rowp + (ix * st_pitch + cgs * G) * (int)sizeof(T) : zeros;
         if (sl < RS) LP_GLDS16(src, tile + (iy * RS + pc * 64) * 16);
       }
     }
@@ -685,7 +697,7 @@ __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5))
     p = p < R1 ? p : R1 - 1;
     const int py = (int)(((unsigned)p * a.rcp_w1) >> 16), px = p - py * W1;
     pk1[i] = (py << 16) | px;
-    pb1[i] = (py * LW + px) * PS;
+    pb1[i] = (py * LW + px) * PSA;
   }
   floatx4 acc[NT][P1];
 #pragma unroll
@@ -764,7 +776,7 @@ __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5))
 #pragma unroll
     for (int i = 0; i < P2; ++i) acc2[t][i] = floatx4{0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < S; ++s) {
-    const int toff = lds_toff[4 * s + g];
+    const int toff = lds_toff[(CL ? 64 : 0) + 4 * s + g];
     typename Tr<T>::frag af[NT], bf[P2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) af[t] = as_frag<T>(lds_w2[(s * NT + t) * 64 + lane]);
@@ -788,7 +800,7 @@ __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5))
         floatx4 v[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) v[t] = acc2[t][i];
-        const T* xres = SEP ? reinterpret_cast<const T*>(tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PS) + chbase
+        const T* xres = SEP ? reinterpret_cast<const T*>(tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PSA + c1off) + chbase
                             : reinterpret_cast<const T*>(a.in) + eoff(pix, a.in_pitch) + chbase;
         store_lane_at<T, NT, ACT_SILU>(reinterpret_cast<T*>(a.out) + eoff(pix, a.out_pitch) + chbase, xres, chbase, a.C, v, bias2);
       }
@@ -830,10 +842,14 @@ __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5))
         for (int t = 0; t < NT; ++t) xdst[t] = *reinterpret_cast<const typename Tr<T>::quad*>(xp + (chbase + t * 4 < a.C ? chbase + t * 4 : 0));
       }
       const T* catpix = reinterpret_cast<const T*>(a.cat) + eoff(pix, a.cat_pitch);
+      // CL: the same groups from the staged tile (the tile pixel is clamped inside the tile: always a valid address)
+      const char* ldspix = tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PSA;
 #pragma unroll
       for (int s = 0; s < SGN; ++s) {
         const int grp = 4 * s + g;   // K group = 8 (4) stored concat channels of the pixel
-        if (FLAT) {
+        if constexpr (CL) {
+          dst[s] = *reinterpret_cast<const u32x4*>(ldspix + (grp < a.kg ? grp * 16 : 0));
+        } else if (FLAT) {
           // lanes whose group lies past the stored segments re-read group 0 of the SAME pixel (masked where used): the address
           // stays inside the pixel -- group `grp` of the last pixel of the last image would lie past the end of the buffer
           dst[s] = *reinterpret_cast<const u32x4*>(catpix + (grp < a.kg ? grp * G : 0));
@@ -866,7 +882,7 @@ __global__ __launch_bounds__(256, ((NT >= 4 || P1 >= 15 || (NT == 2 && P1 == 5))
         __builtin_amdgcn_sched_barrier(0);   // keep the requests up here (the scheduler sinks loads to their first use)
       }
       // y_last: activation, round to T, add the shortcut, round again (= store_lane_at), kept as the register B operand
-      const T* xres = SEP ? reinterpret_cast<const T*>(tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PS) + chbase
+      const T* xres = SEP ? reinterpret_cast<const T*>(tile + (((pk2[i] >> 16) + 2) * LW + (pk2[i] & 0xffff) + 2) * PSA + c1off) + chbase
                           : reinterpret_cast<const T*>(a.in) + eoff(pix, a.in_pitch) + chbase;
       T yl[NT][4];
 #pragma unroll
@@ -2191,7 +2207,9 @@ bool BottleneckPair::cv2_shape(int prec, int c, const Cv2& cv2, int& t2, int& kg
   return sg <= (prec == LP_FP16 ? 3 : 6);
 }
 
-bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, size_t extra_lds, bool tail, int& th, int& tw, int& lw, size_t& lds) {
+bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, size_t extra_lds, bool tail, int& th, int& tw, int& lw, size_t& lds,
+                          int kg_cl, bool* cl_out, int* psa_out) {
+  if (cl_out) *cl_out = false;
   const int G = prec == LP_FP16 ? 8 : 4;
   if (c % 8 != 0 || c > 64) return false;
   const int nt = ceil_div(c, 16), cg = c / G;
@@ -2204,9 +2222,21 @@ bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, size_t 
   const int cand[6][2] = {{20, 40}, {16, 40}, {10, 20}, {8, 40}, {8, 20}, {4, 20}};
   const int B = batch_hint > 0 ? batch_hint : 1;
   const bool sep = nt == 1;  // separate LDS region for the intermediate (see the kernel's SEP)
+  // CL pass first (the kernel's "concat from LDS" variant: fp16, one channel tile, at most one gathered K step, instantiated for
+  // the 16x40 and 8x40 tiles): taken when a tile keeps two workgroups per CU.  OPT-IN, LITEPI_BNECK_CL=1 (2: the 16x40 tile
+  // whatever its LDS size): it removes the re-reads of the concat buffer and is bit-equal, but the kernel is not traffic-bound --
+  // the larger tile costs a workgroup per CU and 53 -> 67 us (v1) / 91 -> 96 us (v2, 8x40 tiles), DESIGN.md section 7
+  const int cl_mode = getenv("LITEPI_BNECK_CL") ? atoi(getenv("LITEPI_BNECK_CL")) : 0;
+  const bool try_cl = cl_out && psa_out && kg_cl > cg && kg_cl <= 4 && cl_mode > 0 && prec == LP_FP16 && nt == 1 && tail;
+  for (int pass = try_cl ? 0 : 1; pass < 2; ++pass) {
+  const bool clp = pass == 0;
+  const int pssa = clp ? (kg_cl | 1) : pss;   // staged slots per pixel: odd = 16 consecutive pixels on 16 different 16-byte columns
   long best = -1;
   for (auto& cd : cand) {
     const int TH = cd[0], TW = cd[1];
+    if (clp && !((TH == 16 || TH == 8) && TW == 40)) continue;
+    if (clp && cl_mode == 2 && TH != 16) continue;
+    if (clp && cl_mode == 3 && TH != 8) continue;    // (3: the 8x40 tile)
     static const bool no_big = getenv("LITEPI_BNECK_SMALL") != nullptr;  // A/B switch
     if (TH >= 16 && (nt != 1 || no_big)) continue;  // 12 + 10 (15 + 13) pixel tiles per wave: only the single-channel-tile variant has the registers
     if (TH == 10 && nt > 2) continue;               // 5 + 4 pixel tiles per wave: instantiated for one and two channel tiles
@@ -2217,18 +2247,25 @@ bool BottleneckPair::plan(int prec, int c, int h, int w, int batch_hint, size_t 
     if (tail && TH == 4) continue;                  // no cv2 instantiation for the smallest tile
     int l = TW + 4;
     if (cg <= 1) while (l % 16 != 2) ++l;  // one K group per pixel: 16 consecutive pixels x 4 taps conflict-free
-    if (ceil_div(l * pss, 64) > 8) continue;
-    const size_t need = 512 + (size_t)2 * steps * nt * 1024 + extra_lds + (size_t)(TH + 4 + (sep ? TH + 2 : 0)) * l * pss * 16;
+    if (ceil_div(l * pssa, 64) > (clp ? 4 : 8)) continue;
+    const size_t need = 512 + (size_t)2 * steps * nt * 1024 + extra_lds + (size_t)(TH + 4) * l * pssa * 16 + (size_t)(sep ? TH + 2 : 0) * l * pss * 16;
     if (need > 150 * 1024) continue;
+    if (clp && cl_mode != 2 && need > 80 * 1024) continue;
     const long tiles = (long)ceil_div(h, TH) * ceil_div(w, TW);
     const int util = (int)(100.0 * h * w / ((double)tiles * TH * TW));
     // enough workgroups to fill the chip first, then two workgroups per CU, then no idle lanes, then the larger tile
     static const long bn_wgs = getenv("LITEPI_BNECK_WGS") ? atol(getenv("LITEPI_BNECK_WGS")) : 256;
+    if (clp && tiles * B < bn_wgs) continue;   // small batches keep the small tiles of the gather plan (latency: workgroups first)
     const long score = (tiles * B >= bn_wgs ? 8 : tiles * B >= bn_wgs / 2 ? 4 : 0) * 1000L + (need <= 80 * 1024 ? 2000L : 0L) +
                        (util >= 95 ? 500L : util >= 80 ? 250L : 0L) + TH * TW / 10;
     if (score > best) { best = score; th = TH; tw = TW; lw = l; lds = need; }
   }
-  return best >= 0;
+  if (best >= 0) {
+    if (clp) { *cl_out = true; *psa_out = pssa * 16; }
+    return true;
+  }
+  }
+  return false;
 }
 
 bool BottleneckPair::supported(int prec, int impl, int c_phys, int h, int w, int batch_hint, const Cv2* cv2) {
@@ -2254,7 +2291,8 @@ void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, 
     LP_CHECK(cv2_shape(prec, C, *cv2, T2, kg, sg), LP_ERR_GRAPH, "bottleneck %s: cv2 tail shape unsupported", name.c_str());
     extra = (size_t)T2 * (sg + SR) * 1024;
   }
-  LP_CHECK(plan(prec, C, h, w, batch_hint, extra, cv2 != nullptr, TH, TW, LW, lds_bytes), LP_ERR_GRAPH, "bottleneck %d ch on %dx%d: no fused plan", C, h, w);
+  LP_CHECK(plan(prec, C, h, w, batch_hint, extra, cv2 != nullptr, TH, TW, LW, lds_bytes, (cv2 && cv2->in_is_last_stored) ? kg : 0, &cl, &PSA),
+           LP_ERR_GRAPH, "bottleneck %d ch on %dx%d: no fused plan", C, h, w);
   a.name = name; b.name = name;
   a.build(prec, IMPL_MFMA, 3, 1, C, C, ACT_SILU, wa, ba, h, w, batch_hint, true, true);
   b.build(prec, IMPL_MFMA, 3, 1, C, C, ACT_SILU, wb, bb, h, w, batch_hint, true, true);
@@ -2265,8 +2303,10 @@ void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, 
     return m;
   };
   rcp_cg = rcp16(CG, 128);
-  rcp_ps = rcp16(PS / 16, 512);
-  rcp_pcs = rcp16(ceil_div(LW * (PS / 16), 64), 1024);
+  const int st_slots = (cl ? PSA : PS) / 16;   // slots per staged pixel
+  rcp_ps = rcp16(st_slots, 512);
+  rcp_pcs = rcp16(ceil_div(LW * st_slots, 64), 1024);
+  LP_CHECK(!cl || steps <= 16, LP_ERR_STATE, "bottleneck CL: tap table too long");
   rcp_w1 = rcp16(TW + 2, 1024);
   rcp_tw = rcp16(TW, 1024);
   LP_CHECK((TH + 2) * (TW + 2) <= p1() * 4 * 16 && TH * TW <= p2() * 4 * 16, LP_ERR_STATE, "bottleneck tile exceeds the kernel's pixel-tile budget");
@@ -2310,6 +2350,14 @@ void BottleneckPair::build(int prec_, int c_phys, const std::vector<float>& wa, 
 template <typename T, int NT, int P1, int P2, int T2, int SG>
 static void launch_bneck_sg(const BneckArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   constexpr bool SEP = NT == 1;
+  if constexpr (NT == 1 && T2 > 0 && SG == 1 && sizeof(T) == 2 && (P1 == 12 || P1 == 7)) {
+    if (a.PSA > 0) {   // the CL variant (BottleneckPair::plan)
+      set_max_dynamic_lds(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2, SG, true>), 160 * 1024);
+      LP_LAUNCH((bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2, SG, true>), grid, dim3(256), lds, st, a);
+      return;
+    }
+  }
+  LP_CHECK(a.PSA == 0, LP_ERR_STATE, "bottleneck: no CL kernel for this shape");
   set_max_dynamic_lds(reinterpret_cast<const void*>(bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2, SG>), 160 * 1024);
   LP_LAUNCH((bottleneck_mfma_kernel<T, NT, P1, P2, SEP, T2, SG>), grid, dim3(256), lds, st, a);
 }
@@ -2372,6 +2420,13 @@ void BottleneckPair::launch(const View& in, const View& out, int N, hipStream_t 
     k.w3 = d_w3.p; k.b3 = d_b3.as<float>(); k.cat = cat->base; k.cat_pitch = cat->pitch;
     k.out3 = out.base; k.out3_pitch = out.pitch; k.C3 = C3; k.act3 = act3; k.kg = kg; k.sg = sg;
     k.out = nullptr;
+    if (cl) {
+      const size_t es = prec == LP_FP16 ? 2 : 4;
+      LP_CHECK(reinterpret_cast<const char*>(in.base) == reinterpret_cast<const char*>(cat->base) + (size_t)(kg * (prec == LP_FP16 ? 8 : 4) - C) * es &&
+                   in.pitch == cat->pitch,
+               LP_ERR_STATE, "bottleneck %s: planned with the input as the concat's last stored segment, launched with another view", name.c_str());
+      k.PSA = PSA;
+    }
   } else {
     LP_CHECK(out.C >= C, LP_ERR_STATE, "bottleneck: output view too narrow");
   }

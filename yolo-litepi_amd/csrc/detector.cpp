@@ -904,6 +904,16 @@ void Detector::load(const std::string& param_path, const std::string& bin_path) 
                     const int glob = tensors_[tfinal].off - TO.off;
                     if (!feeds_add && glob > 0 && glob + TI.Cp == TO.Cp && tensors_[t3].segs.size() == 1) {
                       cv2.cat_global = glob; cv2.c3 = tensors_[t3].Cp; cv2.act = fused_act[c2[0]];
+                      // (C2f: the bottleneck's input y_n sits right in front of y_last in the concat buffer)
+                      {
+                        int bi = TI.buf, oi = TI.off;   // storage of the input: a Slice output is a view of its parent's segment (view())
+                        if (TI.parent >= 0) {
+                          const Tensor& P = tensors_[TI.parent];
+                          oi = P.off; bi = P.buf;
+                          for (int k2 = 0; k2 < TI.parent_seg; ++k2) oi += round_up(P.segs[k2], 8);
+                        }
+                        cv2.in_is_last_stored = bi >= 0 && bi == TO.buf && oi == TO.off + glob - TI.Cp;
+                      }
                       if (BottleneckPair::supported(prec_, impl_, TI.Cp, TI.H, TI.W, maxB_, &cv2)) {
                         jc = c2[0]; tcat = tO;
                         const int cin3 = l3.in_ch, cout3 = l3.ipar(0);
@@ -1422,7 +1432,8 @@ void Detector::forward(const uint8_t* imgs, int B, const ImgGeom* geom, float co
         }
         {  // one name per kernel instantiation <NT, P1, P2, T2, SG> (what rocprofv3 lists as separate kernels)
           const BottleneckPair& bp = *bnecks_[op.conv];
-          kname = fmt("bottleneck3x3x2<%d,%d,%d,%d,%d>", bp.NT, bp.p1(), bp.p2(), bp.T2, (bp.T2 > 0 && prec_ == LP_FP16) ? bp.sg : 0) + sfx;
+          kname = fmt("bottleneck3x3x2<%d,%d,%d,%d,%d%s>", bp.NT, bp.p1(), bp.p2(), bp.T2, (bp.T2 > 0 && prec_ == LP_FP16) ? bp.sg : 0,
+                      bp.cl ? ",cl" : "") + sfx;
         }
         break;
       case DetOp::DWCONV:
